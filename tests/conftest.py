@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are skipped (not failed) where no GPU is visible, so a plain
+    `pytest tests/` works in the CPU container; with a GPU they must run through
+    the HIP library (the product path raises if it is missing)."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def assert_params_close(actual, desired, lr, nsteps, tight=1e-6, frac_tight=0.999):
+    """Post-Adam parameters.  Adam's update lr*m/(sqrt(v)+eps) is ill-conditioned
+    for elements whose gradient is at rounding-noise level (|g| ~ 1e-8: a 1e-10
+    reassociation difference moves the update by ~1 % of lr), so the check is
+    two-tier: >= 99.9 % of the elements agree to `tight`, and every element
+    agrees to 5 % of the total distance Adam can move it (lr * nsteps)."""
+    a = np.asarray(actual, dtype=np.float64).ravel()
+    d = np.asarray(desired, dtype=np.float64).ravel()
+    err = np.abs(a - d)
+    assert err.max() <= 0.05 * lr * nsteps + tight, f"max err {err.max():.3e}"
+    assert (err <= tight).mean() >= frac_tight, f"only {(err <= tight).mean():.5f} within {tight}"

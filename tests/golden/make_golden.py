@@ -1,0 +1,326 @@
+#!/usr/bin/env python3
+"""
+Generates tests/golden/*.npz by running the REFERENCE's own code
+(/root/reference/backend/{model,training,data}.py) in the build container.
+
+Run (container only — /root/reference does not exist on the GPU box, and
+nothing under tests/ reads it at test time):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Only inputs and expected outputs are written (data); no reference source is
+copied.  The fetching constructors (`from_pretrained`, `load_dataset`) are
+bypassed with `__new__` + `nn.Module.__init__`, and every arithmetic line of
+the reference (`AveragePoolingTower.forward/_mean_pooling`, `TwoTowersModel.
+encode_*`, `TripletLoss`, `training.train_epoch`, `TripletDataLoader.
+create_triplets`) is executed unchanged.
+
+Version note: fixtures come from torch {torch.__version__} / transformers as
+installed here; the reference pins torch 2.7.1 / transformers 4.52.4.  The ops
+on the path (embedding, mul, sum, clamp, div, normalize, linear, relu,
+cosine_similarity, mean, Adam) are stable across those versions.
+"""
+
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/backend")
+sys.dont_write_bytecode = True
+
+import model as ref_model  # noqa: E402  (reference)
+import training as ref_training  # noqa: E402  (reference)
+import data as ref_data  # noqa: E402  (reference)
+
+from oracle import two_towers_oracle as orc  # noqa: E402  (only for the closed-form / seeded INPUT generators)
+
+torch.set_num_threads(1)  # deterministic reduction order for the fixtures
+
+
+class _EmbedOnly(torch.nn.Module):
+    """`embed` encoder mode: pretrained model reduced to the word-embedding table."""
+
+    def __init__(self, table):
+        super().__init__()
+        self.emb = torch.nn.Embedding.from_pretrained(table.clone(), freeze=True)
+
+    @property
+    def device(self):
+        return self.emb.weight.device
+
+    def forward(self, input_ids=None, **kw):
+        return (self.emb(input_ids),)
+
+
+class _StubTokenizer:
+    """Returns prepared int64 tensors for a tag string (texts[0])."""
+
+    def __init__(self):
+        self.registry = {}
+
+    def __call__(self, texts, **kw):
+        ids, mask = self.registry[texts[0]]
+        assert len(texts) == ids.shape[0]
+        return {"input_ids": ids.clone(), "attention_mask": mask.clone()}
+
+
+def build_ref_tower(pretrained, tok, D, P, w1, b1, w2, b2):
+    t = ref_model.AveragePoolingTower.__new__(ref_model.AveragePoolingTower)
+    torch.nn.Module.__init__(t)
+    t.tokenizer = tok
+    t.pretrained_model = pretrained
+    t.embedding_dim = D
+    for p in t.pretrained_model.parameters():
+        p.requires_grad = False
+    t.projection = torch.nn.Sequential(torch.nn.Linear(D, P), torch.nn.ReLU(), torch.nn.Linear(P, P))
+    with torch.no_grad():
+        t.projection[0].weight.copy_(w1)
+        t.projection[0].bias.copy_(b1)
+        t.projection[2].weight.copy_(w2)
+        t.projection[2].bias.copy_(b2)
+    return t
+
+
+def build_ref_model(table, params, tok):
+    D = table.shape[1]
+    P = params["query_tower.projection.0.bias"].shape[0]
+    m = ref_model.TwoTowersModel.__new__(ref_model.TwoTowersModel)
+    torch.nn.Module.__init__(m)
+    for tower in ("query_tower", "document_tower"):
+        k = tower + ".projection."
+        setattr(
+            m,
+            tower,
+            build_ref_tower(
+                _EmbedOnly(table), tok, D, P,
+                params[k + "0.weight"], params[k + "0.bias"], params[k + "2.weight"], params[k + "2.bias"],
+            ),
+        )
+    return m
+
+
+def trainable_state(m):
+    return {k: v.detach().clone() for k, v in m.state_dict().items() if ".projection." in k}
+
+
+def np_(x):
+    return x.detach().cpu().numpy()
+
+
+def register_batch(tok, batch, tag):
+    names = []
+    for role, (ids, mask) in zip("qpn", batch):
+        key = f"{tag}:{role}"
+        tok.registry[key] = (ids, mask)
+        names.append([key] * ids.shape[0])
+    return tuple(names)
+
+
+def full_step_fixture(name, table, batches, params, margin, lr):
+    """Reference forward + TripletLoss + backward on batch 0, then reference
+    train_epoch over all batches with torch.optim.Adam(model.parameters(), lr)."""
+    tok = _StubTokenizer()
+    out = {"table": np_(table), "margin": np.float64(margin), "lr": np.float64(lr), "n_batches": np.int64(len(batches))}
+    for k, v in params.items():
+        out["init/" + k] = np_(v)
+
+    # --- single forward/backward on batch 0 through the reference classes
+    m = build_ref_model(table, params, tok)
+    crit = ref_model.TripletLoss(margin=margin)
+    texts = [register_batch(tok, b, f"b{i}") for i, b in enumerate(batches)]
+    for i, b in enumerate(batches):
+        for role, (ids, mask) in zip("qpn", b):
+            out[f"batch{i}/ids_{role}"] = np_(ids)
+            out[f"batch{i}/mask_{role}"] = np_(mask)
+    tq, tp, tn = texts[0]
+    q = m.encode_queries(tq)
+    p = m.encode_documents(tp)
+    n = m.encode_documents(tn)
+    for t in (q, p, n):
+        t.retain_grad()
+    loss = crit(q, p, n)
+    loss.backward()
+    out["fwd/q"], out["fwd/p"], out["fwd/n"] = np_(q), np_(p), np_(n)
+    out["fwd/loss"] = np_(loss)
+    out["fwd/pos_dist"] = np_(crit.cosine_distance(q, p))
+    out["fwd/neg_dist"] = np_(crit.cosine_distance(q, n))
+    out["bwd/dq"], out["bwd/dp"], out["bwd/dn"] = np_(q.grad), np_(p.grad), np_(n.grad)
+    for k, v in m.named_parameters():
+        if v.requires_grad:
+            out["grad/" + k] = np_(v.grad)
+    # pooled-normalised intermediates via the reference's own lines (model.py:51-56)
+    for role, (ids, mask) in zip("qpn", batches[0]):
+        tower = m.query_tower if role == "q" else m.document_tower
+        with torch.no_grad():
+            o = tower.pretrained_model(input_ids=ids, attention_mask=mask)
+        pooled = tower._mean_pooling(o, mask)
+        out[f"fwd/pooled_{role}"] = np_(torch.nn.functional.normalize(pooled, p=2, dim=1))
+
+    # --- reference train_epoch over all batches, fresh model
+    m2 = build_ref_model(table, params, tok)
+    opt = torch.optim.Adam(m2.parameters(), lr=lr)
+    losses = []
+
+    class _Spy(ref_model.TripletLoss):
+        def forward(self, a, p_, n_):
+            l = super().forward(a, p_, n_)
+            losses.append(float(l.detach()))
+            return l
+
+    avg = ref_training.train_epoch(m2, texts, _Spy(margin=margin), opt, log_wandb=False)
+    out["epoch/avg_loss"] = np.float64(avg)
+    out["epoch/loss_trace"] = np.array(losses, dtype=np.float64)
+    for k, v in trainable_state(m2).items():
+        out["final/" + k] = np_(v)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: loss0={float(loss):.9f} avg={avg:.9f} trace={losses}")
+    return out
+
+
+def g_kat0():
+    table, batch, params, margin = orc.kat0_inputs()
+    return full_step_fixture("kat0.npz", table, [batch, batch, batch], params, margin, lr=1e-3)
+
+
+def g_step_mid():
+    """Mid-size seeded case: ragged lengths, B not a multiple of any tile, 3 distinct batches."""
+    V, D, P, B, S = 500, 48, 40, 33, 17
+    table = orc.synthetic_table(V, D, seed=11) * 50.0  # O(1) entries
+    params = orc.init_params(D, P, seed=12)
+    batches = [orc.synthetic_batch(B, S, V, seed=100 + i, ragged=True) for i in range(3)]
+    return full_step_fixture("step_mid.npz", table, batches, params, margin=0.3, lr=1e-3)
+
+
+def g_step_minilm_shape():
+    """MiniLM-shaped D=384, P=64 (BASELINE configs[0] dims), small V/B so the file stays small."""
+    V, D, P, B, S = 300, 384, 64, 16, 24
+    table = orc.synthetic_table(V, D, seed=21) * 50.0
+    params = orc.init_params(D, P, seed=22)
+    batches = [orc.synthetic_batch(B, S, V, seed=200 + i, ragged=True) for i in range(2)]
+    return full_step_fixture("step_d384.npz", table, batches, params, margin=0.3, lr=1e-3)
+
+
+def g_pool_edges():
+    """K1 edge cases through the reference's `_mean_pooling` + F.normalize:
+    ragged prefix masks, S=1-long row, an all-padding row (clamp 1e-9 path ->
+    zero vector -> 1e-12 normalise path), a non-prefix (holey) mask, repeated ids."""
+    g = torch.Generator().manual_seed(5)
+    V, D, B, S = 97, 24, 7, 9
+    table = torch.randn(V, D, generator=g)
+    ids = torch.randint(0, V, (B, S), generator=g)
+    lens = torch.tensor([9, 1, 0, 5, 9, 3, 2])
+    mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+    mask[4] = torch.tensor([1, 0, 1, 1, 0, 0, 1, 0, 1])  # holey mask
+    ids[5] = 13  # same row repeated
+    t = ref_model.AveragePoolingTower.__new__(ref_model.AveragePoolingTower)
+    emb = torch.nn.functional.embedding(ids, table)
+    pooled = ref_model.AveragePoolingTower._mean_pooling(t, (emb,), mask)
+    out = torch.nn.functional.normalize(pooled, p=2, dim=1)
+    np.savez_compressed(
+        os.path.join(HERE, "pool_edges.npz"),
+        table=np_(table), ids=np_(ids), mask=np_(mask), hidden=np_(emb), pooled=np_(pooled), out=np_(out),
+    )
+    print("pool_edges.npz: row2 (all pad) =", out[2, :3].tolist())
+
+
+def g_loss_edges():
+    """K3 edge cases through the reference TripletLoss: a zero anchor row and a
+    zero negative row (cosine eps 1e-8 clamp path), inactive hinge rows, P not a
+    multiple of 64."""
+    g = torch.Generator().manual_seed(6)
+    B, P = 11, 37
+    q = torch.randn(B, P, generator=g)
+    p = torch.randn(B, P, generator=g)
+    n = torch.randn(B, P, generator=g)
+    q[3] = 0
+    n[5] = 0
+    p[7] = q[7] * 2.0  # pos_dist 0 -> inactive at margin 0.3 if neg far
+    n[7] = -q[7]
+    q[8] = q[8] * 1e-10  # tiny-norm anchor: below eps
+    crit = ref_model.TripletLoss(margin=0.3)
+    qq, pp, nn_ = (t.clone().requires_grad_(True) for t in (q, p, n))
+    loss = crit(qq, pp, nn_)
+    loss.backward()
+    np.savez_compressed(
+        os.path.join(HERE, "loss_edges.npz"),
+        q=np_(q), p=np_(p), n=np_(n), margin=np.float64(0.3), loss=np_(loss),
+        pos_dist=np_(crit.cosine_distance(q, p)), neg_dist=np_(crit.cosine_distance(q, n)),
+        dq=np_(qq.grad), dp=np_(pp.grad), dn=np_(nn_.grad),
+    )
+    print("loss_edges.npz: loss =", float(loss))
+
+
+def g_bert_mode():
+    """`bert` encoder mode on a tiny locally-built BertConfig (no fetch): the
+    reference forward with a real BertModel between gather and pool.  The fixture
+    stores the encoder's last_hidden_state (the dense [B,S,D] input of the pool
+    kernel) and the tower output."""
+    from transformers import BertConfig, BertModel
+
+    torch.manual_seed(7)
+    cfg = BertConfig(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=4,
+                     intermediate_size=64, max_position_embeddings=32)
+    bert = BertModel(cfg).eval()
+    D, P, B, S = 32, 16, 5, 12
+    params = orc.init_params(D, P, seed=31)
+    g = torch.Generator().manual_seed(8)
+    ids = torch.randint(0, 120, (B, S), generator=g)
+    lens = torch.tensor([12, 7, 1, 9, 4])
+    mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+    ids = ids * mask
+    tok = _StubTokenizer()
+    tok.registry["x"] = (ids, mask)
+    k = "query_tower.projection."
+    t = build_ref_tower(bert, tok, D, P, params[k + "0.weight"], params[k + "0.bias"], params[k + "2.weight"], params[k + "2.bias"])
+    out = t(["x"] * B)
+    with torch.no_grad():
+        hidden = bert(input_ids=ids, attention_mask=mask)[0]
+    np.savez_compressed(
+        os.path.join(HERE, "bert_mode.npz"),
+        ids=np_(ids), mask=np_(mask), hidden=np_(hidden), out=np_(out),
+        w1=np_(params[k + "0.weight"]), b1=np_(params[k + "0.bias"]), w2=np_(params[k + "2.weight"]), b2=np_(params[k + "2.bias"]),
+    )
+    print("bert_mode.npz: out[0,:3] =", out[0, :3].tolist())
+
+
+def g_triplets():
+    """`TripletDataLoader.create_triplets` (data.py:113-137) on fake items with
+    seeded `random`: expected negative index per item for several seeds."""
+    dl = ref_data.TripletDataLoader.__new__(ref_data.TripletDataLoader)
+    out = {}
+    for case, (n_items, n_q, seed) in enumerate(((8, 3, 0), (32, 5, 1), (64, 40, 2), (5, 2, 3))):
+        rq = random.Random(1000 + case)
+        qids = [rq.randrange(n_q) for _ in range(n_items)]
+        if len(set(qids)) == 1:
+            qids[0] = (qids[0] + 1) % n_q
+        batch = [{"query": f"q{qids[i]}", "positive": f"doc{i}", "query_id": qids[i]} for i in range(n_items)]
+        random.seed(seed)
+        queries, positives, negatives = dl.create_triplets(batch)
+        neg_idx = [int(s[3:]) for s in negatives]
+        assert positives == [f"doc{i}" for i in range(n_items)]
+        out[f"case{case}/query_ids"] = np.array(qids, dtype=np.int64)
+        out[f"case{case}/seed"] = np.int64(seed)
+        out[f"case{case}/neg_idx"] = np.array(neg_idx, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "triplets.npz"), **out)
+    print("triplets.npz written")
+
+
+if __name__ == "__main__":
+    r = g_kat0()
+    g_step_mid()
+    g_step_minilm_shape()
+    g_pool_edges()
+    g_loss_edges()
+    g_bert_mode()
+    g_triplets()
+    with open(os.path.join(HERE, "VERSIONS.txt"), "w") as f:
+        import transformers
+
+        f.write(f"torch {torch.__version__}\ntransformers {transformers.__version__}\nnumpy {np.__version__}\n")
+        f.write("reference pins: torch 2.7.1, transformers 4.52.4 (backend/uv.lock)\n")

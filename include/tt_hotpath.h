@@ -1,0 +1,273 @@
+/*
+ * tt_hotpath.h — C ABI of the MI355X (gfx950) two-tower triplet hot path.
+ *
+ * Drop-in boundary.  The reference (freemvmt/two-towers-overlords) is pure Python
+ * and has no FFI of its own; its boundary for this path is the class surface of
+ * backend/model.py and backend/training.py.  This header is the C ABI *under*
+ * that surface: each entry point replaces the torch op sequence of the reference
+ * lines it cites (paths relative to the reference repo).  The Python host side
+ * (two-towers-overlords_amd/{model,training}.py) mirrors the reference classes
+ * and binds these symbols with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     marked host; the caller (PyTorch) owns every buffer; nothing is retained
+ *     after the call returns except inside an explicit tt_engine handle.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *     the null stream); no call synchronises the device except
+ *     tt_engine_read_stats and the create/destroy pairs.
+ *   - return value: 0 = TT_OK, otherwise a tt_status (negative = argument error
+ *     detected on the host before any launch, positive = hipError_t).  No C++
+ *     exception crosses the boundary, nothing calls exit().
+ *   - row-major fp32 everywhere; token ids / masks are int32 or int64 (the HF
+ *     tokenizer's int64 tensors are consumed as they are: backend/model.py:43-48).
+ *   - re-entrant, no global mutable state; one engine handle per device/rank.
+ */
+#ifndef TT_HOTPATH_H
+#define TT_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TT_ABI_VERSION 1
+
+typedef void* tt_stream_t; /* hipStream_t */
+
+typedef enum {
+  TT_OK = 0,
+  TT_ERR_NULL_POINTER = -1,
+  TT_ERR_BAD_SHAPE = -2,
+  TT_ERR_BAD_DTYPE = -3,
+  TT_ERR_ALIGNMENT = -4,
+  TT_ERR_WORKSPACE = -5,
+  TT_ERR_BAD_HANDLE = -6,
+  TT_ERR_UNSUPPORTED = -7
+} tt_status;
+
+/* integer element widths accepted for ids / masks */
+#define TT_I32 4
+#define TT_I64 8
+
+int tt_abi_version(void);
+/* Static string for a tt_status / hipError_t value (host pointer, never freed). */
+const char* tt_status_string(int status);
+
+/* ------------------------------------------------------------------------- */
+/* K1 — token-embedding gather + masked mean-pool + L2 normalise             */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * out[n,:] = normalize( sum_s w[n,s] * table[ids[n,s],:] / max(sum_s w[n,s], 1e-9) ), eps 1e-12
+ *
+ * Replaces, in `embed` encoder mode, backend/model.py:51-56:
+ *   output = self.pretrained_model(**tokens)            (word-embedding gather)
+ *   pooled = self._mean_pooling(output, attention_mask) (model.py:63-72)
+ *   pooled = F.normalize(pooled, p=2, dim=1)
+ * without materialising the [N,S,D] tensor.
+ *
+ *   table [V,D] f32, 16-byte aligned, D % 4 == 0
+ *   ids   [N,S] int32 or int64 (ids_dtype = TT_I32 / TT_I64)
+ *   w:    mask  [N,S] int32/int64 (mask_dtype) attention mask, any 0/1 pattern
+ *         (values are cast to float as the reference does, so weights other
+ *         than 0/1 are honoured), or, if mask == NULL, lens [N] int32 prefix
+ *         lengths (w = s < lens[n]), or all ones if both are NULL.
+ *   out   [N,D] f32
+ *   oob_flag: optional int32[1]; set to 1 if an id outside [0,V) is met.  Such
+ *         ids are clamped into range, so the kernel never reads outside `table`.
+ */
+int tt_gather_pool_norm_f32(const float* table, const void* ids, int ids_dtype,
+                            const void* mask, int mask_dtype, const int32_t* lens,
+                            float* out, int64_t N, int S, int D, int64_t V,
+                            int32_t* oob_flag, tt_stream_t stream);
+
+/*
+ * Same pooling + normalisation over dense hidden states [N,S,D] (the `bert`
+ * encoder mode: the frozen encoder of backend/model.py:51-52 is run by stock
+ * PyTorch-ROCm, its last_hidden_state is pooled here).  Replaces
+ * backend/model.py:55-56,63-72.
+ */
+int tt_pool_norm_dense_f32(const float* hidden, const void* mask, int mask_dtype,
+                           const int32_t* lens, float* out, int64_t N, int S, int D,
+                           tt_stream_t stream);
+
+/*
+ * Plain row gather out[t,:] = table[ids[t],:] for t < n_tokens — the
+ * materialised form of backend/model.py:51-52 (`embed` mode).  Used to prove
+ * the gather indices bit-exact, and by callers that need token embeddings.
+ */
+int tt_embed_gather_f32(const float* table, const void* ids, int ids_dtype, float* out,
+                        int64_t n_tokens, int D, int64_t V, int32_t* oob_flag,
+                        tt_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* K2 — per-tower projection Linear(D,P) -> ReLU -> Linear(P,P), fp32 MFMA     */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * H = relu(X W1^T + b1),  Out = H W2^T + b2.     Replaces backend/model.py:33-38,59.
+ *   X [M,D], W1 [P,D], b1 [P], W2 [P,P], b2 [P], H [M,P] (saved for backward), Out [M,P]
+ * Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): each output is a k-ordered fmaf chain.
+ */
+int tt_proj_fwd_f32(const float* X, const float* W1, const float* b1, const float* W2,
+                    const float* b2, float* H, float* Out, int64_t M, int D, int P,
+                    tt_stream_t stream);
+
+/* Bytes of scratch tt_proj_bwd_f32 needs for (M, D, P). */
+size_t tt_proj_bwd_workspace_bytes(int64_t M, int D, int P);
+
+/*
+ * Backward of the projection for the parameters only (the tower input does not
+ * require grad: the encoder is frozen, backend/model.py:29-30,51).  Replaces
+ * what loss.backward() (backend/training.py:50) does through model.py:33-38:
+ *   dW2 = dOut^T H, db2 = sum_m dOut, dH = (dOut W2) * [H > 0],
+ *   dW1 = dH^T X,   db1 = sum_m dH
+ * accumulate != 0 adds into dW1/db1/dW2/db2 (the document tower is called for
+ * positives and negatives, backend/training.py:41-42), else overwrites.
+ * workspace: tt_proj_bwd_workspace_bytes() bytes, 16-byte aligned.
+ */
+int tt_proj_bwd_f32(const float* dOut, const float* X, const float* H, const float* W2,
+                    float* dW1, float* db1, float* dW2, float* db2, void* workspace,
+                    size_t workspace_bytes, int accumulate, int64_t M, int D, int P,
+                    tt_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* K3 — cosine-distance triplet loss, forward + gradient                      */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * pos_dist = 1 - cos(q,p), neg_dist = 1 - cos(q,n) (F.cosine_similarity, eps 1e-8),
+ * loss = mean_b relu(pos_dist - neg_dist + margin).   Replaces backend/model.py:132-145.
+ * If dq/dp/dn are non-NULL also writes grad_scale * d(sum_b hinge_b)/d{q,p,n}
+ * (grad_scale = 1/B reproduces loss.backward(); 1/(B*k) gradient accumulation over
+ * k batches, backend/training.py:93; 1/B_global data-parallel shards).
+ *   q,p,n [B,P]; loss [1]; pos_dist,neg_dist [B] (may be NULL); hinge_rows [B] scratch
+ */
+int tt_triplet_fwd_bwd_f32(const float* q, const float* p, const float* n, float margin,
+                           float grad_scale, int64_t B, int P, float* loss,
+                           float* pos_dist, float* neg_dist, float* hinge_rows,
+                           float* dq, float* dp, float* dn, tt_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* K4 — Adam                                                                   */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * One torch.optim.Adam step (defaults of backend/training.py:436: betas
+ * (0.9,0.999), eps 1e-8, weight_decay 0, no amsgrad) over a flat fp32 array:
+ *   g = grad_scale * sum_{z<nslabs} grads[z*slab_stride + i]
+ *   m = m + (g - m)(1-b1);  v = v*b2 + (1-b2) g g
+ *   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)        t = step (1-based)
+ * nslabs > 1 folds the split-K partial gradients of tt_engine into the update.
+ * lr/betas/eps are doubles because torch derives 1-b1, 1-b2 and the bias
+ * corrections in Python double precision before casting to fp32.
+ */
+int tt_adam_f32(float* params, const float* grads, int nslabs, int64_t slab_stride,
+                float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                double beta2, double eps, int64_t step, float grad_scale, tt_stream_t stream);
+
+/* grad_out[i] (+)= sum_z slabs[z*slab_stride+i] — sums split-K partial gradient slabs. */
+int tt_reduce_slabs_f32(const float* slabs, int nslabs, int64_t slab_stride, float* out,
+                        int64_t n, int accumulate, tt_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Engine — the whole train_epoch batch body as one host call                  */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Replaces the per-batch body of backend/training.py:36-53 (zero_grad, three
+ * encodes, criterion, backward, optimizer.step, loss accumulation) for one
+ * replica.  The engine borrows the caller's table, flat parameter / Adam state
+ * buffers and its activation + split-K workspace; it allocates no device memory.
+ *
+ * Flat parameter layout (floats), the reference's model.parameters() order
+ * (backend/model.py:33-38,84-85):
+ *   query_tower.projection.0.weight [P,D], .0.bias [P], .2.weight [P,P], .2.bias [P],
+ *   document_tower.projection.0.weight, .0.bias, .2.weight, .2.bias
+ */
+typedef struct tt_engine tt_engine;
+
+typedef struct {
+  int64_t V;        /* table rows */
+  int32_t D;        /* embedding dim */
+  int32_t P;        /* projection dim */
+  int32_t max_B;    /* max triplets per step on this replica */
+  int32_t max_S;    /* max padded sequence length */
+  int32_t device;   /* HIP device ordinal */
+  int32_t reserved;
+} tt_engine_config;
+
+/* Device bytes of activation + split-K workspace an engine of this config needs. */
+size_t tt_engine_workspace_bytes(const tt_engine_config* cfg);
+/* workspace: caller-owned device buffer (256-byte aligned, >= tt_engine_workspace_bytes),
+ * borrowed until tt_engine_destroy; it is zero-filled on `stream` here. */
+int tt_engine_create(const tt_engine_config* cfg, void* workspace, size_t workspace_bytes,
+                     tt_stream_t stream, tt_engine** out);
+int tt_engine_destroy(tt_engine* e);
+/* floats in the flat parameter buffer: 2*(P*D + P + P*P + P) */
+int64_t tt_engine_param_count(const tt_engine* e);
+/* number of split-K gradient slabs the backward writes (>= 1) */
+int tt_engine_grad_slabs(const tt_engine* e);
+
+/* Borrow caller-owned device buffers (valid until rebound or destroy). */
+int tt_engine_bind(tt_engine* e, const float* table, float* params, float* exp_avg,
+                   float* exp_avg_sq);
+
+/*
+ * Phase A (weight-independent): K1 over the 3B texts of one batch into pooled
+ * slot `slot` (0/1; two slots so the next batch's gather can overlap the
+ * gradient all-reduce / optimizer of the current one).
+ *   ids  [3,B,S] (q, pos, neg — the call order of backend/training.py:40-42)
+ *   mask [3,B,S] or NULL; lens [3,B] int32 or NULL
+ */
+int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask,
+                   int mask_dtype, const int32_t* lens, int32_t B, int32_t S,
+                   tt_stream_t stream);
+
+/*
+ * Phase B: projection forward (both towers), triplet loss, backward.  Leaves
+ * the parameter gradient as tt_engine_grad_slabs() partial slabs (summed by
+ * tt_engine_reduce_grads or inside tt_engine_adam) and adds the batch loss to
+ * the engine's device-side loss accumulator (no host sync:
+ * backend/training.py:53's loss.item() is deferred to tt_engine_read_stats).
+ *   grad_scale: 1/B for the reference semantics (mean over the batch);
+ *               1/B_global under data parallelism; 1/(B*k) under accumulation.
+ */
+int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin, float grad_scale,
+                      tt_stream_t stream);
+
+/* grad_out[param_count] (+)= sum of slabs — the flat bucket handed to the RCCL all-reduce. */
+int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumulate, tt_stream_t stream);
+
+/*
+ * Phase C: Adam over the bound flat buffers.  grads == NULL: consume the
+ * engine's own slabs (single replica); else a reduced flat gradient
+ * (after all-reduce / accumulation).  step is 1-based.
+ */
+int tt_engine_adam(tt_engine* e, const float* grads, double lr, double beta1, double beta2,
+                   double eps, int64_t step, tt_stream_t stream);
+
+/* A+B+C on one stream: one reference batch body.  */
+int tt_engine_train_step(tt_engine* e, const void* ids, int ids_dtype, const void* mask,
+                         int mask_dtype, const int32_t* lens, int32_t B, int32_t S,
+                         float margin, double lr, int64_t step, tt_stream_t stream);
+
+/* Device pointers into the engine's activations for the last fwd_bwd on `slot`
+ * (rows: [q(B); pos(B); neg(B)]).  Valid until the next call on that slot. */
+const float* tt_engine_pooled(const tt_engine* e, int slot);   /* [3B, D] */
+const float* tt_engine_embeddings(const tt_engine* e);         /* [3B, P] projected */
+const float* tt_engine_grad_slab0(const tt_engine* e);         /* [slabs, param_count] */
+
+/* Host-side read of {sum of batch losses, number of batches, last loss}; synchronises
+ * `stream`.  reset != 0 zeroes the accumulator afterwards. */
+int tt_engine_read_stats(tt_engine* e, double* loss_sum, int64_t* n_batches, float* last_loss,
+                         int reset, tt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TT_HOTPATH_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of libtt_hotpath.so (the C ABI declared in include/tt_hotpath.h).
+
+The product path has no fallback: if the library is missing or fails to load,
+every op raises.  `build()` compiles it in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtt_hotpath.so")
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+TT_I32, TT_I64 = 4, 8
+ABI_VERSION = 1
+
+_lib = None
+_lock = threading.Lock()
+
+
+class TTError(RuntimeError):
+    """A C-ABI call returned a non-zero tt_status / hipError_t."""
+
+    def __init__(self, fn: str, code: int, msg: str):
+        super().__init__(f"{fn} failed with status {code}: {msg}")
+        self.code = code
+
+
+class TTEngineConfig(C.Structure):
+    _fields_ = [
+        ("V", C.c_int64),
+        ("D", C.c_int32),
+        ("P", C.c_int32),
+        ("max_B", C.c_int32),
+        ("max_S", C.c_int32),
+        ("device", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_vp, _i, _i32, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/tt_hotpath.h one to one
+SIGNATURES = {
+    "tt_abi_version": (_i, []),
+    "tt_status_string": (C.c_char_p, [_i]),
+    "tt_gather_pool_norm_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp]),
+    "tt_pool_norm_dense_f32": (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _i, _vp]),
+    "tt_embed_gather_f32": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _vp]),
+    "tt_proj_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "tt_proj_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "tt_proj_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, _i, _vp]),
+    "tt_triplet_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _f, _f, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_adam_f32": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i64, _d, _d, _d, _d, _i64, _f, _vp]),
+    "tt_reduce_slabs_f32": (_i, [_vp, _i, _i64, _vp, _i64, _i, _vp]),
+    "tt_engine_workspace_bytes": (_sz, [C.POINTER(TTEngineConfig)]),
+    "tt_engine_create": (_i, [C.POINTER(TTEngineConfig), _vp, _sz, _vp, C.POINTER(_vp)]),
+    "tt_engine_destroy": (_i, [_vp]),
+    "tt_engine_param_count": (_i64, [_vp]),
+    "tt_engine_grad_slabs": (_i, [_vp]),
+    "tt_engine_bind": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "tt_engine_pool": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i32, _i32, _vp]),
+    "tt_engine_fwd_bwd": (_i, [_vp, _i, _i32, _f, _f, _vp]),
+    "tt_engine_reduce_grads": (_i, [_vp, _vp, _i, _vp]),
+    "tt_engine_adam": (_i, [_vp, _vp, _d, _d, _d, _d, _i64, _vp]),
+    "tt_engine_train_step": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i32, _i32, _f, _d, _i64, _vp]),
+    "tt_engine_pooled": (_vp, [_vp, _i]),
+    "tt_engine_embeddings": (_vp, [_vp]),
+    "tt_engine_grad_slab0": (_vp, [_vp]),
+    "tt_engine_read_stats": (_i, [_vp, C.POINTER(_d), C.POINTER(_i64), C.POINTER(_f), _i, _vp]),
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip -> libtt_hotpath.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libtt_hotpath.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+def load():
+    """Load the library (once) and attach the signatures.  Raises if it is absent —
+    there is deliberately no CPU / PyTorch fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950). The HIP library is the only implementation of this path."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        v = lib.tt_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f"libtt_hotpath ABI {v} != expected {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(fn: str, rc: int) -> None:
+    if rc != 0:
+        raise TTError(fn, rc, load().tt_status_string(rc).decode())
+
+
+def call(fn: str, *args) -> None:
+    check(fn, getattr(load(), fn)(*args))

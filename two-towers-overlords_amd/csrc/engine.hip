@@ -1,0 +1,258 @@
+// tt_engine — the per-batch body of backend/training.py:36-53 for one replica,
+// as stream-ordered launches over caller-owned table / parameter / Adam-state
+// buffers and a caller-owned workspace (activations + split-K gradient slabs).
+//
+//   pool     : K1 over [q; pos; neg] (3B texts, one launch)            -> pooled[slot]
+//   fwd_bwd  : K2 fwd (both towers grouped: query rows 0..B, document rows B..3B so
+//              the positive and negative calls of training.py:41-42 share one GEMM
+//              and their gradients accumulate inside it), K3, K2 bwd     -> grad slabs
+//   adam     : K4, folding the slab sum into the update
+#include <new>
+#include "proj.h"
+
+int tt_launch_loss_mean(const float* hinge_rows, long long B, float* loss, double* acc_sum,
+                        long long* acc_count, hipStream_t st);
+int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float margin, float grad_scale,
+                           long long B, int P, float* pos_dist, float* neg_dist, float* hinge_rows,
+                           float* dq, float* dp, float* dn, hipStream_t st);
+
+struct tt_engine {
+  uint32_t magic;
+  tt_engine_config cfg;
+  int64_t tower_n;   // floats per tower: P*D + P + P*P + P
+  int64_t nparam;    // 2 * tower_n
+  int64_t slab_stride;
+  int nslabs;
+  // borrowed
+  const float* table;
+  float* params;
+  float* exp_avg;
+  float* exp_avg_sq;
+  // carved out of the caller's workspace
+  char* arena;
+  float* pooled[2];
+  float* H;
+  float* emb;
+  float* dOut;
+  float* dH;
+  float* slabs;
+  float* hinge;
+  float* pos_dist;
+  float* neg_dist;
+  float* loss;
+  double* loss_sum;
+  long long* loss_cnt;
+  int32_t* oob;
+};
+
+namespace {
+constexpr uint32_t kMagic = 0x7754454eu;
+inline bool ok(const tt_engine* e) { return e && e->magic == kMagic; }
+inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += up256(n * sizeof(T));
+    return p;
+  }
+};
+
+void carve(tt_engine* e, char* base, size_t* total) {
+  Carver c{base};
+  const size_t rows = 3 * (size_t)e->cfg.max_B;
+  e->pooled[0] = c.take<float>(rows * e->cfg.D);
+  e->pooled[1] = c.take<float>(rows * e->cfg.D);
+  e->H = c.take<float>(rows * e->cfg.P);
+  e->emb = c.take<float>(rows * e->cfg.P);
+  e->dOut = c.take<float>(rows * e->cfg.P);
+  e->dH = c.take<float>(rows * e->cfg.P);
+  e->slabs = c.take<float>((size_t)e->nslabs * e->slab_stride);
+  e->hinge = c.take<float>(e->cfg.max_B);
+  e->pos_dist = c.take<float>(e->cfg.max_B);
+  e->neg_dist = c.take<float>(e->cfg.max_B);
+  e->loss = c.take<float>(4);
+  e->loss_sum = c.take<double>(2);
+  e->loss_cnt = c.take<long long>(2);
+  e->oob = c.take<int32_t>(4);
+  *total = c.off;
+}
+}  // namespace
+
+static int fill_dims(tt_engine* e, const tt_engine_config* cfg) {
+  TT_REQUIRE(cfg->V >= 1 && cfg->V <= 0x7fffffffLL && cfg->D >= 1 && cfg->P >= 1 && cfg->P <= 1024 &&
+                 cfg->max_B >= 1 && cfg->max_S >= 1 && (int64_t)cfg->max_B * 3 <= 0x7fffffffLL,
+             TT_ERR_BAD_SHAPE);
+  e->cfg = *cfg;
+  e->tower_n = (int64_t)cfg->P * cfg->D + cfg->P + (int64_t)cfg->P * cfg->P + cfg->P;
+  e->nparam = 2 * e->tower_n;
+  e->slab_stride = (e->nparam + 3) / 4 * 4;
+  e->nslabs = ttp::choose_nsplit(cfg->max_B);
+  return TT_OK;
+}
+
+extern "C" size_t tt_engine_workspace_bytes(const tt_engine_config* cfg) {
+  if (!cfg) return 0;
+  tt_engine tmp{};
+  if (fill_dims(&tmp, cfg) != TT_OK) return 0;
+  size_t total = 0;
+  carve(&tmp, nullptr, &total);
+  return total;
+}
+
+extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, size_t workspace_bytes,
+                                tt_stream_t stream, tt_engine** out) {
+  TT_REQUIRE(cfg && out && workspace, TT_ERR_NULL_POINTER);
+  TT_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, TT_ERR_ALIGNMENT);
+  tt_engine* e = new (std::nothrow) tt_engine();
+  TT_REQUIRE(e, TT_ERR_WORKSPACE);
+  int rc = fill_dims(e, cfg);
+  size_t total = 0;
+  if (rc == TT_OK) {
+    carve(e, nullptr, &total);
+    if (workspace_bytes < total) rc = TT_ERR_WORKSPACE;
+  }
+  if (rc == TT_OK) {
+    hipError_t herr = hipMemsetAsync(workspace, 0, total, static_cast<hipStream_t>(stream));
+    if (herr != hipSuccess) rc = (int)herr;
+  }
+  if (rc != TT_OK) {
+    delete e;
+    return rc;
+  }
+  e->arena = static_cast<char*>(workspace);
+  carve(e, e->arena, &total);
+  e->magic = kMagic;
+  *out = e;
+  return TT_OK;
+}
+
+extern "C" int tt_engine_destroy(tt_engine* e) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  e->magic = 0;
+  delete e;
+  return TT_OK;
+}
+
+extern "C" int64_t tt_engine_param_count(const tt_engine* e) { return ok(e) ? e->nparam : -1; }
+extern "C" int tt_engine_grad_slabs(const tt_engine* e) { return ok(e) ? e->nslabs : -1; }
+extern "C" const float* tt_engine_pooled(const tt_engine* e, int slot) {
+  return ok(e) && (slot == 0 || slot == 1) ? e->pooled[slot] : nullptr;
+}
+extern "C" const float* tt_engine_embeddings(const tt_engine* e) { return ok(e) ? e->emb : nullptr; }
+extern "C" const float* tt_engine_grad_slab0(const tt_engine* e) { return ok(e) ? e->slabs : nullptr; }
+
+extern "C" int tt_engine_bind(tt_engine* e, const float* table, float* params, float* exp_avg,
+                              float* exp_avg_sq) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(table && params && exp_avg && exp_avg_sq, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(tt_aligned16(table) && tt_aligned16(params) && tt_aligned16(exp_avg) && tt_aligned16(exp_avg_sq),
+             TT_ERR_ALIGNMENT);
+  e->table = table;
+  e->params = params;
+  e->exp_avg = exp_avg;
+  e->exp_avg_sq = exp_avg_sq;
+  return TT_OK;
+}
+
+extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask,
+                              int mask_dtype, const int32_t* lens, int32_t B, int32_t S, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(e->table, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(slot == 0 || slot == 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && S >= 1 && S <= e->cfg.max_S, TT_ERR_BAD_SHAPE);
+  return tt_gather_pool_norm_f32(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot],
+                                 3 * (int64_t)B, S, e->cfg.D, e->cfg.V, e->oob, stream);
+}
+
+extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin, float grad_scale,
+                                 tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(slot == 0 || slot == 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B, TT_ERR_BAD_SHAPE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int D = e->cfg.D, P = e->cfg.P;
+  ttp::Tower t[2] = {};
+  for (int i = 0; i < 2; ++i) {
+    const int64_t row0 = i == 0 ? 0 : B;
+    float* w = e->params + i * e->tower_n;
+    float* g = e->slabs + i * e->tower_n;
+    t[i].M = i == 0 ? B : 2 * B;
+    t[i].X = e->pooled[slot] + row0 * D;
+    t[i].W1 = w;
+    t[i].b1 = w + (int64_t)P * D;
+    t[i].W2 = t[i].b1 + P;
+    t[i].b2 = t[i].W2 + (int64_t)P * P;
+    t[i].H = e->H + row0 * P;
+    t[i].Out = e->emb + row0 * P;
+    t[i].dOut = e->dOut + row0 * P;
+    t[i].dH = e->dH + row0 * P;
+    t[i].gW1 = g;
+    t[i].gb1 = g + (int64_t)P * D;
+    t[i].gW2 = t[i].gb1 + P;
+    t[i].gb2 = t[i].gW2 + (int64_t)P * P;
+  }
+  int rc = ttp::forward(t, 2, D, P, st);
+  if (rc != TT_OK) return rc;
+  const float* q = e->emb;
+  const float* p = e->emb + (int64_t)B * P;
+  const float* n = e->emb + 2 * (int64_t)B * P;
+  rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
+                              e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, st);
+  if (rc != TT_OK) return rc;
+  rc = tt_launch_loss_mean(e->hinge, B, e->loss, e->loss_sum, e->loss_cnt, st);
+  if (rc != TT_OK) return rc;
+  return ttp::backward(t, 2, D, P, e->nslabs, e->slab_stride, st);
+}
+
+extern "C" int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumulate, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(grad_out, TT_ERR_NULL_POINTER);
+  return tt_reduce_slabs_f32(e->slabs, e->nslabs, e->slab_stride, grad_out, e->nparam, accumulate, stream);
+}
+
+extern "C" int tt_engine_adam(tt_engine* e, const float* grads, double lr, double beta1, double beta2,
+                              double eps, int64_t step, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
+  if (grads) return tt_adam_f32(e->params, grads, 1, 0, e->exp_avg, e->exp_avg_sq, e->nparam, lr, beta1, beta2, eps, step, 1.f, stream);
+  return tt_adam_f32(e->params, e->slabs, e->nslabs, e->slab_stride, e->exp_avg, e->exp_avg_sq, e->nparam, lr,
+                     beta1, beta2, eps, step, 1.f, stream);
+}
+
+extern "C" int tt_engine_train_step(tt_engine* e, const void* ids, int ids_dtype, const void* mask,
+                                    int mask_dtype, const int32_t* lens, int32_t B, int32_t S, float margin,
+                                    double lr, int64_t step, tt_stream_t stream) {
+  int rc = tt_engine_pool(e, 0, ids, ids_dtype, mask, mask_dtype, lens, B, S, stream);
+  if (rc != TT_OK) return rc;
+  rc = tt_engine_fwd_bwd(e, 0, B, margin, 1.0f / (float)B, stream);
+  if (rc != TT_OK) return rc;
+  return tt_engine_adam(e, nullptr, lr, 0.9, 0.999, 1e-8, step, stream);
+}
+
+extern "C" int tt_engine_read_stats(tt_engine* e, double* loss_sum, int64_t* n_batches, float* last_loss,
+                                    int reset, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double s = 0;
+  long long c = 0;
+  float l = 0;
+  int32_t oob = 0;
+  TT_HIP(hipMemcpyAsync(&s, e->loss_sum, sizeof(double), hipMemcpyDeviceToHost, st));
+  TT_HIP(hipMemcpyAsync(&c, e->loss_cnt, sizeof(long long), hipMemcpyDeviceToHost, st));
+  TT_HIP(hipMemcpyAsync(&l, e->loss, sizeof(float), hipMemcpyDeviceToHost, st));
+  TT_HIP(hipMemcpyAsync(&oob, e->oob, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (reset) {
+    TT_HIP(hipMemsetAsync(e->loss_sum, 0, sizeof(double), st));
+    TT_HIP(hipMemsetAsync(e->loss_cnt, 0, sizeof(long long), st));
+  }
+  TT_HIP(hipStreamSynchronize(st));
+  if (loss_sum) *loss_sum = s;
+  if (n_batches) *n_batches = c;
+  if (last_loss) *last_loss = l;
+  return oob ? TT_ERR_BAD_SHAPE : TT_OK;  // an out-of-range token id was clamped
+}

@@ -1,0 +1,329 @@
+// K1 — token-embedding gather + masked mean-pool + L2 normalise (gfx950).
+//
+// Replaces backend/model.py:51-56,63-72 of the reference (see include/tt_hotpath.h).
+//
+// Mapping: one 256-thread workgroup (4 waves) per text.  A lane owns 16-byte
+// column chunks {lane, lane+64, ...} of the D-float row, so one wave-instruction
+// reads 1 KiB of one embedding row, fully coalesced.  Token positions are dealt
+// round-robin to the 4 waves (position % 4), each wave keeps U rows in flight
+// (U x C dwordx4 loads issued before the first use) and accumulates in
+// registers; masked-out tokens are never fetched (their weight is 0), so the
+// bytes moved are the algorithmic bytes.  The 4 partial sums meet in LDS, then
+// mean (clamp 1e-9), L2 norm (wave __shfl_xor butterfly + 4-entry LDS), divide
+// (clamp 1e-12) and one coalesced float4 store per lane.  The [N,S,D] tensor of
+// the reference is never materialised.
+//
+// Row ids are wave-uniform (v_readlane from the lane that loaded them), so the
+// row base address is scalar and each load is `global_load_dwordx4 v, v_off, s[base]`.
+#include "tt_common.h"
+
+namespace {
+
+constexpr int kWavesPerText = 4;
+constexpr int kThreads = kWavesPerText * TT_WAVE;
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+__device__ __forceinline__ void f4_fma(float4& acc, float w, const float4& r) {
+  acc.x = fmaf(w, r.x, acc.x);
+  acc.y = fmaf(w, r.y, acc.y);
+  acc.z = fmaf(w, r.z, acc.z);
+  acc.w = fmaf(w, r.w, acc.w);
+}
+
+// Pops K token positions from `mine` (wave-uniform bit set), issues all K*C row
+// loads, then accumulates.  DENSE: rows are hidden[text_base + seg + pos].
+template <int K, int C, bool DENSE>
+__device__ __forceinline__ void pool_group(unsigned long long& mine, const float* __restrict__ src,
+                                           int id_lane, float w_lane, long long dense_row0, int D,
+                                           int lane, bool last_ok, float4 (&acc)[C]) {
+  float4 r[K][C];
+  float wk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int pos = __builtin_ctzll(mine);
+    mine &= mine - 1;
+    wk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_lane), pos));
+    long long row;
+    if (DENSE) {
+      row = dense_row0 + pos;
+    } else {
+      row = (long long)__builtin_amdgcn_readlane(id_lane, pos);
+    }
+    const float4* __restrict__ rp = reinterpret_cast<const float4*>(src + row * (long long)D);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (c < C - 1 || last_ok) {
+        r[k][c] = rp[c * TT_WAVE + lane];
+      } else {
+        r[k][c] = f4_zero();
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) f4_fma(acc[c], wk[k], r[k][c]);
+  }
+}
+
+// C = float4 chunks per lane = ceil(D/4/64); U = rows in flight per wave.
+template <typename IdT, typename MaskT, int C, int U, bool DENSE>
+__global__ __launch_bounds__(kThreads) void pool_norm_kernel(
+    const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
+    const int* __restrict__ lens, float* __restrict__ out, int S, int D, long long V,
+    int* __restrict__ oob_flag) {
+  __shared__ float4 part[kWavesPerText][C * TT_WAVE];
+  __shared__ float red[kWavesPerText];
+
+  const long long text = blockIdx.x;
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = D >> 2;
+  const bool last_ok = (C - 1) * TT_WAVE + lane < nchunk;
+  const long long tbase = text * (long long)S;
+  const int len = lens ? lens[text] : S;
+
+  float4 acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = f4_zero();
+  float wtot = 0.f;
+
+  for (int seg = 0; seg < S; seg += TT_WAVE) {
+    const int tok = seg + lane;
+    int id = 0;
+    float w = 0.f;
+    if (tok < S) {
+      w = mask ? static_cast<float>(mask[tbase + tok]) : (tok < len ? 1.f : 0.f);
+      if (!DENSE) {
+        const long long raw = static_cast<long long>(ids[tbase + tok]);
+        if (raw < 0 || raw >= V) {
+          // never read outside the table: clamp, and tell the host if it asked
+          if (w != 0.f && oob_flag) atomicOr(oob_flag, 1);
+          id = raw < 0 ? 0 : static_cast<int>(V - 1);
+        } else {
+          id = static_cast<int>(raw);
+        }
+      }
+    }
+    wtot += w;
+    const unsigned long long live = __ballot(w != 0.f);
+    unsigned long long mine = live & (0x1111111111111111ULL << wave);
+    int cnt = __popcll(mine);
+    const long long drow0 = tbase + seg;
+    while (cnt >= U) {
+      pool_group<U, C, DENSE>(mine, src, id, w, drow0, D, lane, last_ok, acc);
+      cnt -= U;
+    }
+    if (U > 4 && cnt >= 4) {
+      pool_group<4, C, DENSE>(mine, src, id, w, drow0, D, lane, last_ok, acc);
+      cnt -= 4;
+    }
+    if (U > 2 && cnt >= 2) {
+      pool_group<2, C, DENSE>(mine, src, id, w, drow0, D, lane, last_ok, acc);
+      cnt -= 2;
+    }
+    if (cnt >= 1) {
+      pool_group<1, C, DENSE>(mine, src, id, w, drow0, D, lane, last_ok, acc);
+    }
+  }
+
+  // denominator: sum of the mask over ALL positions (every wave saw them all)
+  const float wsum = tt_wave_sum(wtot);
+
+#pragma unroll
+  for (int c = 0; c < C; ++c) part[wave][c * TT_WAVE + lane] = acc[c];
+  __syncthreads();
+
+  const int t = threadIdx.x;
+  const bool act = t < nchunk;  // C <= 4  =>  nchunk <= 256: one chunk per thread
+  float4 m = f4_zero();
+  float ss = 0.f;
+  if (act) {
+    const float4 a = part[0][t], b = part[1][t], c2 = part[2][t], d = part[3][t];
+    const float den = fmaxf(wsum, 1e-9f);  // clamp(mask.sum(1), min=1e-9)
+    m.x = (((a.x + b.x) + c2.x) + d.x) / den;
+    m.y = (((a.y + b.y) + c2.y) + d.y) / den;
+    m.z = (((a.z + b.z) + c2.z) + d.z) / den;
+    m.w = (((a.w + b.w) + c2.w) + d.w) / den;
+    ss = fmaf(m.x, m.x, fmaf(m.y, m.y, fmaf(m.z, m.z, m.w * m.w)));
+  }
+  ss = tt_wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  const float nrm = sqrtf(((red[0] + red[1]) + red[2]) + red[3]);
+  const float dn = fmaxf(nrm, 1e-12f);  // F.normalize eps
+  if (act) {
+    float4 o;
+    o.x = m.x / dn;
+    o.y = m.y / dn;
+    o.z = m.z / dn;
+    o.w = m.w / dn;
+    reinterpret_cast<float4*>(out + text * (long long)D)[t] = o;
+  }
+}
+
+// Any D (not a multiple of 4, or > 1024, or unaligned): correct, not fast.
+template <typename IdT, typename MaskT, bool DENSE>
+__global__ __launch_bounds__(kThreads) void pool_norm_generic_kernel(
+    const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
+    const int* __restrict__ lens, float* __restrict__ out, int S, int D, long long V,
+    int* __restrict__ oob_flag) {
+  __shared__ float red[kWavesPerText];
+  const long long text = blockIdx.x;
+  const long long tbase = text * (long long)S;
+  const int len = lens ? lens[text] : S;
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+
+  float wsum = 0.f;
+  for (int s = 0; s < S; ++s) wsum += mask ? static_cast<float>(mask[tbase + s]) : (s < len ? 1.f : 0.f);
+  const float den = fmaxf(wsum, 1e-9f);
+
+  float ss = 0.f;
+  for (int col = threadIdx.x; col < D; col += kThreads) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float w = mask ? static_cast<float>(mask[tbase + s]) : (s < len ? 1.f : 0.f);
+      if (w == 0.f) continue;
+      long long row;
+      if (DENSE) {
+        row = tbase + s;
+      } else {
+        row = static_cast<long long>(ids[tbase + s]);
+        if (row < 0 || row >= V) {
+          if (oob_flag) atomicOr(oob_flag, 1);
+          row = row < 0 ? 0 : V - 1;
+        }
+      }
+      a = fmaf(w, src[row * (long long)D + col], a);
+    }
+    const float m = a / den;
+    out[text * (long long)D + col] = m;
+    ss = fmaf(m, m, ss);
+  }
+  ss = tt_wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  const float dn = fmaxf(sqrtf(((red[0] + red[1]) + red[2]) + red[3]), 1e-12f);
+  for (int col = threadIdx.x; col < D; col += kThreads) {
+    const long long o = text * (long long)D + col;
+    out[o] = out[o] / dn;
+  }
+}
+
+// Materialised gather: one wave per token row, grid-stride.
+template <typename IdT>
+__global__ __launch_bounds__(kThreads) void embed_gather_kernel(const float* __restrict__ table,
+                                                                const IdT* __restrict__ ids,
+                                                                float* __restrict__ out,
+                                                                long long n_tokens, int D, long long V,
+                                                                int vec, int* __restrict__ oob_flag) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const long long wave0 = (long long)blockIdx.x * kWavesPerText + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * kWavesPerText;
+  for (long long t = wave0; t < n_tokens; t += nwaves) {
+    long long row = static_cast<long long>(ids[t]);
+    if (row < 0 || row >= V) {
+      if (oob_flag && lane == 0) atomicOr(oob_flag, 1);
+      row = row < 0 ? 0 : V - 1;
+    }
+    if (vec) {
+      const float4* __restrict__ rp = reinterpret_cast<const float4*>(table + row * (long long)D);
+      float4* __restrict__ op = reinterpret_cast<float4*>(out + t * (long long)D);
+      for (int c = lane; c < (D >> 2); c += TT_WAVE) op[c] = rp[c];
+    } else {
+      for (int c = lane; c < D; c += TT_WAVE) out[t * (long long)D + c] = table[row * (long long)D + c];
+    }
+  }
+}
+
+template <typename IdT, typename MaskT, bool DENSE>
+int launch_pool(const float* src, const void* ids, const void* mask, const int32_t* lens, float* out,
+                int64_t N, int S, int D, int64_t V, int32_t* oob, hipStream_t st) {
+  const IdT* ids_t = static_cast<const IdT*>(ids);
+  const MaskT* mask_t = static_cast<const MaskT*>(mask);
+  const dim3 grid(static_cast<unsigned>(N)), block(kThreads);
+  const bool fast = (D % 4 == 0) && D <= 1024 && tt_aligned16(src) && tt_aligned16(out);
+  if (!fast) {
+    hipLaunchKernelGGL((pool_norm_generic_kernel<IdT, MaskT, DENSE>), grid, block, 0, st, src, ids_t,
+                       mask_t, lens, out, S, D, (long long)V, oob);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+  }
+  const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
+#define TT_POOL_CASE(CC, UU)                                                                       \
+  hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, CC, UU, DENSE>), grid, block, 0, st, src, ids_t, \
+                     mask_t, lens, out, S, D, (long long)V, oob)
+  switch (C) {
+    case 1: TT_POOL_CASE(1, 8); break;
+    case 2: TT_POOL_CASE(2, 8); break;
+    case 3: TT_POOL_CASE(3, 4); break;
+    default: TT_POOL_CASE(4, 4); break;
+  }
+#undef TT_POOL_CASE
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
+template <bool DENSE>
+int dispatch_pool(const float* src, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                  const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob,
+                  hipStream_t st) {
+  // without a mask the MaskT instantiation is irrelevant: use int32
+  const int md = mask ? mask_dtype : TT_I32;
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_pool<int32_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, st);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_pool<int32_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, st);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_pool<int64_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, st);
+  if (ids_dtype == TT_I64 && md == TT_I64) return launch_pool<int64_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, st);
+  return TT_ERR_BAD_DTYPE;
+}
+
+}  // namespace
+
+extern "C" int tt_gather_pool_norm_f32(const float* table, const void* ids, int ids_dtype,
+                                       const void* mask, int mask_dtype, const int32_t* lens,
+                                       float* out, int64_t N, int S, int D, int64_t V,
+                                       int32_t* oob_flag, tt_stream_t stream) {
+  TT_REQUIRE(table && ids && out, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x7fffffffLL, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  if (N == 0) return TT_OK;
+  return dispatch_pool<false>(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag,
+                              static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tt_pool_norm_dense_f32(const float* hidden, const void* mask, int mask_dtype,
+                                      const int32_t* lens, float* out, int64_t N, int S, int D,
+                                      tt_stream_t stream) {
+  TT_REQUIRE(hidden && out, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && N <= 0x7fffffffLL, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  if (N == 0) return TT_OK;
+  // ids are unused in dense mode; pass the hidden pointer as a non-null placeholder
+  return dispatch_pool<true>(hidden, hidden, TT_I32, mask, mask_dtype, lens, out, N, S, D, 1, nullptr,
+                             static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tt_embed_gather_f32(const float* table, const void* ids, int ids_dtype, float* out,
+                                   int64_t n_tokens, int D, int64_t V, int32_t* oob_flag,
+                                   tt_stream_t stream) {
+  TT_REQUIRE(table && ids && out, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(n_tokens >= 0 && D >= 1 && V >= 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  if (n_tokens == 0) return TT_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int vec = (D % 4 == 0) && tt_aligned16(table) && tt_aligned16(out);
+  long long blocks = (n_tokens + kWavesPerText - 1) / kWavesPerText;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (ids_dtype == TT_I32) {
+    hipLaunchKernelGGL(embed_gather_kernel<int32_t>, dim3((unsigned)blocks), dim3(kThreads), 0, st, table,
+                       static_cast<const int32_t*>(ids), out, (long long)n_tokens, D, (long long)V, vec, oob_flag);
+  } else {
+    hipLaunchKernelGGL(embed_gather_kernel<int64_t>, dim3((unsigned)blocks), dim3(kThreads), 0, st, table,
+                       static_cast<const int64_t*>(ids), out, (long long)n_tokens, D, (long long)V, vec, oob_flag);
+  }
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}

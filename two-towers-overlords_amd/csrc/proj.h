@@ -1,0 +1,34 @@
+// Projection (K2) forward/backward as grouped MFMA GEMM launches.  Internal.
+#pragma once
+#include "gemm_f32.h"
+
+namespace ttp {
+
+// One tower's slice of a grouped projection call.
+struct Tower {
+  const float* X;   // [M, D] pooled-normalised inputs
+  const float* W1;  // [P, D]
+  const float* b1;  // [P]
+  const float* W2;  // [P, P]
+  const float* b2;  // [P]
+  float* H;         // [M, P] relu(X W1^T + b1)
+  float* Out;       // [M, P]
+  const float* dOut;  // [M, P]          (backward)
+  float* dH;          // [M, P] scratch  (backward)
+  float* gW1;         // slab 0 of dW1 [P, D]; slab z at + z*slab_stride
+  float* gb1;
+  float* gW2;
+  float* gb2;
+  int M;
+};
+
+// k_per_split for `M` rows over `nsplit` slabs (multiple of 32, >= 32)
+int k_per_split(int M, int nsplit);
+// split count used for a standalone backward over M rows
+int choose_nsplit(long long M);
+
+int forward(const Tower* t, int count, int D, int P, hipStream_t st);
+// writes nsplit partial slabs of (dW1, db1, dW2, db2) per tower; dH is scratch
+int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
+
+}  // namespace ttp

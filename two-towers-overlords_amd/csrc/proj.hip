@@ -1,0 +1,133 @@
+// K2 — per-tower projection Linear(D,P) -> ReLU -> Linear(P,P) and its parameter
+// gradients, as grouped exact-fp32 MFMA GEMMs (both towers in one launch).
+// Replaces backend/model.py:33-38,59 and the part of loss.backward()
+// (backend/training.py:50) that runs through it.
+#include "proj.h"
+
+namespace ttp {
+
+int k_per_split(int M, int nsplit) {
+  int k = (M + nsplit - 1) / nsplit;
+  k = ((k + 31) / 32) * 32;
+  return k < 32 ? 32 : k;
+}
+
+int choose_nsplit(long long M) {
+  long long s = (M + 255) / 256;
+  if (s < 1) s = 1;
+  if (s > 16) s = 16;
+  return (int)s;
+}
+
+// block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
+static void pick_tile(long long total_rows, int N, int& wm, int& wn) {
+  const long long tiles64 = ((total_rows + 63) / 64) * ((N + 63) / 64);
+  if (tiles64 >= 2048 && N >= 128) { wm = 2; wn = 2; }
+  else if (tiles64 >= 1024) { wm = 2; wn = 1; }
+  else { wm = 1; wn = 1; }
+}
+
+int forward(const Tower* t, int count, int D, int P, hipStream_t st) {
+  ttg::Batch b1{}, b2{};
+  b1.count = b2.count = count;
+  b1.nsplit = b2.nsplit = 1;
+  long long rows = 0;
+  for (int i = 0; i < count; ++i) {
+    rows += t[i].M;
+    ttg::Problem& p = b1.p[i];
+    p.A = t[i].X; p.B = t[i].W1; p.C = t[i].H; p.bias = t[i].b1;
+    p.M = t[i].M; p.N = P; p.K = D; p.lda = D; p.ldb = D; p.ldc = P;
+    ttg::Problem& q = b2.p[i];
+    q.A = t[i].H; q.B = t[i].W2; q.C = t[i].Out; q.bias = t[i].b2;
+    q.M = t[i].M; q.N = P; q.K = P; q.lda = P; q.ldb = P; q.ldc = P;
+  }
+  int wm, wn;
+  pick_tile(rows, P, wm, wn);
+  int rc = ttg::launch(ttg::kNT, ttg::kBiasRelu, b1, wm, wn, st);
+  if (rc != TT_OK) return rc;
+  return ttg::launch(ttg::kNT, ttg::kBias, b2, wm, wn, st);
+}
+
+int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
+  ttg::Batch g2{}, gh{}, g1{};
+  g2.count = gh.count = g1.count = count;
+  g2.nsplit = g1.nsplit = nsplit;
+  gh.nsplit = 1;
+  g2.slab_stride = g1.slab_stride = slab_stride;
+  long long rows = 0;
+  for (int i = 0; i < count; ++i) {
+    rows += t[i].M;
+    const int kps = k_per_split(t[i].M, nsplit);
+    // dW2[i,j] = sum_m dOut[m,i] H[m,j];  db2[i] = sum_m dOut[m,i]
+    ttg::Problem& a = g2.p[i];
+    a.A = t[i].dOut; a.B = t[i].H; a.C = t[i].gW2; a.colsum = t[i].gb2;
+    a.M = P; a.N = P; a.K = t[i].M; a.lda = P; a.ldb = P; a.ldc = P; a.k_per_split = kps;
+    // dH = (dOut W2) * [H > 0]
+    ttg::Problem& h = gh.p[i];
+    h.A = t[i].dOut; h.B = t[i].W2; h.C = t[i].dH; h.aux = t[i].H;
+    h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
+    // dW1[i,j] = sum_m dH[m,i] X[m,j];  db1[i] = sum_m dH[m,i]
+    ttg::Problem& c = g1.p[i];
+    c.A = t[i].dH; c.B = t[i].X; c.C = t[i].gW1; c.colsum = t[i].gb1;
+    c.M = P; c.N = D; c.K = t[i].M; c.lda = P; c.ldb = D; c.ldc = D; c.k_per_split = kps;
+  }
+  int wm, wn;
+  int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, 1, 1, st);
+  if (rc != TT_OK) return rc;
+  pick_tile(rows, P, wm, wn);
+  rc = ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st);
+  if (rc != TT_OK) return rc;
+  return ttg::launch(ttg::kTN, ttg::kStore, g1, 1, 1, st);
+}
+
+}  // namespace ttp
+
+extern "C" int tt_proj_fwd_f32(const float* X, const float* W1, const float* b1, const float* W2,
+                               const float* b2, float* H, float* Out, int64_t M, int D, int P,
+                               tt_stream_t stream) {
+  TT_REQUIRE(X && W1 && b1 && W2 && b2 && H && Out, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(M >= 0 && M <= 0x7fffffffLL && D >= 1 && P >= 1, TT_ERR_BAD_SHAPE);
+  if (M == 0) return TT_OK;
+  ttp::Tower t{};
+  t.X = X; t.W1 = W1; t.b1 = b1; t.W2 = W2; t.b2 = b2; t.H = H; t.Out = Out; t.M = (int)M;
+  return ttp::forward(&t, 1, D, P, static_cast<hipStream_t>(stream));
+}
+
+static int64_t tower_floats(int D, int P) { return (int64_t)P * D + P + (int64_t)P * P + P; }
+static int64_t round4(int64_t x) { return (x + 3) / 4 * 4; }
+
+extern "C" size_t tt_proj_bwd_workspace_bytes(int64_t M, int D, int P) {
+  const int ns = ttp::choose_nsplit(M);
+  return (size_t)(round4(M * P) + (int64_t)ns * round4(tower_floats(D, P))) * sizeof(float);
+}
+
+extern "C" int tt_proj_bwd_f32(const float* dOut, const float* X, const float* H, const float* W2,
+                               float* dW1, float* db1, float* dW2, float* db2, void* workspace,
+                               size_t workspace_bytes, int accumulate, int64_t M, int D, int P,
+                               tt_stream_t stream) {
+  TT_REQUIRE(dOut && X && H && W2 && dW1 && db1 && dW2 && db2 && workspace, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(M >= 1 && M <= 0x7fffffffLL && D >= 1 && P >= 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(workspace_bytes >= tt_proj_bwd_workspace_bytes(M, D, P), TT_ERR_WORKSPACE);
+  TT_REQUIRE(tt_aligned16(workspace), TT_ERR_ALIGNMENT);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int ns = ttp::choose_nsplit(M);
+  const int64_t stride = round4(tower_floats(D, P));
+  float* ws = static_cast<float*>(workspace);
+  float* dH = ws;
+  float* slabs = ws + round4(M * P);
+  ttp::Tower t{};
+  t.X = X; t.W2 = W2; t.H = const_cast<float*>(H); t.dOut = dOut; t.dH = dH; t.M = (int)M;
+  t.gW1 = slabs;
+  t.gb1 = slabs + (int64_t)P * D;
+  t.gW2 = t.gb1 + P;
+  t.gb2 = t.gW2 + (int64_t)P * P;
+  int rc = ttp::backward(&t, 1, D, P, ns, stride, st);
+  if (rc != TT_OK) return rc;
+  rc = tt_reduce_slabs_f32(t.gW1, ns, stride, dW1, (int64_t)P * D, accumulate, stream);
+  if (rc != TT_OK) return rc;
+  rc = tt_reduce_slabs_f32(t.gb1, ns, stride, db1, P, accumulate, stream);
+  if (rc != TT_OK) return rc;
+  rc = tt_reduce_slabs_f32(t.gW2, ns, stride, dW2, (int64_t)P * P, accumulate, stream);
+  if (rc != TT_OK) return rc;
+  return tt_reduce_slabs_f32(t.gb2, ns, stride, db2, P, accumulate, stream);
+}

@@ -1,0 +1,236 @@
+// K3 (cosine-distance triplet loss fwd+bwd), K4 (Adam) and the split-K slab
+// reduction — the bandwidth-trivial kernels of the hot path (gfx950).
+#include "tt_common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreads = kWavesPerBlock * TT_WAVE;
+
+// One wave per triplet row.  Follows the op order of F.cosine_similarity
+// (normalise each operand by max(|x|, 1e-8), then dot) so that values agree with
+// the reference to rounding; gradient is the closed form checked against
+// autograd in oracle/two_towers_oracle.py::triplet_loss_closed_form.
+// NC = ceil(P / 64) columns held per lane (register-resident rows).
+template <int NC>
+__global__ __launch_bounds__(kThreads) void triplet_kernel(
+    const float* __restrict__ q, const float* __restrict__ p, const float* __restrict__ n, float margin,
+    float grad_scale, long long B, int P, float* __restrict__ pos_dist, float* __restrict__ neg_dist,
+    float* __restrict__ hinge_rows, float* __restrict__ dq, float* __restrict__ dp, float* __restrict__ dn) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const long long row = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float eps = 1e-8f;
+  const long long o = row * (long long)P;
+
+  float xq[NC], xp[NC], xn[NC];
+  float sq = 0.f, sp = 0.f, sn = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * TT_WAVE + lane;
+    const bool ok = col < P;
+    xq[c] = ok ? q[o + col] : 0.f;
+    xp[c] = ok ? p[o + col] : 0.f;
+    xn[c] = ok ? n[o + col] : 0.f;
+    sq = fmaf(xq[c], xq[c], sq);
+    sp = fmaf(xp[c], xp[c], sp);
+    sn = fmaf(xn[c], xn[c], sn);
+  }
+  const float nq = sqrtf(tt_wave_sum(sq)), np_ = sqrtf(tt_wave_sum(sp)), nn = sqrtf(tt_wave_sum(sn));
+  const float cq = fmaxf(nq, eps), cp = fmaxf(np_, eps), cn = fmaxf(nn, eps);
+
+  float dqp = 0.f, dqn = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    xq[c] = xq[c] / cq;  // unit vectors from here on
+    xp[c] = xp[c] / cp;
+    xn[c] = xn[c] / cn;
+    dqp = fmaf(xq[c], xp[c], dqp);
+    dqn = fmaf(xq[c], xn[c], dqn);
+  }
+  const float cos_p = tt_wave_sum(dqp), cos_n = tt_wave_sum(dqn);
+  const float pd = 1.f - cos_p, nd = 1.f - cos_n;  // model.py:135
+  const float hinge = pd - nd + margin;            // model.py:143
+  if (lane == 0) {
+    if (pos_dist) pos_dist[row] = pd;
+    if (neg_dist) neg_dist[row] = nd;
+    hinge_rows[row] = fmaxf(hinge, 0.f);
+  }
+  if (!dq) return;
+
+  // d cos(a,b)/da = (v - u cos r)/c, r = c/|a| (|a|>0) else 0  (r == 1 unless |a| < eps)
+  const float g = hinge > 0.f ? grad_scale : 0.f;
+  const float rq = nq > 0.f ? cq / nq : 0.f, rp = np_ > 0.f ? cp / np_ : 0.f, rn = nn > 0.f ? cn / nn : 0.f;
+  const float kqp = cos_p * rq, kqn = cos_n * rq, kp = cos_p * rp, kn = cos_n * rn;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * TT_WAVE + lane;
+    if (col < P) {
+      const float u = xq[c], vp = xp[c], vn = xn[c];
+      const float dcp_dq = (vp - u * kqp) / cq;
+      const float dcn_dq = (vn - u * kqn) / cq;
+      dq[o + col] = g * (dcn_dq - dcp_dq);
+      dp[o + col] = -g * ((u - vp * kp) / cp);
+      dn[o + col] = g * ((u - vn * kn) / cn);
+    }
+  }
+}
+
+// Single workgroup: loss = (sum_b hinge_b) / B in a fixed order; optionally adds
+// into a running {sum, count, last} accumulator (the engine's deferred loss.item()).
+__global__ __launch_bounds__(kThreads) void loss_mean_kernel(const float* __restrict__ hinge_rows,
+                                                             long long B, float* __restrict__ loss,
+                                                             double* __restrict__ acc_sum,
+                                                             long long* __restrict__ acc_count) {
+  __shared__ float red[kWavesPerBlock];
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < B; i += kThreads) s += hinge_rows[i];
+  s = tt_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float l = (((red[0] + red[1]) + red[2]) + red[3]) / static_cast<float>(B);
+    if (loss) *loss = l;
+    if (acc_sum) {
+      *acc_sum += static_cast<double>(l);
+      *acc_count += 1;
+    }
+  }
+}
+
+// torch.optim.Adam single-tensor op order (see oracle adam_step): fp32 throughout,
+// un-fused multiplies/adds where ATen's vectorised CPU kernels do not fuse.
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float one_minus_b1, float b2,
+                                          float one_minus_b2, float step_size, float bc2_sqrt, float eps) {
+  m = __fadd_rn(m, __fmul_rn(one_minus_b1, __fsub_rn(g, m)));                        // m.lerp_(g, 1-b1)
+  v = __fadd_rn(__fmul_rn(v, b2), __fmul_rn(__fmul_rn(one_minus_b2, g), g));         // v.mul_(b2).addcmul_(g, g, 1-b2)
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);            // (v.sqrt()/bc2_sqrt).add_(eps)
+  p = __fadd_rn(p, __fmul_rn(-step_size, __fdiv_rn(m, denom)));                      // p.addcdiv_(m, denom, -step_size)
+}
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        int nslabs, long long slab_stride,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        long long n, float one_minus_b1, float b2,
+                                                        float one_minus_b2, float step_size,
+                                                        float bc2_sqrt, float eps, float grad_scale) {
+  const long long i4 = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 3 < n) {
+    float4 gs = *reinterpret_cast<const float4*>(g + i4);
+    for (int z = 1; z < nslabs; ++z) {
+      const float4 t = *reinterpret_cast<const float4*>(g + z * slab_stride + i4);
+      gs.x += t.x; gs.y += t.y; gs.z += t.z; gs.w += t.w;
+    }
+    float4 pp = *reinterpret_cast<float4*>(p + i4);
+    float4 mm = *reinterpret_cast<float4*>(m + i4);
+    float4 vv = *reinterpret_cast<float4*>(v + i4);
+    float* ge = &gs.x; float* pe = &pp.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      adam_elem(pe[e], me[e], ve[e], ge[e] * grad_scale, one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps);
+    }
+    *reinterpret_cast<float4*>(p + i4) = pp;
+    *reinterpret_cast<float4*>(m + i4) = mm;
+    *reinterpret_cast<float4*>(v + i4) = vv;
+  } else {
+    for (long long i = i4; i < n; ++i) {
+      float gg = g[i];
+      for (int z = 1; z < nslabs; ++z) gg += g[z * slab_stride + i];
+      gg *= grad_scale;
+      adam_elem(p[i], m[i], v[i], gg, one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs,
+                                                                long long slab_stride,
+                                                                float* __restrict__ out, long long n,
+                                                                int accumulate) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  float s = slabs[i];
+  for (int z = 1; z < nslabs; ++z) s += slabs[z * slab_stride + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+}  // namespace
+
+// internal (engine.hip): loss mean with the running accumulator
+int tt_launch_loss_mean(const float* hinge_rows, long long B, float* loss, double* acc_sum,
+                        long long* acc_count, hipStream_t st) {
+  hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(kThreads), 0, st, hinge_rows, B, loss, acc_sum, acc_count);
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
+// internal: triplet rows only (no mean)
+int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float margin, float grad_scale,
+                           long long B, int P, float* pos_dist, float* neg_dist, float* hinge_rows,
+                           float* dq, float* dp, float* dn, hipStream_t st) {
+  const dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
+  const int nc = (P + TT_WAVE - 1) / TT_WAVE;
+#define TT_TRIP(NC)                                                                                     \
+  hipLaunchKernelGGL(triplet_kernel<NC>, grid, block, 0, st, q, p, n, margin, grad_scale, B, P, pos_dist, \
+                     neg_dist, hinge_rows, dq, dp, dn)
+  if (nc <= 1) TT_TRIP(1);
+  else if (nc <= 2) TT_TRIP(2);
+  else if (nc <= 4) TT_TRIP(4);
+  else if (nc <= 6) TT_TRIP(6);
+  else if (nc <= 8) TT_TRIP(8);
+  else if (nc <= 12) TT_TRIP(12);
+  else if (nc <= 16) TT_TRIP(16);
+  else return TT_ERR_UNSUPPORTED;  // P > 1024
+#undef TT_TRIP
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
+extern "C" int tt_triplet_fwd_bwd_f32(const float* q, const float* p, const float* n, float margin,
+                                      float grad_scale, int64_t B, int P, float* loss, float* pos_dist,
+                                      float* neg_dist, float* hinge_rows, float* dq, float* dp, float* dn,
+                                      tt_stream_t stream) {
+  TT_REQUIRE(q && p && n && hinge_rows, TT_ERR_NULL_POINTER);
+  TT_REQUIRE((dq && dp && dn) || (!dq && !dp && !dn), TT_ERR_NULL_POINTER);
+  TT_REQUIRE(B >= 1 && P >= 1 && P <= 1024, TT_ERR_BAD_SHAPE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, pos_dist, neg_dist, hinge_rows, dq, dp, dn, st);
+  if (rc != TT_OK) return rc;
+  if (loss) return tt_launch_loss_mean(hinge_rows, B, loss, nullptr, nullptr, st);
+  return TT_OK;
+}
+
+extern "C" int tt_adam_f32(float* params, const float* grads, int nslabs, int64_t slab_stride,
+                           float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                           double eps, int64_t step, float grad_scale, tt_stream_t stream) {
+  TT_REQUIRE(params && grads && exp_avg && exp_avg_sq, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(n >= 0 && nslabs >= 1 && step >= 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(tt_aligned16(params) && tt_aligned16(grads) && tt_aligned16(exp_avg) && tt_aligned16(exp_avg_sq),
+             TT_ERR_ALIGNMENT);
+  TT_REQUIRE(nslabs == 1 || (slab_stride % 4) == 0, TT_ERR_ALIGNMENT);
+  if (n == 0) return TT_OK;
+  // bias corrections in double on the host, as torch does for a python-float step
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const long long nthreads = (n + 3) / 4;
+  const dim3 grid((unsigned)((nthreads + kThreads - 1) / kThreads)), block(kThreads);
+  hipLaunchKernelGGL(adam_kernel, grid, block, 0, static_cast<hipStream_t>(stream), params, grads, nslabs,
+                     (long long)slab_stride, exp_avg, exp_avg_sq, (long long)n, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps, grad_scale);
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
+extern "C" int tt_reduce_slabs_f32(const float* slabs, int nslabs, int64_t slab_stride, float* out, int64_t n,
+                                   int accumulate, tt_stream_t stream) {
+  TT_REQUIRE(slabs && out, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(n >= 0 && nslabs >= 1, TT_ERR_BAD_SHAPE);
+  if (n == 0) return TT_OK;
+  const dim3 grid((unsigned)((n + kThreads - 1) / kThreads)), block(kThreads);
+  hipLaunchKernelGGL(reduce_slabs_kernel, grid, block, 0, static_cast<hipStream_t>(stream), slabs, nslabs,
+                     (long long)slab_stride, out, (long long)n, accumulate);
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}

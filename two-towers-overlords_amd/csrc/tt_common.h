@@ -1,0 +1,38 @@
+// Shared device/host helpers for the gfx950 two-tower hot path kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tt_hotpath.h"
+
+#define TT_WAVE 64
+
+#define TT_REQUIRE(cond, code) \
+  do {                         \
+    if (!(cond)) return (code); \
+  } while (0)
+
+// Launch-error check without synchronising (launch errors surface immediately,
+// execution errors at the caller's next sync).
+#define TT_CHECK_LAUNCH()                    \
+  do {                                       \
+    hipError_t _e = hipGetLastError();       \
+    if (_e != hipSuccess) return (int)_e;    \
+  } while (0)
+
+#define TT_HIP(call)                         \
+  do {                                       \
+    hipError_t _e = (call);                  \
+    if (_e != hipSuccess) return (int)_e;    \
+  } while (0)
+
+static inline bool tt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#ifdef __HIPCC__
+// Butterfly sum over the 64 lanes of a wave; every lane ends with the total.
+// Fixed order => bitwise reproducible.
+__device__ __forceinline__ float tt_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, TT_WAVE);
+  return v;
+}
+#endif

@@ -1,0 +1,146 @@
+"""HotPathEngine — Python handle on tt_engine (include/tt_hotpath.h): the whole
+batch body of backend/training.py:36-53 (three encodes, loss, backward, Adam) as
+a few C calls over flat, torch-owned device buffers."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import TTEngineConfig, call
+from .ops import _INT_WIDTH, _req
+
+
+def tower_param_count(D: int, P: int) -> int:
+    return P * D + P + P * P + P
+
+
+def flat_param_slices(D: int, P: int):
+    """(name, offset, shape) of the 8 trainable tensors inside the flat buffer —
+    the reference's model.parameters() order (backend/model.py:33-38,84-85)."""
+    out, off = [], 0
+    for tower in ("query_tower", "document_tower"):
+        for name, shape in (("projection.0.weight", (P, D)), ("projection.0.bias", (P,)),
+                            ("projection.2.weight", (P, P)), ("projection.2.bias", (P,))):
+            n = 1
+            for s in shape:
+                n *= s
+            out.append((f"{tower}.{name}", off, shape))
+            off += n
+    return out
+
+
+class HotPathEngine:
+    def __init__(self, table: torch.Tensor, projection_dim: int, max_batch: int, max_seq_len: int):
+        _req(table, "table", torch.float32, 2)
+        self.device = table.device
+        self.table = table
+        self.V, self.D = table.shape
+        self.P = int(projection_dim)
+        self.max_B, self.max_S = int(max_batch), int(max_seq_len)
+        cfg = TTEngineConfig(self.V, self.D, self.P, self.max_B, self.max_S, self.device.index or 0, 0)
+        lib = _lib.load()
+        nbytes = lib.tt_engine_workspace_bytes(C.byref(cfg))
+        if nbytes == 0:
+            raise ValueError(f"unsupported engine configuration V={self.V} D={self.D} P={self.P} B={max_batch} S={max_seq_len}")
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            assert self.workspace.data_ptr() % 256 == 0
+            h = C.c_void_p()
+            call("tt_engine_create", C.byref(cfg), self.workspace.data_ptr(), nbytes, self._stream(), C.byref(h))
+        self._h = h
+        self.n_params = int(lib.tt_engine_param_count(h))
+        self.n_slabs = int(lib.tt_engine_grad_slabs(h))
+        self.params = self.exp_avg = self.exp_avg_sq = None
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            _lib.load().tt_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ binding
+    def bind(self, params: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor) -> None:
+        for t, name in ((params, "params"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+            _req(t, name, torch.float32, 1)
+            if t.numel() != self.n_params or t.device != self.device:
+                raise ValueError(f"{name}: expected {self.n_params} floats on {self.device}")
+        self.params, self.exp_avg, self.exp_avg_sq = params, exp_avg, exp_avg_sq
+        call("tt_engine_bind", self._h, self.table.data_ptr(), params.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr())
+
+    # ------------------------------------------------------------------ phases
+    def _ids_args(self, ids, mask, lens) -> Tuple[int, int, Optional[int], int, Optional[int], int, int]:
+        _req(ids, "ids", ndim=3)
+        if ids.dtype not in _INT_WIDTH or ids.shape[0] != 3 or ids.device != self.device:
+            raise ValueError("ids: expected an int32/int64 [3, B, S] tensor (q, pos, neg) on the engine device")
+        _, B, S = ids.shape
+        mw = 8
+        if mask is not None:
+            _req(mask, "mask", ndim=3)
+            if mask.dtype not in _INT_WIDTH or tuple(mask.shape) != (3, B, S) or mask.device != self.device:
+                raise ValueError("mask: expected an int32/int64 [3, B, S] tensor")
+            mw = _INT_WIDTH[mask.dtype]
+            lens = None
+        elif lens is not None:
+            _req(lens, "lens", torch.int32, 2)
+            if tuple(lens.shape) != (3, B) or lens.device != self.device:
+                raise ValueError("lens: expected an int32 [3, B] tensor")
+        return (ids.data_ptr(), _INT_WIDTH[ids.dtype], None if mask is None else mask.data_ptr(), mw,
+                None if lens is None else lens.data_ptr(), B, S)
+
+    def pool(self, slot: int, ids, mask=None, lens=None) -> None:
+        a = self._ids_args(ids, mask, lens)
+        call("tt_engine_pool", self._h, slot, a[0], a[1], a[2], a[3], a[4], a[5], a[6], self._stream())
+
+    def fwd_bwd(self, slot: int, B: int, margin: float, grad_scale: Optional[float] = None) -> None:
+        call("tt_engine_fwd_bwd", self._h, slot, B, margin, (1.0 / B) if grad_scale is None else grad_scale, self._stream())
+
+    def reduce_grads(self, out: torch.Tensor, accumulate: bool = False) -> None:
+        _req(out, "grad_out", torch.float32, 1)
+        if out.numel() != self.n_params:
+            raise ValueError("grad_out: wrong size")
+        call("tt_engine_reduce_grads", self._h, out.data_ptr(), int(accumulate), self._stream())
+
+    def adam(self, step: int, lr: float, grads: Optional[torch.Tensor] = None, beta1=0.9, beta2=0.999, eps=1e-8) -> None:
+        g = None
+        if grads is not None:
+            _req(grads, "grads", torch.float32, 1)
+            g = grads.data_ptr()
+        call("tt_engine_adam", self._h, g, lr, beta1, beta2, eps, step, self._stream())
+
+    def train_step(self, ids, mask=None, lens=None, *, margin: float, lr: float, step: int) -> None:
+        a = self._ids_args(ids, mask, lens)
+        call("tt_engine_train_step", self._h, a[0], a[1], a[2], a[3], a[4], a[5], a[6], margin, lr, step, self._stream())
+
+    def read_stats(self, reset: bool = True) -> Tuple[float, int, float]:
+        """(sum of batch losses, batches, last batch loss); synchronises the stream."""
+        s, c, l = C.c_double(), C.c_int64(), C.c_float()
+        call("tt_engine_read_stats", self._h, C.byref(s), C.byref(c), C.byref(l), int(reset), self._stream())
+        return s.value, c.value, l.value
+
+    # ------------------------------------------------------------------ views
+    def _view(self, ptr: int, numel: int) -> torch.Tensor:
+        off = ptr - self.workspace.data_ptr()
+        assert 0 <= off and off + 4 * numel <= self.workspace.numel()
+        return self.workspace[off: off + 4 * numel].view(torch.float32)
+
+    def pooled(self, slot: int, B: int) -> torch.Tensor:
+        return self._view(_lib.load().tt_engine_pooled(self._h, slot), 3 * B * self.D).view(3, B, self.D)
+
+    def embeddings(self, B: int) -> torch.Tensor:
+        return self._view(_lib.load().tt_engine_embeddings(self._h), 3 * B * self.P).view(3, B, self.P)
+
+    def grad_slabs(self) -> torch.Tensor:
+        stride = (self.n_params + 3) // 4 * 4
+        return self._view(_lib.load().tt_engine_grad_slab0(self._h), self.n_slabs * stride).view(self.n_slabs, stride)[:, : self.n_params]

@@ -1,0 +1,213 @@
+"""Tensor-level entry points over the C ABI (include/tt_hotpath.h).
+
+Shapes, dtypes, contiguity and devices are validated here, *before* the call;
+the C side only sees raw device pointers and sizes.  All work is enqueued on
+torch's current HIP stream.  There is no fallback implementation: without a
+GPU tensor and the HIP library these functions raise.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import TT_I32, TT_I64, call
+
+_INT_WIDTH = {torch.int32: TT_I32, torch.int64: TT_I64}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, dtype=None, ndim: Optional[int] = None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name}: expected a GPU (HIP) tensor, got device {t.device}. The MI355X HIP library is the "
+            "only implementation of this path; there is no CPU fallback."
+        )
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous (shape {tuple(t.shape)}, stride {t.stride()})")
+    return t
+
+
+def _int_tensor(t: torch.Tensor, name: str) -> int:
+    if t.dtype not in _INT_WIDTH:
+        raise TypeError(f"{name}: expected int32 or int64, got {t.dtype}")
+    return _INT_WIDTH[t.dtype]
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _mask_or_lens(mask, lens, N: int, S: int, dev) -> Tuple[Optional[torch.Tensor], int, Optional[torch.Tensor]]:
+    mw = TT_I64
+    if mask is not None:
+        _req(mask, "attention_mask", ndim=2)
+        mw = _int_tensor(mask, "attention_mask")
+        if tuple(mask.shape) != (N, S) or mask.device != dev:
+            raise ValueError(f"attention_mask: expected shape {(N, S)} on {dev}, got {tuple(mask.shape)} on {mask.device}")
+        lens = None
+    elif lens is not None:
+        _req(lens, "lens", dtype=torch.int32, ndim=1)
+        if lens.shape[0] != N or lens.device != dev:
+            raise ValueError(f"lens: expected shape {(N,)} on {dev}")
+    return mask, mw, lens
+
+
+def gather_pool_norm(
+    table: torch.Tensor,
+    input_ids: torch.Tensor,
+    attention_mask: Optional[torch.Tensor] = None,
+    lens: Optional[torch.Tensor] = None,
+    out: Optional[torch.Tensor] = None,
+    check_ids: bool = False,
+) -> torch.Tensor:
+    """K1: normalize(mean_pool(table[input_ids], attention_mask)) -> [N, D].
+    Replaces backend/model.py:51-56 (`embed` mode).  check_ids=True synchronises
+    and raises if any unmasked id was outside [0, V)."""
+    _req(table, "table", torch.float32, 2)
+    _req(input_ids, "input_ids", ndim=2)
+    iw = _int_tensor(input_ids, "input_ids")
+    if input_ids.device != table.device:
+        raise ValueError("input_ids and table must be on the same device")
+    N, S = input_ids.shape
+    V, D = table.shape
+    mask, mw, lens = _mask_or_lens(attention_mask, lens, N, S, table.device)
+    if out is None:
+        out = torch.empty((N, D), dtype=torch.float32, device=table.device)
+    else:
+        _req(out, "out", torch.float32, 2)
+        if tuple(out.shape) != (N, D):
+            raise ValueError(f"out: expected {(N, D)}, got {tuple(out.shape)}")
+    flag = torch.zeros(1, dtype=torch.int32, device=table.device) if check_ids else None
+    with torch.cuda.device(table.device):
+        call("tt_gather_pool_norm_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw, _ptr(lens),
+             out.data_ptr(), N, S, D, V, _ptr(flag), _stream())
+    if check_ids and int(flag.item()) != 0:
+        raise IndexError(f"input_ids contains a token id outside [0, {V})")
+    return out
+
+
+def pool_norm_dense(
+    hidden: torch.Tensor,
+    attention_mask: Optional[torch.Tensor] = None,
+    lens: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """normalize(mean_pool(hidden, attention_mask)) over dense [N,S,D] states
+    (`bert` mode).  Replaces backend/model.py:55-56,63-72."""
+    _req(hidden, "hidden", torch.float32, 3)
+    N, S, D = hidden.shape
+    mask, mw, lens = _mask_or_lens(attention_mask, lens, N, S, hidden.device)
+    out = torch.empty((N, D), dtype=torch.float32, device=hidden.device)
+    with torch.cuda.device(hidden.device):
+        call("tt_pool_norm_dense_f32", hidden.data_ptr(), _ptr(mask), mw, _ptr(lens), out.data_ptr(), N, S, D, _stream())
+    return out
+
+
+def embed_gather(table: torch.Tensor, input_ids: torch.Tensor, check_ids: bool = False) -> torch.Tensor:
+    """table[input_ids] -> [..., D] (materialised; backend/model.py:51-52 `embed` mode)."""
+    _req(table, "table", torch.float32, 2)
+    _req(input_ids, "input_ids")
+    iw = _int_tensor(input_ids, "input_ids")
+    V, D = table.shape
+    out = torch.empty((*input_ids.shape, D), dtype=torch.float32, device=table.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=table.device) if check_ids else None
+    with torch.cuda.device(table.device):
+        call("tt_embed_gather_f32", table.data_ptr(), input_ids.data_ptr(), iw, out.data_ptr(), input_ids.numel(), D, V,
+             _ptr(flag), _stream())
+    if check_ids and int(flag.item()) != 0:
+        raise IndexError(f"input_ids contains a token id outside [0, {V})")
+    return out
+
+
+def proj_fwd(x, w1, b1, w2, b2) -> Tuple[torch.Tensor, torch.Tensor]:
+    """K2 forward: returns (out, h) with h = relu(x w1^T + b1), out = h w2^T + b2.
+    Replaces backend/model.py:33-38,59."""
+    _req(x, "x", torch.float32, 2)
+    M, D = x.shape
+    P = w1.shape[0]
+    for t, name, shape in ((w1, "w1", (P, D)), (b1, "b1", (P,)), (w2, "w2", (P, P)), (b2, "b2", (P,))):
+        _req(t, name, torch.float32)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{name}: expected {shape}, got {tuple(t.shape)}")
+    h = torch.empty((M, P), dtype=torch.float32, device=x.device)
+    out = torch.empty((M, P), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        call("tt_proj_fwd_f32", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+             h.data_ptr(), out.data_ptr(), M, D, P, _stream())
+    return out, h
+
+
+def proj_bwd(d_out, x, h, w2) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """K2 backward for the parameters: returns (dW1, db1, dW2, db2)."""
+    _req(d_out, "d_out", torch.float32, 2)
+    _req(x, "x", torch.float32, 2)
+    _req(h, "h", torch.float32, 2)
+    _req(w2, "w2", torch.float32, 2)
+    M, P = d_out.shape
+    D = x.shape[1]
+    if tuple(x.shape) != (M, D) or tuple(h.shape) != (M, P) or tuple(w2.shape) != (P, P):
+        raise ValueError("proj_bwd: inconsistent shapes")
+    dev = x.device
+    dW1 = torch.empty((P, D), dtype=torch.float32, device=dev)
+    db1 = torch.empty((P,), dtype=torch.float32, device=dev)
+    dW2 = torch.empty((P, P), dtype=torch.float32, device=dev)
+    db2 = torch.empty((P,), dtype=torch.float32, device=dev)
+    if M == 0:
+        for t in (dW1, db1, dW2, db2):
+            t.zero_()
+        return dW1, db1, dW2, db2
+    nbytes = _lib.load().tt_proj_bwd_workspace_bytes(M, D, P)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        call("tt_proj_bwd_f32", d_out.data_ptr(), x.data_ptr(), h.data_ptr(), w2.data_ptr(), dW1.data_ptr(),
+             db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), ws.data_ptr(), nbytes, 0, M, D, P, _stream())
+    return dW1, db1, dW2, db2
+
+
+def triplet_fwd_bwd(q, p, n, margin: float, grad_scale: Optional[float] = None, need_grad: bool = True):
+    """K3: returns (loss[1], pos_dist[B], neg_dist[B], dq, dp, dn); grads are
+    grad_scale * d(sum hinge) (default 1/B == loss.backward()).  Replaces
+    backend/model.py:132-145."""
+    for t, name in ((q, "anchor"), (p, "positive"), (n, "negative")):
+        _req(t, name, torch.float32, 2)
+    B, P = q.shape
+    if tuple(p.shape) != (B, P) or tuple(n.shape) != (B, P):
+        raise ValueError("triplet: anchor/positive/negative shapes differ")
+    if B == 0:
+        raise ValueError("triplet: empty batch")
+    dev = q.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    pd = torch.empty(B, dtype=torch.float32, device=dev)
+    nd = torch.empty(B, dtype=torch.float32, device=dev)
+    hinge = torch.empty(B, dtype=torch.float32, device=dev)
+    dq = dp = dn = None
+    if need_grad:
+        dq, dp, dn = (torch.empty_like(q) for _ in range(3))
+    gs = (1.0 / B) if grad_scale is None else grad_scale
+    with torch.cuda.device(dev):
+        call("tt_triplet_fwd_bwd_f32", q.data_ptr(), p.data_ptr(), n.data_ptr(), margin, gs, B, P, loss.data_ptr(),
+             pd.data_ptr(), nd.data_ptr(), hinge.data_ptr(), _ptr(dq), _ptr(dp), _ptr(dn), _stream())
+    return loss, pd, nd, dq, dp, dn
+
+
+def adam_step_flat(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8,
+                   grad_scale: float = 1.0) -> None:
+    """K4: one torch.optim.Adam step (defaults of backend/training.py:436) over flat fp32 buffers, in place."""
+    n = params.numel()
+    for t, name in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, name, torch.float32)
+        if t.numel() != n:
+            raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
+    with torch.cuda.device(params.device):
+        call("tt_adam_f32", params.data_ptr(), grads.data_ptr(), 1, 0, exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+             lr, beta1, beta2, eps, step, grad_scale, _stream())

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — triplets/sec of the full training step (3 encodes + triplet loss +
+backward + Adam [+ gradient all-reduce]) of the two-tower hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], the shape the metric is quoted on): synthetic
+(q, pos, neg) token-id triplets, seq_len 128 full length, MiniLM-shaped table
+V=30522 x D=384 (N(0, 0.02^2), seed 1), proj_dim 384, 2048 triplets per GPU per
+step (weak scaling), `embed` encoder mode, fp32.  Inputs (ids) are resident in
+HBM before the timed region.  One JSON line on rank 0.
+
+Extra objects: `roofline` (K1 gather+pool kernel, HBM bound, live HIP-event
+timing) and `cpu_baseline` (the CPU oracle — a torch-CPU restatement of the
+reference loop — on a bounded sample of the same workload, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: V, D, P, B per GPU, S
+    "c2": dict(V=30522, D=384, P=384, B=2048, S=128, label="configs[1]: MiniLM-L6 table V=30522 d=384, proj 384, batch 2048/GPU, seq 128"),
+    "c4": dict(V=250000, D=768, P=768, B=16384, S=256, label="configs[3]: synthetic V=250k d=768 proj 768 batch 16384/GPU seq 256 (HBM stress)"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def k1_algorithmic_bytes(n_texts, S, D):
+    """per text n_valid*D*4 (table rows) + S*4 (ids as int32) + D*4 (output)."""
+    return n_texts * (S * D * 4 + S * 4 + D * 4)
+
+
+def make_ids(V, B, S, n_batches, seed, device, zipf=False):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        if zipf:
+            u = torch.rand(3, B, S, generator=g, dtype=torch.float64)
+            ids = (torch.exp(u * torch.log(torch.tensor(float(V)))) - 1).long().clamp_(0, V - 1)
+        else:
+            ids = torch.randint(0, V, (3, B, S), generator=g, dtype=torch.int64)
+        out.append(ids.to(torch.int32).to(device))
+    return out
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """Oracle train_epoch (torch-CPU restatement of backend/training.py:26-63) on all host cores."""
+    from oracle import two_towers_oracle as orc
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    V, D, P, S = cfg["V"], cfg["D"], cfg["P"], cfg["S"]
+    B = min(cfg["B"], 2048)
+    table = orc.synthetic_table(V, D, seed=1)
+    params = orc.init_params(D, P, seed=2)
+    st = orc.AdamState(lr=1e-3)
+    batch = orc.synthetic_batch(B, S, V, seed=1234)
+    orc.train_epoch(table, [batch], params, st, 0.3)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.train_epoch(table, [batch], params, st, 0.3)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 64:
+            break
+    return {
+        "value": n * B / el, "unit": "triplets/s", "cores": cores, "kind": "port",
+        "sample": f"{n} batches of {B} triplets (S={S}, D={D}, P={P}, V={V}, embed mode, fp32) in {el:.1f} s, "
+                  f"oracle/two_towers_oracle.train_epoch, torch {torch.__version__} CPU, {cores} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default: the config's)")
+    ap.add_argument("--zipf", action="store_true", help="Zipf(1) token ids instead of uniform")
+    ap.add_argument("--k1-only", action="store_true", help="time only the gather+pool kernel (diagnostic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-streams", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP library is the only implementation of the hot path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import two_towers_overlords_amd as pkg
+    from two_towers_overlords_amd.training import TripletTrainer
+
+    pkg.load()
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    V, D, P, B, S = cfg["V"], cfg["D"], cfg["P"], cfg["B"], cfg["S"]
+
+    gt = torch.Generator().manual_seed(1)
+    table = (torch.randn(V, D, generator=gt) * 0.02).to(device)
+    from two_towers_overlords_amd.engine import flat_param_slices
+    gp = torch.Generator().manual_seed(2)
+    params = {}
+    for name, _, shape in flat_param_slices(D, P):
+        bound = 1.0 / (shape[-1] if len(shape) == 2 else (D if ".0." in name else P)) ** 0.5
+        params[name] = ((torch.rand(*shape, generator=gp) * 2 - 1) * bound).to(device)
+    trainer = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
+                             overlap_streams=args.overlap_streams)
+    n_distinct = 8
+    id_batches = make_ids(V, B, S, n_distinct, seed=1234 + rank, device=device, zipf=args.zipf)
+    batches = [(ids, None, None) for ids in id_batches]  # full-length: no mask, no lens
+    eng = trainer.engine
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    k1_ev = []
+
+    def run(n_steps, timed):
+        """n_steps batch bodies with the next batch's gather prefetched (TripletTrainer.train_epoch order)."""
+        slot = 0
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); trainer._pool(slot, batches[0]); e1.record(); k1_ev.append((e0, e1))
+        else:
+            trainer._pool(slot, batches[0])
+        for i in range(n_steps):
+            nxt = batches[(i + 1) % n_distinct] if i + 1 < n_steps else None
+            if args.k1_only:
+                if nxt is not None:
+                    trainer._pool(slot ^ 1, nxt)
+            elif timed and nxt is not None:
+                # same sequence as TripletTrainer._apply, with HIP events around the K1 launch
+                _apply_with_events(trainer, B, B * world, slot, nxt, k1_ev)
+            else:
+                trainer._apply(B, B * world, slot, nxt)
+            slot ^= 1
+
+    run(args.warmup, timed=False)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, timed=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    loss_avg = trainer.epoch_loss()
+
+    k1_ms = sum(a.elapsed_time(b) for a, b in k1_ev) / max(len(k1_ev), 1)
+    alg = k1_algorithmic_bytes(3 * B, S, D)
+    achieved = alg / (k1_ms * 1e-3) / 1e9
+    result = {
+        "metric": "triplets/sec (q,pos,neg @ seq128/d384), full training step" if args.config == "c2"
+                  else "triplets/sec, full training step",
+        "value": args.steps * B * world / elapsed,
+        "unit": "triplets/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["label"], "encoder_mode": "embed", "vocab": V, "embed_dim": D, "proj_dim": P,
+                   "seq_len": S, "batch_per_gpu": B, "global_batch": B * world, "ids": "int32 [3,B,S], "
+                   + ("zipf" if args.zipf else "uniform") + ", full length", "parallelism": f"dp{world}",
+                   "k1_only": bool(args.k1_only)},
+        "roofline": {"kernel": "pool_norm_kernel (K1 gather + masked mean-pool + L2 normalise)", "bound": "hbm",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
+                     "launches_timed": len(k1_ev)},
+        "avg_loss": loss_avg,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _apply_with_events(trainer, B, gB, slot, nxt, k1_ev):
+    """TripletTrainer._apply with the K1 launch bracketed by HIP events on the launch stream."""
+    orig = trainer._pool
+
+    def timed_pool(s, b):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); orig(s, b); e1.record()
+        k1_ev.append((e0, e1))
+
+    trainer._pool = timed_pool
+    try:
+        trainer._apply(B, gB, slot, nxt)
+    finally:
+        trainer._pool = orig
+
+
+if __name__ == "__main__":
+    main()

@@ -236,9 +236,12 @@ int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const
  * backend/training.py:53's loss.item() is deferred to tt_engine_read_stats).
  *   grad_scale: 1/B for the reference semantics (mean over the batch);
  *               1/B_global under data parallelism; 1/(B*k) under accumulation.
+ *   loss_denominator: the logged batch loss is (sum_b hinge_b) / loss_denominator —
+ *               B for the reference semantics; B_global on a data-parallel shard,
+ *               so that the per-rank values add up to the global batch loss.
  */
 int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin, float grad_scale,
-                      tt_stream_t stream);
+                      float loss_denominator, tt_stream_t stream);
 
 /* grad_out[param_count] (+)= sum of slabs — the flat bucket handed to the RCCL all-reduce. */
 int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumulate, tt_stream_t stream);

@@ -37,14 +37,15 @@ def golden():
     return load_golden
 
 
-def assert_params_close(actual, desired, lr, nsteps, tight=1e-6, frac_tight=0.999):
+def assert_params_close(actual, desired, lr, nsteps, tight=1e-6, frac_loose=0.002):
     """Post-Adam parameters.  Adam's update lr*m/(sqrt(v)+eps) is ill-conditioned
     for elements whose gradient is at rounding-noise level (|g| ~ 1e-8: a 1e-10
     reassociation difference moves the update by ~1 % of lr), so the check is
-    two-tier: >= 99.9 % of the elements agree to `tight`, and every element
-    agrees to 5 % of the total distance Adam can move it (lr * nsteps)."""
+    two-tier: all but max(3, 0.2 %) of the elements agree to `tight`, and every
+    element agrees to 5 % of the total distance Adam can move it (lr * nsteps)."""
     a = np.asarray(actual, dtype=np.float64).ravel()
     d = np.asarray(desired, dtype=np.float64).ravel()
     err = np.abs(a - d)
     assert err.max() <= 0.05 * lr * nsteps + tight, f"max err {err.max():.3e}"
-    assert (err <= tight).mean() >= frac_tight, f"only {(err <= tight).mean():.5f} within {tight}"
+    n_loose = int((err > tight).sum())
+    assert n_loose <= max(3, frac_loose * err.size), f"{n_loose} of {err.size} elements beyond {tight}"

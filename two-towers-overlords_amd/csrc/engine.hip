@@ -10,7 +10,7 @@
 #include <new>
 #include "proj.h"
 
-int tt_launch_loss_mean(const float* hinge_rows, long long B, float* loss, double* acc_sum,
+int tt_launch_loss_mean(const float* hinge_rows, long long B, float denom, float* loss, double* acc_sum,
                         long long* acc_count, hipStream_t st);
 int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float margin, float grad_scale,
                            long long B, int P, float* pos_dist, float* neg_dist, float* hinge_rows,
@@ -169,11 +169,11 @@ extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_d
 }
 
 extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin, float grad_scale,
-                                 tt_stream_t stream) {
+                                 float loss_denominator, tt_stream_t stream) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
   TT_REQUIRE(slot == 0 || slot == 1, TT_ERR_BAD_SHAPE);
-  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && loss_denominator > 0.f, TT_ERR_BAD_SHAPE);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int D = e->cfg.D, P = e->cfg.P;
   ttp::Tower t[2] = {};
@@ -204,7 +204,7 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin
   rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
                               e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, st);
   if (rc != TT_OK) return rc;
-  rc = tt_launch_loss_mean(e->hinge, B, e->loss, e->loss_sum, e->loss_cnt, st);
+  rc = tt_launch_loss_mean(e->hinge, B, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
   if (rc != TT_OK) return rc;
   return ttp::backward(t, 2, D, P, e->nslabs, e->slab_stride, st);
 }
@@ -229,7 +229,7 @@ extern "C" int tt_engine_train_step(tt_engine* e, const void* ids, int ids_dtype
                                     double lr, int64_t step, tt_stream_t stream) {
   int rc = tt_engine_pool(e, 0, ids, ids_dtype, mask, mask_dtype, lens, B, S, stream);
   if (rc != TT_OK) return rc;
-  rc = tt_engine_fwd_bwd(e, 0, B, margin, 1.0f / (float)B, stream);
+  rc = tt_engine_fwd_bwd(e, 0, B, margin, 1.0f / (float)B, (float)B, stream);
   if (rc != TT_OK) return rc;
   return tt_engine_adam(e, nullptr, lr, 0.9, 0.999, 1e-8, step, stream);
 }

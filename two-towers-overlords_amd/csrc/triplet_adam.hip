@@ -76,10 +76,10 @@ __global__ __launch_bounds__(kThreads) void triplet_kernel(
   }
 }
 
-// Single workgroup: loss = (sum_b hinge_b) / B in a fixed order; optionally adds
+// Single workgroup: loss = (sum_b hinge_b) / denom in a fixed order; optionally adds
 // into a running {sum, count, last} accumulator (the engine's deferred loss.item()).
 __global__ __launch_bounds__(kThreads) void loss_mean_kernel(const float* __restrict__ hinge_rows,
-                                                             long long B, float* __restrict__ loss,
+                                                             long long B, float denom, float* __restrict__ loss,
                                                              double* __restrict__ acc_sum,
                                                              long long* __restrict__ acc_count) {
   __shared__ float red[kWavesPerBlock];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void loss_mean_kernel(const float* __rest
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float l = (((red[0] + red[1]) + red[2]) + red[3]) / static_cast<float>(B);
+    const float l = (((red[0] + red[1]) + red[2]) + red[3]) / denom;
     if (loss) *loss = l;
     if (acc_sum) {
       *acc_sum += static_cast<double>(l);
@@ -157,9 +157,9 @@ __global__ __launch_bounds__(kThreads) void reduce_slabs_kernel(const float* __r
 }  // namespace
 
 // internal (engine.hip): loss mean with the running accumulator
-int tt_launch_loss_mean(const float* hinge_rows, long long B, float* loss, double* acc_sum,
+int tt_launch_loss_mean(const float* hinge_rows, long long B, float denom, float* loss, double* acc_sum,
                         long long* acc_count, hipStream_t st) {
-  hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(kThreads), 0, st, hinge_rows, B, loss, acc_sum, acc_count);
+  hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(kThreads), 0, st, hinge_rows, B, denom, loss, acc_sum, acc_count);
   TT_CHECK_LAUNCH();
   return TT_OK;
 }
@@ -196,7 +196,7 @@ extern "C" int tt_triplet_fwd_bwd_f32(const float* q, const float* p, const floa
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, pos_dist, neg_dist, hinge_rows, dq, dp, dn, st);
   if (rc != TT_OK) return rc;
-  if (loss) return tt_launch_loss_mean(hinge_rows, B, loss, nullptr, nullptr, st);
+  if (loss) return tt_launch_loss_mean(hinge_rows, B, static_cast<float>(B), loss, nullptr, nullptr, st);
   return TT_OK;
 }
 

@@ -1,0 +1,133 @@
+"""Host-side mirror of the triplet batching of backend/data.py:90-152, plus the
+token-level form the device path consumes.
+
+`TripletDataLoader` keeps the reference's semantics exactly: shuffle, batch, and
+for every item draw an in-batch negative uniformly from the *other* items
+(`random.choice([j for j != i])`, rejected while the query_id is equal); the
+negative text is that item's *positive*.  Because negatives are in-batch
+positives, the token-level loader tokenises every query and
+positive ONCE and forms each batch's negatives by an index gather of the
+positives' token rows — no third tokenisation, identical ids.
+
+MSMarcoDataset (backend/data.py:13-87) is a network fetch + string wrangling
+and is out of scope; any map-style dataset of {"query_id","query","positive"}
+works here, as it does for the reference's loader.
+"""
+from __future__ import annotations
+
+import random
+from typing import Callable, Iterator, List, Optional, Sequence, Tuple
+
+import torch
+from torch.utils.data import DataLoader
+
+Triplet = Tuple[List[str], List[str], List[str]]
+
+
+def sample_negative_indices(query_ids: Sequence[int], rng=random) -> List[int]:
+    """backend/data.py:113-137 on indices: neg_idx[i] = j, drawn like
+    `_get_random_negative` (same `choice` call sequence, so the same seed gives the
+    same draws as the reference) and rejected while query_ids[j] == query_ids[i].
+    Like the reference this never terminates if every item shares one query_id and
+    raises IndexError for a batch of one."""
+    n = len(query_ids)
+    out = []
+    for i in range(n):
+        while True:
+            j = rng.choice([k for k in range(n) if k != i])
+            if query_ids[j] != query_ids[i]:
+                out.append(j)
+                break
+    return out
+
+
+class TripletDataLoader:
+    """Creates (queries, positives, negatives) string batches.  Mirrors backend/data.py:90-152."""
+
+    def __init__(self, dataset, batch_size: int = 1024, num_workers: int = 4, device: Optional[torch.device] = None):
+        self.dataset = dataset
+        self.batch_size = batch_size
+        self.dataloader = DataLoader(
+            dataset,
+            batch_size=batch_size,
+            shuffle=True,
+            num_workers=num_workers,
+            pin_memory=False,  # the items are Python strings; nothing to pin (data.py:106-108 pins for cuda)
+            persistent_workers=True if num_workers > 0 else False,
+        )
+
+    def create_triplets(self, batch: list) -> Triplet:
+        queries = [item["query"] for item in batch]
+        positives = [item["positive"] for item in batch]
+        neg_idx = sample_negative_indices([int(item["query_id"]) for item in batch])
+        negatives = [batch[j]["positive"] for j in neg_idx]
+        return queries, positives, negatives
+
+    def __iter__(self) -> Iterator[Triplet]:
+        for batch in self.dataloader:
+            batch_list = [
+                {"query": batch["query"][i], "positive": batch["positive"][i], "query_id": batch["query_id"][i]}
+                for i in range(len(batch["query"]))
+            ]
+            yield self.create_triplets(batch_list)
+
+    def __len__(self) -> int:
+        return len(self.dataloader)
+
+
+class TokenTripletLoader:
+    """Device-side triplet batches for the fused engine: yields
+    (ids [3,B,S] int32, lens [3,B] int32) with rows ordered (query, positive,
+    negative) like backend/training.py:40-42.
+
+    Every query and positive is tokenised once up front (`tokenizer(texts,
+    padding=True, truncation=True, max_length=512)` like model.py:43-45, any
+    callable returning `input_ids` + `attention_mask`), packed as int32 rows +
+    lengths, and kept on `device`.  Per batch only an index permutation and the
+    in-batch negative indices are produced on the host (reference semantics:
+    shuffle=True, drop_last=False, negatives via `sample_negative_indices`).
+    """
+
+    def __init__(self, dataset, tokenizer: Callable, batch_size: int, device, max_length: int = 512,
+                 seed: Optional[int] = None, shuffle: bool = True):
+        self.batch_size = batch_size
+        self.device = torch.device(device)
+        self.shuffle = shuffle
+        self.rng = random.Random(seed) if seed is not None else random
+        n = len(dataset)
+        items = [dataset[i] for i in range(n)]
+        self.query_ids = [int(it["query_id"]) for it in items]
+        self.q_ids, self.q_lens = self._tokenize(tokenizer, [it["query"] for it in items], max_length)
+        self.p_ids, self.p_lens = self._tokenize(tokenizer, [it["positive"] for it in items], max_length)
+
+    def _tokenize(self, tokenizer, texts, max_length):
+        tok = tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=max_length)
+        ids, mask = tok["input_ids"], tok["attention_mask"]
+        lens = mask.sum(1)
+        if not torch.equal(mask, (torch.arange(mask.shape[1]).unsqueeze(0) < lens.unsqueeze(1)).to(mask.dtype)):
+            raise ValueError("TokenTripletLoader expects prefix (right-padded) attention masks")
+        return ids.to(torch.int32).to(self.device), lens.to(torch.int32).to(self.device)
+
+    def __len__(self) -> int:
+        return (len(self.query_ids) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.query_ids)
+        order = list(range(n))
+        if self.shuffle:
+            self.rng.shuffle(order)
+        for s in range(0, n, self.batch_size):
+            idx = order[s: s + self.batch_size]
+            neg = sample_negative_indices([self.query_ids[i] for i in idx], self.rng)
+            it = torch.tensor(idx, device=self.device)
+            nt = it[torch.tensor(neg, device=self.device)]
+            q, ql = self.q_ids[it], self.q_lens[it]
+            p, pl = self.p_ids[it], self.p_lens[it]
+            ng, nl = self.p_ids[nt], self.p_lens[nt]
+            # pad to the longest row of this batch, like `padding=True` does per call
+            S = int(max(int(ql.max()), int(pl.max()), int(nl.max())))
+            ids = torch.zeros((3, len(idx), S), dtype=torch.int32, device=self.device)
+            ids[0, :, : min(S, q.shape[1])] = q[:, :S]
+            ids[1, :, : min(S, p.shape[1])] = p[:, :S]
+            ids[2, :, : min(S, ng.shape[1])] = ng[:, :S]
+            yield ids, torch.stack([ql, pl, nl])

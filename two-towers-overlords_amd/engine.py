@@ -103,8 +103,10 @@ class HotPathEngine:
         a = self._ids_args(ids, mask, lens)
         call("tt_engine_pool", self._h, slot, a[0], a[1], a[2], a[3], a[4], a[5], a[6], self._stream())
 
-    def fwd_bwd(self, slot: int, B: int, margin: float, grad_scale: Optional[float] = None) -> None:
-        call("tt_engine_fwd_bwd", self._h, slot, B, margin, (1.0 / B) if grad_scale is None else grad_scale, self._stream())
+    def fwd_bwd(self, slot: int, B: int, margin: float, grad_scale: Optional[float] = None,
+                loss_denominator: Optional[float] = None) -> None:
+        call("tt_engine_fwd_bwd", self._h, slot, B, margin, (1.0 / B) if grad_scale is None else grad_scale,
+             float(B) if loss_denominator is None else loss_denominator, self._stream())
 
     def reduce_grads(self, out: torch.Tensor, accumulate: bool = False) -> None:
         _req(out, "grad_out", torch.float32, 1)

@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference's backend/model.py (same class names,
+constructor arguments, methods, attribute names and state_dict keys), with the
+arithmetic done by the HIP kernels behind the C ABI.
+
+    reference                              here
+    -------------------------------------  ------------------------------------------
+    AveragePoolingTower  (model.py:13-72)   AveragePoolingTower  (+ encode_ids, encoder_mode)
+    TwoTowersModel       (model.py:75-121)  TwoTowersModel       (+ encode_*_ids)
+    TripletLoss          (model.py:125-145) TripletLoss
+
+Additive only: tensor-level entry points (`encode_ids`) that take the
+tokenizer's int64 `input_ids` / `attention_mask` directly, and
+`encoder_mode={"embed","bert"}`: "embed" pools the frozen
+word-embedding rows (the gather hot path), "bert" runs the frozen encoder with
+stock PyTorch-ROCm ops and pools its last_hidden_state (reference-exact).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+
+DEFAULT_MODEL_NAME = "sentence-transformers/all-MiniLM-L6-v2"
+
+
+class _ProjectionFn(torch.autograd.Function):
+    """Linear(D,P) -> ReLU -> Linear(P,P) (backend/model.py:33-38,59) on the fp32
+    MFMA kernels; gradients for the four parameters only (the input comes from the
+    frozen encoder under no_grad, backend/model.py:29-30,51)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = x.contiguous()
+        out, h = ops.proj_fwd(x, w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous())
+        ctx.save_for_backward(x, h, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, h, w2 = ctx.saved_tensors
+        dW1, db1, dW2, db2 = ops.proj_bwd(d_out.contiguous(), x, h, w2.contiguous())
+        return None, dW1, db1, dW2, db2
+
+
+class _TripletLossFn(torch.autograd.Function):
+    """mean(relu((1-cos(a,p)) - (1-cos(a,n)) + margin)) (backend/model.py:137-145);
+    the kernel produces the loss and d loss/d{a,p,n} in one pass."""
+
+    @staticmethod
+    def forward(ctx, anchor, positive, negative, margin):
+        loss, _, _, dq, dp, dn = ops.triplet_fwd_bwd(
+            anchor.contiguous(), positive.contiguous(), negative.contiguous(), float(margin)
+        )
+        ctx.save_for_backward(dq, dp, dn)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dq, dp, dn = ctx.saved_tensors
+        return g * dq, g * dp, g * dn, None
+
+
+class AveragePoolingTower(nn.Module):
+    """Frozen token embeddings -> masked average pool -> L2 normalise -> trainable
+    projection.  Mirrors backend/model.py:13-72.
+
+    `tokenizer` / `pretrained_model` may be injected (offline use, tests, sharing
+    one frozen model between towers); otherwise they are loaded exactly like the
+    reference does (`AutoTokenizer/AutoModel.from_pretrained(model_name)`,
+    model.py:23-24), which needs the files locally or network access.
+    """
+
+    def __init__(
+        self,
+        model_name: str = DEFAULT_MODEL_NAME,
+        projection_dim: int = 128,
+        *,
+        tokenizer: Optional[Callable] = None,
+        pretrained_model: Optional[nn.Module] = None,
+        encoder_mode: str = "embed",
+    ):
+        super().__init__()
+        if encoder_mode not in ("embed", "bert"):
+            raise ValueError("encoder_mode must be 'embed' or 'bert'")
+        if tokenizer is None or pretrained_model is None:
+            from transformers import AutoModel, AutoTokenizer  # same loaders as model.py:23-24
+
+            tokenizer = tokenizer or AutoTokenizer.from_pretrained(model_name)
+            pretrained_model = pretrained_model or AutoModel.from_pretrained(model_name)
+        self.tokenizer = tokenizer
+        self.pretrained_model = pretrained_model
+        self.encoder_mode = encoder_mode
+        self.embedding_dim = int(_hidden_size(pretrained_model))
+        for param in self.pretrained_model.parameters():  # model.py:29-30
+            param.requires_grad = False
+        # same container and default init as model.py:33-38, so state_dict keys are
+        # projection.0.{weight,bias} / projection.2.{weight,bias}
+        self.projection = nn.Sequential(
+            nn.Linear(self.embedding_dim, projection_dim),
+            nn.ReLU(),
+            nn.Linear(projection_dim, projection_dim),
+        )
+
+    # -- the reference entry point ------------------------------------------------
+    def forward(self, texts: list[str]) -> Tensor:
+        """model.py:40-60: tokenize, move to the model's device, pool, project."""
+        tokens = self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=512)
+        device = _module_device(self.pretrained_model)
+        tokens = {k: v.to(device) for k, v in tokens.items()}
+        return self.encode_tokens(tokens)
+
+    # -- tensor-level entry points (additive) -------------------------------------
+    def embedding_table(self) -> Tensor:
+        """The frozen word-embedding matrix [V, D] the `embed` mode gathers from."""
+        pm = self.pretrained_model
+        if hasattr(pm, "get_input_embeddings"):
+            return pm.get_input_embeddings().weight
+        return pm.word_embeddings.weight
+
+    def pool_tokens(self, tokens: dict) -> Tensor:
+        """model.py:51-56 -> pooled, normalised [B, D] (no grad)."""
+        ids, mask = tokens["input_ids"], tokens.get("attention_mask")
+        with torch.no_grad():
+            if self.encoder_mode == "embed":
+                return ops.gather_pool_norm(self.embedding_table().detach(), ids.contiguous(),
+                                            None if mask is None else mask.contiguous())
+            output = self.pretrained_model(**tokens)  # frozen encoder, stock PyTorch-ROCm ops
+            hidden = output[0].float().contiguous()
+            return ops.pool_norm_dense(hidden, None if mask is None else mask.contiguous())
+
+    def encode_tokens(self, tokens: dict) -> Tensor:
+        pooled = self.pool_tokens(tokens)
+        p = self.projection
+        return _ProjectionFn.apply(pooled, p[0].weight, p[0].bias, p[2].weight, p[2].bias)
+
+    def encode_ids(self, input_ids: Tensor, attention_mask: Optional[Tensor] = None) -> Tensor:
+        tokens = {"input_ids": input_ids}
+        if attention_mask is not None:
+            tokens["attention_mask"] = attention_mask
+        return self.encode_tokens(tokens)
+
+
+class TwoTowersModel(nn.Module):
+    """Two-towers architecture for document retrieval.  Mirrors backend/model.py:75-121.
+
+    The reference builds two private copies of the same frozen MiniLM
+    (model.py:84-85); here both towers may share one `pretrained_model` object —
+    `state_dict()` still lists it under both `query_tower.` and `document_tower.`
+    prefixes, so checkpoints interchange with the reference (search.py:104-106,229-231).
+    """
+
+    def __init__(
+        self,
+        projection_dim: int = 128,
+        model_name: str = DEFAULT_MODEL_NAME,
+        *,
+        tokenizer: Optional[Callable] = None,
+        pretrained_model: Optional[nn.Module] = None,
+        encoder_mode: str = "embed",
+    ):
+        super().__init__()
+        kw = dict(tokenizer=tokenizer, pretrained_model=pretrained_model, encoder_mode=encoder_mode)
+        self.query_tower = AveragePoolingTower(model_name, projection_dim, **kw)
+        if pretrained_model is None:  # loaded from disk: share the frozen weights and tokenizer
+            kw = dict(tokenizer=self.query_tower.tokenizer, pretrained_model=self.query_tower.pretrained_model,
+                      encoder_mode=encoder_mode)
+        self.document_tower = AveragePoolingTower(model_name, projection_dim, **kw)
+
+    def encode_queries(self, queries: list[str]) -> Tensor:
+        return self.query_tower(queries)
+
+    def encode_documents(self, documents: list[str]) -> Tensor:
+        return self.document_tower(documents)
+
+    def encode_documents_batched(self, documents: list[str], batch_size: int = 1024) -> Tensor:
+        """model.py:95-112 without the per-chunk `.cpu()` round trip: chunks are
+        encoded under the same batch-size control and concatenated on the device."""
+        if len(documents) <= batch_size:
+            return self.encode_documents(documents)
+        embeddings = []
+        for i in range(0, len(documents), batch_size):
+            embeddings.append(self.encode_documents(documents[i: i + batch_size]))
+        return torch.cat(embeddings, dim=0)
+
+    def forward(self, queries: list[str], documents: list[str]) -> Tuple[Tensor, Tensor]:
+        return self.encode_queries(queries), self.encode_documents(documents)
+
+    # tensor-level (additive)
+    def encode_query_ids(self, input_ids: Tensor, attention_mask: Optional[Tensor] = None) -> Tensor:
+        return self.query_tower.encode_ids(input_ids, attention_mask)
+
+    def encode_document_ids(self, input_ids: Tensor, attention_mask: Optional[Tensor] = None) -> Tensor:
+        return self.document_tower.encode_ids(input_ids, attention_mask)
+
+    def trainable_parameters(self):
+        """The 8 trainable tensors in `model.parameters()` order (model.py:33-38,84-85)."""
+        out = []
+        for tower in (self.query_tower, self.document_tower):
+            p = tower.projection
+            out += [p[0].weight, p[0].bias, p[2].weight, p[2].bias]
+        return out
+
+
+class TripletLoss(nn.Module):
+    """Triplet loss with cosine distance.  Mirrors backend/model.py:125-145."""
+
+    def __init__(self, margin: float = 0.3):
+        super().__init__()
+        self.margin = margin
+
+    def cosine_distance(self, x: Tensor, y: Tensor) -> Tensor:
+        """1 - cosine_similarity(x, y, dim=1) (model.py:132-135).  Evaluation helper:
+        not differentiable here (the differentiable use is inside `forward`)."""
+        if x.requires_grad or y.requires_grad:
+            x, y = x.detach(), y.detach()
+        _, pos_dist, _, _, _, _ = ops.triplet_fwd_bwd(x.contiguous(), y.contiguous(), y.contiguous(), 0.0, need_grad=False)
+        return pos_dist
+
+    def forward(self, anchor: Tensor, positive: Tensor, negative: Tensor) -> Tensor:
+        return _TripletLossFn.apply(anchor, positive, negative, self.margin)
+
+
+class EmbeddingOnlyEncoder(nn.Module):
+    """A frozen `pretrained_model` that is just a word-embedding table — what the
+    `embed` encoder mode needs, constructible offline (synthetic or loaded rows).
+    `forward(input_ids=...)` returns `(embeddings,)` like an HF model's first output."""
+
+    def __init__(self, table: Tensor):
+        super().__init__()
+        self.word_embeddings = nn.Embedding.from_pretrained(table, freeze=True)
+
+        class _Cfg:
+            hidden_size = table.shape[1]
+            vocab_size = table.shape[0]
+
+        self.config = _Cfg()
+
+    def get_input_embeddings(self):
+        return self.word_embeddings
+
+    @property
+    def device(self):
+        return self.word_embeddings.weight.device
+
+    def forward(self, input_ids=None, **kw):
+        return (self.word_embeddings(input_ids),)
+
+
+def _hidden_size(pm: nn.Module) -> int:
+    cfg = getattr(pm, "config", None)
+    if cfg is not None and hasattr(cfg, "hidden_size"):
+        return cfg.hidden_size  # model.py:26
+    return pm.get_input_embeddings().weight.shape[1]
+
+
+def _module_device(pm: nn.Module):
+    dev = getattr(pm, "device", None)  # model.py:48 uses pretrained_model.device
+    if dev is not None:
+        return dev
+    return next(pm.parameters()).device

@@ -1,0 +1,302 @@
+"""Host-side mirror of the training loop of backend/training.py (`train_epoch`,
+`train_epoch_optimized`, `run_training`) over the HIP hot path.
+
+Two ways to run the batch body of backend/training.py:36-53:
+
+* `train_epoch(model, dataloader, criterion, optimizer)` — the reference's
+  signature and call sequence on the mirrored nn.Modules (each op is one HIP
+  kernel behind torch.autograd); any torch optimizer works, `FusedAdam` runs K4.
+* `TripletTrainer` — the same arithmetic as a few C calls per batch on the
+  fused engine (flat parameters, no autograd graph, device-side loss
+  accumulation instead of a per-batch `loss.item()` sync), data-parallel over
+  `torch.distributed` (RCCL on GPUs) with one flat-bucket all-reduce per step
+  that overlaps the next batch's gather.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .engine import HotPathEngine, flat_param_slices
+from .model import TripletLoss, TwoTowersModel
+
+try:  # logging only (backend/training.py:13,57-58); optional here
+    import wandb  # type: ignore
+
+    _HAVE_WANDB = hasattr(wandb, "log")
+except Exception:  # pragma: no cover
+    wandb = None
+    _HAVE_WANDB = False
+
+
+# --------------------------------------------------------------------------- #
+# Optimizer
+# --------------------------------------------------------------------------- #
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr) with the defaults the reference uses
+    (backend/training.py:436: betas (0.9, 0.999), eps 1e-8, no weight decay), each
+    parameter updated by the K4 kernel.  Parameters without a gradient are skipped,
+    as torch does for the frozen encoder."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                ops.adam_step_flat(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1),
+                                   st["exp_avg_sq"].view(-1), st["step"], group["lr"], b1, b2, group["eps"])
+        return loss
+
+
+# --------------------------------------------------------------------------- #
+# Reference-signature loops (module path)
+# --------------------------------------------------------------------------- #
+def _encode3(model, queries, positives, negatives):
+    """The three encodes of backend/training.py:40-42, in that order.  Batches may
+    be the reference's string lists or pre-tokenised (input_ids, attention_mask) pairs."""
+    if isinstance(queries, (list, tuple)) and len(queries) and isinstance(queries[0], str):
+        return model.encode_queries(queries), model.encode_documents(positives), model.encode_documents(negatives)
+    return (model.encode_query_ids(*queries), model.encode_document_ids(*positives),
+            model.encode_document_ids(*negatives))
+
+
+def train_epoch(model: TwoTowersModel, dataloader, criterion: TripletLoss, optimizer: torch.optim.Optimizer,
+                log_wandb: bool = True) -> float:
+    """Train for one epoch.  Mirrors backend/training.py:26-63 line for line."""
+    total_loss = 0.0
+    num_batches = 0
+    for queries, positives, negatives in dataloader:
+        optimizer.zero_grad()
+        query_embeds, positive_embeds, negative_embeds = _encode3(model, queries, positives, negatives)
+        loss = criterion(query_embeds, positive_embeds, negative_embeds)
+        loss.backward()
+        optimizer.step()
+        total_loss += loss.item()
+        num_batches += 1
+        if log_wandb and _HAVE_WANDB:
+            wandb.log({"batch_loss": loss.item(), "batch": num_batches})
+        if num_batches % 10 == 0:
+            print(f"Batch {num_batches}, Loss: {loss.item():.4f}")
+    return total_loss / num_batches
+
+
+def train_epoch_optimized(model: TwoTowersModel, dataloader, criterion: TripletLoss,
+                          optimizer: torch.optim.Optimizer, device=None, scaler=None,
+                          accumulation_steps: int = 2, log_wandb: bool = True) -> float:
+    """Gradient-accumulation loop with the semantics of backend/training.py:66-133
+    (`loss / accumulation_steps`, optimizer step + zero_grad every k-th batch,
+    left-over gradients neither applied nor cleared at the end of the epoch), in
+    fp32: the reference's fp16 autocast + GradScaler are not a parity target
+    (SURVEY.md §2.2 O11), so `scaler` is accepted and ignored."""
+    model.train()
+    total_loss = 0.0
+    num_batches = 0
+    for batch_idx, (queries, positives, negatives) in enumerate(dataloader):
+        query_embeds, positive_embeds, negative_embeds = _encode3(model, queries, positives, negatives)
+        loss = criterion(query_embeds, positive_embeds, negative_embeds) / accumulation_steps
+        loss.backward()
+        if (batch_idx + 1) % accumulation_steps == 0:
+            optimizer.step()
+            optimizer.zero_grad()
+        total_loss += loss.item() * accumulation_steps
+        num_batches += 1
+        if log_wandb and _HAVE_WANDB and batch_idx % 10 == 0:
+            wandb.log({"batch_loss": loss.item() * accumulation_steps, "batch": num_batches})
+    return total_loss / num_batches
+
+
+# --------------------------------------------------------------------------- #
+# Fused engine path (+ data parallel)
+# --------------------------------------------------------------------------- #
+Batch = Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]  # ids[3,B,S], mask[3,B,S]|None, lens[3,B]|None
+
+
+class TripletTrainer:
+    """The batch body of backend/training.py:36-53 on the fused engine.
+
+    Data parallel: every rank holds the frozen table and the 8
+    trainable tensors, takes its contiguous shard of the global batch, scales its
+    hinge gradients by 1/B_global, sums the flat gradient bucket with ONE
+    all-reduce per optimizer step and applies the identical Adam update.  The
+    all-reduce is asynchronous and the next batch's gather+pool (which does not
+    depend on the weights) is issued under it.
+
+    `engine` may be injected (tests drive the data-parallel logic on CPU/gloo with
+    an oracle-backed stand-in); the product default is the HIP engine.
+    """
+
+    def __init__(self, model: Optional[TwoTowersModel] = None, *, table: Optional[torch.Tensor] = None,
+                 params: Optional[dict] = None, max_batch: int, max_seq_len: int, margin: float = 0.3,
+                 lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
+                 process_group=None, engine=None, overlap_streams: bool = False):
+        if model is not None:
+            if model.query_tower.encoder_mode != "embed":
+                raise ValueError("the fused engine implements the `embed` encoder mode; use train_epoch for `bert`")
+            table = model.query_tower.embedding_table().detach()
+            tensors = [p.detach() for p in model.trainable_parameters()]
+        else:
+            if table is None or params is None:
+                raise ValueError("pass a TwoTowersModel or table= and params=")
+            tensors = [params[name] for name, _, _ in flat_param_slices(table.shape[1], _proj_dim(params))]
+        self.device = table.device
+        self.D = table.shape[1]
+        self.P = tensors[1].shape[0]
+        self.margin, self.lr, self.betas, self.eps = float(margin), float(lr), betas, float(eps)
+        self.accumulation_steps = int(accumulation_steps)
+        self.engine = engine if engine is not None else HotPathEngine(table.contiguous(), self.P, max_batch, max_seq_len)
+        n = self.engine.n_params
+        self.flat = torch.cat([t.reshape(-1).float() for t in tensors]).to(self.device).contiguous()
+        assert self.flat.numel() == n
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.engine.bind(self.flat, self.exp_avg, self.exp_avg_sq)
+        if model is not None:  # the modules now alias the flat buffer: state_dict() sees the trained weights
+            for p, (_, off, shape) in zip(model.trainable_parameters(), flat_param_slices(self.D, self.P)):
+                p.data = self.flat[off: off + p.numel()].view(shape)
+        self.model = model
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self.bucket = torch.empty_like(self.flat) if (self.world > 1 or self.accumulation_steps > 1) else None
+        self.step_count = 0        # optimizer steps taken
+        self._micro = 0            # batches since the last optimizer step (carried across epochs, like the reference)
+        self.side = torch.cuda.Stream(self.device) if (overlap_streams and self.device.type == "cuda") else None
+
+    # -- helpers ---------------------------------------------------------------
+    def named_parameters(self) -> dict:
+        return {name: self.flat[off: off + int(math.prod(shape))].view(shape)
+                for name, off, shape in flat_param_slices(self.D, self.P)}
+
+    def _pool(self, slot: int, batch: Batch) -> None:
+        ids, mask, lens = batch
+        self.engine.pool(slot, ids, mask, lens)
+
+    def _apply(self, local_B: int, global_B: int, slot: int, nxt: Optional[Batch]) -> None:
+        """fwd+bwd of the pooled batch in `slot`, gradient exchange, optimizer; issues
+        the NEXT batch's gather where it overlaps the exchange."""
+        k = self.accumulation_steps
+        self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B))
+        self._micro += 1
+        do_step = self._micro % k == 0
+        if self.bucket is None:  # single replica, no accumulation: Adam folds the slab sum
+            self.step_count += 1
+            self.engine.adam(self.step_count, self.lr, None, self.betas[0], self.betas[1], self.eps)
+            if nxt is not None:
+                self._pool(slot ^ 1, nxt)
+            return
+        self.engine.reduce_grads(self.bucket, accumulate=(k > 1 and self._micro % k != 1))
+        work = None
+        if do_step and self.world > 1:
+            work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if nxt is not None:
+            self._pool(slot ^ 1, nxt)  # weight-independent: runs under the all-reduce
+        if work is not None:
+            work.wait()
+        if do_step:
+            self.step_count += 1
+            self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
+
+    # -- public ------------------------------------------------------------------
+    def train_step(self, batch: Batch, global_batch: Optional[int] = None) -> None:
+        """One batch (this rank's shard).  No host synchronisation."""
+        B = batch[0].shape[1]
+        self._pool(0, batch)
+        self._apply(B, global_batch or B * self.world, 0, None)
+
+    def train_epoch(self, batches: Iterable[Batch], global_batch_sizes: Optional[Sequence[int]] = None) -> float:
+        """All batches of an epoch; returns the mean of the per-batch (global) losses
+        like backend/training.py:63.  One host sync at the end."""
+        it = iter(batches)
+        cur = next(it, None)
+        if cur is None:
+            return float("nan")
+        slot, i = 0, 0
+        self._pool(slot, cur)
+        while cur is not None:
+            nxt = next(it, None)
+            B = cur[0].shape[1]
+            gB = global_batch_sizes[i] if global_batch_sizes is not None else B * self.world
+            self._apply(B, gB, slot, nxt)
+            cur, slot, i = nxt, slot ^ 1, i + 1
+        return self.epoch_loss()
+
+    def epoch_loss(self) -> float:
+        loss_sum, n, _ = self.engine.read_stats(reset=True)
+        if self.world > 1:  # per-rank sums are hinge_sum / B_global: adding them gives the global batch losses
+            t = torch.tensor([loss_sum], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            loss_sum = float(t.item())
+        return loss_sum / max(n, 1)
+
+
+def shard_batch(batch: Batch, rank: int, world: int) -> Tuple[Batch, int]:
+    """Contiguous split of a global batch over `world` ranks; the
+    last ranks get one triplet fewer when B % world != 0.  Returns (shard, B_global)."""
+    ids, mask, lens = batch
+    B = ids.shape[1]
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    cut = lambda t: None if t is None else t[:, lo:hi].contiguous()
+    return (cut(ids), cut(mask), cut(lens)), B
+
+
+def _proj_dim(params: dict) -> int:
+    return params["query_tower.projection.0.bias"].shape[0]
+
+
+# --------------------------------------------------------------------------- #
+# run_training
+# --------------------------------------------------------------------------- #
+def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: float = 1e-4,
+                 max_samples: int = 10000, projection_dim: int = 128, margin: float = 0.1,
+                 project_name: str = "two-towers-retrieval", use_wandb: bool = True,
+                 wandb_config: Optional[dict] = None, accumulation_steps: int = 2,
+                 use_mixed_precision: bool = True, num_workers: int = 4,
+                 run_comprehensive_test: bool = True, *, train_dataset=None, tokenizer=None,
+                 pretrained_model=None, model_name: Optional[str] = None, seed: Optional[int] = None) -> TwoTowersModel:
+    """Same keyword surface and defaults as backend/training.py:383-397; builds the
+    model / criterion / Adam exactly like :433-436 and runs `num_epochs` epochs on
+    the fused engine.  Differences, all outside the hot path: the dataset is passed
+    in (`train_dataset`, any map-style {"query_id","query","positive"}; the
+    reference's MSMarcoDataset is a network fetch), wandb and the NDCG evaluation
+    harness (training.py:136-380) are not reproduced, `use_mixed_precision` /
+    `num_workers` / `run_comprehensive_test` are accepted for signature parity and
+    ignored (fp32 is the parity path; tokenisation happens once, up front)."""
+    from .data import TokenTripletLoader
+
+    if train_dataset is None:
+        raise ValueError("run_training: pass train_dataset= (MS MARCO loading is outside the hot path)")
+    device = torch.device("cuda")
+    kw = {}
+    if model_name is not None:
+        kw["model_name"] = model_name
+    model = TwoTowersModel(projection_dim=projection_dim, tokenizer=tokenizer, pretrained_model=pretrained_model, **kw)
+    model = model.to(device)
+    if max_samples and max_samples > 0 and len(train_dataset) > max_samples:
+        train_dataset = torch.utils.data.Subset(train_dataset, range(max_samples))
+    loader = TokenTripletLoader(train_dataset, model.query_tower.tokenizer, batch_size, device, seed=seed)
+    max_S = int(max(loader.q_ids.shape[1], loader.p_ids.shape[1]))
+    trainer = TripletTrainer(model, max_batch=batch_size, max_seq_len=max_S, margin=margin, lr=learning_rate,
+                             accumulation_steps=accumulation_steps)
+    print(f"Starting training for {num_epochs} epochs...")
+    for epoch in range(num_epochs):
+        avg = trainer.train_epoch((ids, None, lens) for ids, lens in loader)
+        print(f"Epoch {epoch + 1}/{num_epochs}  avg_train_loss {avg:.6f}")
+    return model

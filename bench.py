@@ -57,7 +57,13 @@ def cpu_baseline(cfg, budget_s=20.0):
     """Oracle train_epoch (torch-CPU restatement of backend/training.py:26-63) on all host cores."""
     from oracle import two_towers_oracle as orc
 
-    cores = os.cpu_count() or 1
+    # threads actually used: the cores this process may run on, capped at the GPU box's
+    # per-GPU CPU share (16) — oversubscribing a 256-thread host makes torch-CPU far slower
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     V, D, P, S = cfg["V"], cfg["D"], cfg["P"], cfg["S"]
     B = min(cfg["B"], 2048)

@@ -101,6 +101,10 @@ def load():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc, gfx950). The HIP library is the only implementation of this path."
             )
+        # torch ships its own libamdhip64; it must be in the process first so that this
+        # library binds to the SAME HIP runtime (streams and pointers are shared with torch).
+        import torch  # noqa: F401
+
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

@@ -1,0 +1,74 @@
+"""Host-side triplet batching (mirror of backend/data.py:90-152) against the reference's own draws."""
+import random
+
+import torch
+
+from conftest import load_golden
+from two_towers_overlords_amd.data import TokenTripletLoader, TripletDataLoader, sample_negative_indices
+
+
+def test_negative_sampling_matches_reference_draws():
+    g = load_golden("triplets.npz")
+    for case in range(4):
+        qids = g[f"case{case}/query_ids"].tolist()
+        random.seed(int(g[f"case{case}/seed"]))
+        assert sample_negative_indices(qids) == g[f"case{case}/neg_idx"].tolist()
+
+
+class _DS(torch.utils.data.Dataset):
+    def __init__(self, n, nq):
+        r = random.Random(0)
+        self.items = [{"query_id": r.randrange(nq), "query": "", "positive": ""} for _ in range(n)]
+        for i, it in enumerate(self.items):
+            it["query"] = " ".join(["q%d" % it["query_id"]] * (1 + it["query_id"] % 3))
+            it["positive"] = " ".join(["d%d" % i] * (2 + i % 5))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _tok(texts, padding=True, truncation=True, return_tensors="pt", max_length=512):
+    rows = [[1 + (hash(w) % 97) for w in t.split()][:max_length] for t in texts]
+    S = max(len(r) for r in rows)
+    ids = torch.zeros(len(rows), S, dtype=torch.int64)
+    mask = torch.zeros(len(rows), S, dtype=torch.int64)
+    for i, r in enumerate(rows):
+        ids[i, : len(r)] = torch.tensor(r)
+        mask[i, : len(r)] = 1
+    return {"input_ids": ids, "attention_mask": mask}
+
+
+def test_string_loader_semantics():
+    ds = _DS(23, 6)
+    dl = TripletDataLoader(ds, batch_size=8, num_workers=0)
+    seen = 0
+    for q, p, n in dl:
+        assert len(q) == len(p) == len(n)
+        for qi, pi, ni in zip(q, p, n):
+            # the negative is some in-batch item's positive, from a different query
+            j = p.index(ni)
+            assert q[j] != qi and ni != pi
+        seen += len(q)
+    assert seen == 23 and len(dl) == 3  # drop_last is not set (data.py:102-111)
+
+
+def test_token_loader_negatives_are_in_batch_positives():
+    ds = _DS(23, 6)
+    tl = TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5)
+    total = 0
+    for ids, lens in tl:
+        B = ids.shape[1]
+        total += B
+        assert ids.dtype == torch.int32 and lens.shape == (3, B)
+        S = ids.shape[2]
+        assert int(lens.max()) == S  # padded to the longest row of the batch
+        for i in range(B):
+            nrow = ids[2, i, : lens[2, i]]
+            matches = [j for j in range(B) if lens[1, j] == lens[2, i] and torch.equal(ids[1, j, : lens[1, j]], nrow)]
+            assert matches and i not in matches
+            # positions past the length are padding zeros
+            assert int(ids[2, i, lens[2, i]:].abs().sum()) == 0
+    assert total == 23

@@ -1,0 +1,169 @@
+"""GPU: the mirrored reference surface (TwoTowersModel / AveragePoolingTower /
+TripletLoss / train_epoch / FusedAdam / TripletTrainer) against the golden vectors
+produced by the reference's own classes and loop."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_params_close, load_golden
+from oracle import two_towers_oracle as orc
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+TOL = 1e-5
+
+
+class StubTokenizer:
+    """texts[0] is a tag; returns the prepared int64 tensors (like tests/golden/make_golden.py)."""
+
+    def __init__(self):
+        self.registry = {}
+
+    def __call__(self, texts, **kw):
+        ids, mask = self.registry[texts[0]]
+        return {"input_ids": ids.clone(), "attention_mask": mask.clone()}
+
+
+def build_model(g, encoder_mode="embed"):
+    from two_towers_overlords_amd.model import EmbeddingOnlyEncoder, TwoTowersModel
+
+    tok = StubTokenizer()
+    P = g["init/query_tower.projection.0.bias"].shape[0]
+    m = TwoTowersModel(projection_dim=P, tokenizer=tok, pretrained_model=EmbeddingOnlyEncoder(T(g["table"])),
+                       encoder_mode=encoder_mode)
+    sd = m.state_dict()
+    for k in orc.PARAM_KEYS:
+        sd[k] = T(g["init/" + k])
+    m.load_state_dict(sd)
+    m = m.cuda()
+    nb = int(g["n_batches"])
+    texts = []
+    for i in range(nb):
+        names = []
+        for r in "qpn":
+            key = f"b{i}:{r}"
+            tok.registry[key] = (T(g[f"batch{i}/ids_{r}"]), T(g[f"batch{i}/mask_{r}"]))
+            names.append([key] * g[f"batch{i}/ids_{r}"].shape[0])
+        texts.append(tuple(names))
+    return m, texts
+
+
+def test_state_dict_keys_match_reference_layout():
+    g = load_golden("kat0.npz")
+    m, _ = build_model(g)
+    keys = set(m.state_dict().keys())
+    for k in orc.PARAM_KEYS:  # search.py:104-106 sniffs query_tower.projection.2.weight
+        assert k in keys
+    assert any(k.startswith("query_tower.pretrained_model.") for k in keys)
+    assert any(k.startswith("document_tower.pretrained_model.") for k in keys)
+    assert [tuple(p.shape) for p in m.parameters() if p.requires_grad] == [tuple(g["init/" + k].shape) for k in orc.PARAM_KEYS]
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 2 * (8 * 4 + 4 + 16 + 4)
+
+
+@pytest.mark.parametrize("name", ["kat0.npz", "step_mid.npz", "step_d384.npz"])
+def test_module_forward_backward_matches_reference(name):
+    from two_towers_overlords_amd.model import TripletLoss
+
+    g = load_golden(name)
+    m, texts = build_model(g)
+    crit = TripletLoss(margin=float(g["margin"]))
+    tq, tp, tn = texts[0]
+    q, p, n = m.encode_queries(tq), m.encode_documents(tp), m.encode_documents(tn)
+    for a, k in ((q, "q"), (p, "p"), (n, "n")):
+        assert np.abs(a.detach().cpu().numpy() - g["fwd/" + k]).max() <= TOL
+    q2, d2 = m(tq, tp)  # TwoTowersModel.forward
+    assert torch.equal(q2, q) and torch.equal(d2, p)
+    loss = crit(q, p, n)
+    assert abs(loss.item() - float(g["fwd/loss"])) <= TOL
+    assert np.abs(crit.cosine_distance(q, p).cpu().numpy() - g["fwd/pos_dist"]).max() <= TOL
+    loss.backward()
+    for k, prm in m.named_parameters():
+        if prm.requires_grad:
+            ref = g["grad/" + k]
+            assert np.abs(prm.grad.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max()) <= TOL
+        else:
+            assert prm.grad is None  # frozen encoder (model.py:29-30)
+    big = m.encode_documents_batched(tp, batch_size=10 ** 6)
+    assert torch.equal(big, p)
+
+
+@pytest.mark.parametrize("name", ["kat0.npz", "step_mid.npz"])
+@pytest.mark.parametrize("opt", ["fused", "torch"])
+def test_train_epoch_module_path_matches_reference(name, opt):
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import FusedAdam, train_epoch
+
+    g = load_golden(name)
+    m, texts = build_model(g)
+    lr = float(g["lr"])
+    optim = FusedAdam(m.parameters(), lr=lr) if opt == "fused" else torch.optim.Adam(m.parameters(), lr=lr)
+    avg = train_epoch(m, texts, TripletLoss(margin=float(g["margin"])), optim, log_wandb=False)
+    assert abs(avg - float(g["epoch/avg_loss"])) <= TOL
+    sd = m.state_dict()
+    for k in orc.PARAM_KEYS:
+        assert_params_close(sd[k].cpu().numpy(), g["final/" + k], lr, len(texts))
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_trainer_from_model_matches_reference_and_aliases_modules(overlap):
+    from two_towers_overlords_amd.training import TripletTrainer
+
+    g = load_golden("step_mid.npz")
+    m, _ = build_model(g)
+    nb = int(g["n_batches"])
+    B, S = g["batch0/ids_q"].shape
+    tr = TripletTrainer(m, max_batch=B, max_seq_len=S, margin=float(g["margin"]), lr=float(g["lr"]), overlap_streams=overlap)
+    batches = [(torch.stack([T(g[f"batch{i}/ids_{r}"]) for r in "qpn"]).cuda(),
+                torch.stack([T(g[f"batch{i}/mask_{r}"]) for r in "qpn"]).cuda(), None) for i in range(nb)]
+    avg = tr.train_epoch(batches)
+    assert abs(avg - float(g["epoch/avg_loss"])) <= TOL
+    sd = m.state_dict()  # the nn.Module parameters alias the trainer's flat buffer
+    for k in orc.PARAM_KEYS:
+        assert_params_close(sd[k].cpu().numpy(), g["final/" + k], float(g["lr"]), nb)
+
+
+def test_trainer_accumulation_matches_oracle():
+    from two_towers_overlords_amd.training import TripletTrainer
+
+    V, D, P, B, S = 300, 64, 48, 40, 12
+    table = orc.synthetic_table(V, D, seed=5) * 50
+    params = orc.init_params(D, P, seed=6)
+    batches = [orc.synthetic_batch(B, S, V, seed=90 + i, ragged=True) for i in range(5)]
+    ref_params = {k: v.clone() for k, v in params.items()}
+    st = orc.AdamState(lr=1e-3)
+    ref_avg, _, carry = orc.train_epoch_accum(table, batches, ref_params, st, 0.3, 2)
+    tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B, max_seq_len=S,
+                        margin=0.3, lr=1e-3, accumulation_steps=2)
+    dev = [(torch.stack([r[0] for r in b]).cuda(), torch.stack([r[1] for r in b]).cuda(), None) for b in batches]
+    avg = tr.train_epoch(dev)
+    assert tr.step_count == 2 and abs(avg - ref_avg) <= TOL
+    for k, v in tr.named_parameters().items():
+        assert_params_close(v.cpu().numpy(), ref_params[k].numpy(), 1e-3, 2)
+    # the 5th batch's gradient is left in the bucket, un-applied (training.py:99-102)
+    flat_carry = torch.cat([carry[k].reshape(-1) for k in orc.PARAM_KEYS])
+    assert (tr.bucket.cpu() - flat_carry).abs().max() <= TOL * max(1.0, float(flat_carry.abs().max()))
+
+
+def test_bert_mode_tower_matches_reference():
+    """`bert` encoder mode: a tiny BertModel (rebuilt with the fixture's seed) between gather and pool."""
+    transformers = pytest.importorskip("transformers")
+    from two_towers_overlords_amd.model import AveragePoolingTower
+
+    g = load_golden("bert_mode.npz")
+    torch.manual_seed(7)
+    cfg = transformers.BertConfig(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=4,
+                                  intermediate_size=64, max_position_embeddings=32)
+    bert = transformers.BertModel(cfg).eval()
+    with torch.no_grad():
+        hidden_cpu = bert(input_ids=T(g["ids"]), attention_mask=T(g["mask"]))[0]
+    if not np.allclose(hidden_cpu.numpy(), g["hidden"], atol=1e-6):
+        pytest.skip("transformers RNG/initialisation differs from the fixture's; dense-pool parity is covered elsewhere")
+    tok = StubTokenizer()
+    tok.registry["x"] = (T(g["ids"]), T(g["mask"]))
+    t = AveragePoolingTower(projection_dim=16, tokenizer=tok, pretrained_model=bert, encoder_mode="bert")
+    with torch.no_grad():
+        t.projection[0].weight.copy_(T(g["w1"])); t.projection[0].bias.copy_(T(g["b1"]))
+        t.projection[2].weight.copy_(T(g["w2"])); t.projection[2].bias.copy_(T(g["b2"]))
+    t = t.cuda()
+    out = t(["x"] * g["ids"].shape[0])
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() <= 2e-5  # encoder itself runs on stock GPU ops

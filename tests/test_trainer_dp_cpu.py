@@ -1,0 +1,99 @@
+"""Data-parallel / accumulation logic of TripletTrainer on CPU: world_size-2 gloo
+processes (and a single process) with the oracle-backed engine must reproduce the
+oracle's single-replica train_epoch on the GLOBAL batches."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import two_towers_oracle as orc  # noqa: E402
+
+V, D, P, B, S, NB = 200, 16, 12, 33, 9, 4  # B odd: ranks get 17 + 16 triplets
+
+
+def _setup():
+    table = orc.synthetic_table(V, D, seed=3) * 50
+    params = orc.init_params(D, P, seed=4)
+    batches = [orc.synthetic_batch(B, S, V, seed=70 + i, ragged=True) for i in range(NB)]
+    return table, params, batches
+
+
+def _global_batches(batches):
+    return [(torch.stack([r[0] for r in b]), torch.stack([r[1] for r in b]), None) for b in batches]
+
+
+def _reference(accum=1):
+    table, params, batches = _setup()
+    st = orc.AdamState(lr=1e-3)
+    if accum == 1:
+        avg, _ = orc.train_epoch(table, batches, params, st, 0.3)
+    else:
+        avg, _, _ = orc.train_epoch_accum(table, batches, params, st, 0.3, accum)
+    return avg, params
+
+
+def _worker(rank, world, port, accum, q):
+    from oracle_engine import OracleEngine
+    from two_towers_overlords_amd.training import TripletTrainer, shard_batch
+
+    torch.set_num_threads(1)
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    table, params, batches = _setup()
+    tr = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
+                        accumulation_steps=accum, engine=OracleEngine(table, P, B, S))
+    shards, sizes = [], []
+    for gb in _global_batches(batches):
+        sh, n = shard_batch(gb, rank, world)
+        shards.append(sh)
+        sizes.append(n)
+    avg = tr.train_epoch(shards, global_batch_sizes=sizes)
+    if rank == 0:
+        q.put((avg, {k: v.detach().numpy().copy() for k, v in tr.named_parameters().items()}, tr.step_count))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(world, accum):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29500 + (os.getpid() % 2000) + 7 * world + accum
+    procs = [ctx.Process(target=_worker, args=(r, world, port, accum, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize("world,accum", [(1, 1), (2, 1), (2, 2), (1, 3)])
+def test_sharded_epoch_equals_single_replica(world, accum):
+    avg, params, steps = _run(world, accum)
+    ref_avg, ref_params = _reference(accum)
+    assert steps == NB // accum
+    assert abs(avg - ref_avg) < 1e-6
+    for k in orc.PARAM_KEYS:
+        np.testing.assert_allclose(params[k], ref_params[k].numpy(), atol=2e-6, rtol=0)
+
+
+def test_shard_batch_partition():
+    from two_towers_overlords_amd.training import shard_batch
+
+    ids = torch.arange(3 * 10 * 2).view(3, 10, 2)
+    lens = torch.arange(30).view(3, 10).int()
+    got = [shard_batch((ids, None, lens), r, 4) for r in range(4)]
+    assert [g[0][0].shape[1] for g in got] == [3, 3, 2, 2] and all(g[1] == 10 for g in got)
+    assert torch.equal(torch.cat([g[0][0] for g in got], dim=1), ids)
+    assert torch.equal(torch.cat([g[0][2] for g in got], dim=1), lens)

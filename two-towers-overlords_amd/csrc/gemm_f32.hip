@@ -32,19 +32,27 @@ constexpr int kThreads = 256;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- global -> register staging ------------------------------------------------
+// VEC path (16-byte aligned base, ld % 4 == 0, and for K-contiguous operands K % 4 == 0):
+// branch-free — the address is clamped in range, the float4 load is unconditional and
+// out-of-range chunks are zeroed with a select, so the loads of tile t+1 stay in flight
+// under the MFMAs of tile t.  The scalar path (any shape) is correct, not fast.
+//
 // K-contiguous operand: tile [R rows][BK], element (row, k) at P[(r0+row)*ld + k0+k].
-template <int R>
+template <int R, bool VEC>
 __device__ __forceinline__ void gload_kc(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
-                                         int ld, int r0, int rmax, int k0, int kend, bool vec, int tid) {
+                                         int ld, int r0, int rmax, int k0, int kend, int tid) {
 #pragma unroll
   for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
     const int f = tid + i * kThreads;
     const int row = f >> 3, kq = f & 7;
     const int gr = r0 + row, gk = k0 + kq * 4;
-    const float* __restrict__ src = P + (long long)gr * ld + gk;
-    if (gr < rmax && gk + 3 < kend && vec) {
-      v[i] = *reinterpret_cast<const float4*>(src);
+    if (VEC) {
+      const bool ok = gr < rmax && gk < kend;  // K % 4 == 0: a chunk is all in or all out
+      const int cr = min(gr, rmax - 1), ck = min(gk, kend - 4);
+      const float4 t = *reinterpret_cast<const float4*>(P + (long long)cr * ld + ck);
+      v[i] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
+      const float* __restrict__ src = P + (long long)gr * ld + gk;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < rmax) {
         if (gk + 0 < kend) t.x = src[0];
@@ -66,19 +74,23 @@ __device__ __forceinline__ void sstore_kc(const float4 (&v)[R * BK / 4 / kThread
   }
 }
 // K-strided operand: tile [BK][R cols], element (k, col) at P[(k0+k)*ld + r0+col].
-template <int R>
+// VEC additionally needs rmax % 4 == 0 (a 4-column chunk is all in or all out).
+template <int R, bool VEC>
 __device__ __forceinline__ void gload_ks(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
-                                         int ld, int r0, int rmax, int k0, int kend, bool vec, int tid) {
+                                         int ld, int r0, int rmax, int k0, int kend, int tid) {
   constexpr int RQ = R / 4;
 #pragma unroll
   for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
     const int f = tid + i * kThreads;
     const int krow = f / RQ, rq = f % RQ;
     const int gk = k0 + krow, gr = r0 + rq * 4;
-    const float* __restrict__ src = P + (long long)gk * ld + gr;
-    if (gk < kend && gr + 3 < rmax && vec) {
-      v[i] = *reinterpret_cast<const float4*>(src);
+    if (VEC) {
+      const bool ok = gk < kend && gr < rmax;
+      const int ck = min(gk, kend - 1), cr = min(gr, rmax - 4);
+      const float4 t = *reinterpret_cast<const float4*>(P + (long long)ck * ld + cr);
+      v[i] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
+      const float* __restrict__ src = P + (long long)gk * ld + gr;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gk < kend) {
         if (gr + 0 < rmax) t.x = src[0];
@@ -111,7 +123,7 @@ __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, 
   return make_float4(p[0], p[R], p[2 * R], p[3 * R]);
 }
 
-template <int LAYOUT, int EPI, int WM, int WN>
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr bool A_KC = (LAYOUT != kTN);
@@ -120,25 +132,36 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   constexpr int B_TILE = B_KC ? BN * BKP : BK * BN;
   constexpr int NVA = BM * BK / 4 / kThreads, NVB = BN * BK / 4 / kThreads;
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+  constexpr int CP = BN + 4;  // padded row of the epilogue's C tile
+  constexpr int LDS_FLOATS = (2 * (A_TILE + B_TILE) > BM * CP) ? 2 * (A_TILE + B_TILE) : BM * CP;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int grp = blockIdx.z / b.nsplit;
   const int split = blockIdx.z - grp * b.nsplit;
-  const Problem& pr = b.p[grp];
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  if (m0 >= pr.M || n0 >= pr.N) return;  // grouped launch: grid is sized for the largest problem
+  // Copy the problem descriptor out of the kernarg segment once: stores to C could
+  // alias it as far as the compiler knows, which would force a reload + vmcnt(0)
+  // after every store.
+  const float* __restrict__ gA = b.p[grp].A;
+  const float* __restrict__ gB = b.p[grp].B;
+  float* __restrict__ gC = b.p[grp].C;
+  const float* __restrict__ gbias = b.p[grp].bias;
+  const float* __restrict__ gaux = b.p[grp].aux;
+  float* __restrict__ gcolsum = b.p[grp].colsum;
+  const int M = b.p[grp].M, N = b.p[grp].N, K = b.p[grp].K;
+  const int lda = b.p[grp].lda, ldb = b.p[grp].ldb, ldc = b.p[grp].ldc, ldaux = b.p[grp].ldaux;
+  const int kps = b.p[grp].k_per_split;
 
-  const int kbeg = (LAYOUT == kTN) ? min(pr.K, split * pr.k_per_split) : 0;
-  const int kend = (LAYOUT == kTN) ? min(pr.K, kbeg + pr.k_per_split) : pr.K;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (m0 >= M || n0 >= N) return;  // grouped launch: grid is sized for the largest problem
+
+  const int kbeg = (LAYOUT == kTN) ? min(K, split * kps) : 0;
+  const int kend = (LAYOUT == kTN) ? min(K, kbeg + kps) : K;
   const long long slab = (long long)split * b.slab_stride;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wrow = wave >> 1, wcol = wave & 1;
-
-  const bool vecA = ((pr.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.A) & 15) == 0);
-  const bool vecB = ((pr.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.B) & 15) == 0);
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -150,13 +173,13 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
 
   float4 ra[NVA], rb[NVB];
   float csum = 0.f;  // kTN column sums of A (bias gradient), threads tid < BM of n-tile 0
-  const bool do_colsum = (LAYOUT == kTN) && pr.colsum != nullptr && blockIdx.x == 0;
+  const bool do_colsum = (LAYOUT == kTN) && gcolsum != nullptr && blockIdx.x == 0;
 
   auto gload = [&](int k0) {
-    if (A_KC) gload_kc<BM>(ra, pr.A, pr.lda, m0, pr.M, k0, kend, vecA, tid);
-    else      gload_ks<BM>(ra, pr.A, pr.lda, m0, pr.M, k0, kend, vecA, tid);
-    if (B_KC) gload_kc<BN>(rb, pr.B, pr.ldb, n0, pr.N, k0, kend, vecB, tid);
-    else      gload_ks<BN>(rb, pr.B, pr.ldb, n0, pr.N, k0, kend, vecB, tid);
+    if (A_KC) gload_kc<BM, VEC>(ra, gA, lda, m0, M, k0, kend, tid);
+    else      gload_ks<BM, VEC>(ra, gA, lda, m0, M, k0, kend, tid);
+    if (B_KC) gload_kc<BN, VEC>(rb, gB, ldb, n0, N, k0, kend, tid);
+    else      gload_ks<BN, VEC>(rb, gB, ldb, n0, N, k0, kend, tid);
   };
   auto sstore = [&](int buf) {
     float* As = lds + buf * (A_TILE + B_TILE);
@@ -176,7 +199,8 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
     const int cur = kt & 1;
     const float* __restrict__ As = lds + cur * (A_TILE + B_TILE);
     const float* __restrict__ Bs = As + A_TILE;
-    if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+    const bool more = kt + 1 < nk;
+    if (more) gload(kbeg + (kt + 1) * BK);
 
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
@@ -205,31 +229,69 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) csum += As[k * BM + tid];
     }
-    if (kt + 1 < nk) sstore(cur ^ 1);
+    if (more) sstore(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*h
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*h.
+  // The tile goes through LDS (free after the K loop's last barrier) so that global
+  // stores are whole 16-byte chunks of contiguous rows (4 per thread instead of 16
+  // dword stores whose address registers the compiler serialises with vmcnt(0)).
+  float* __restrict__ Cs = lds;
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int jj = 0; jj < WN; ++jj) {
-      const int n = n0 + (wcol * WN + jj) * 32 + r;
-      if (n >= pr.N) continue;
-      float bias = 0.f;
-      if (EPI == kBias || EPI == kBiasRelu) bias = pr.bias[n];
+      const int col = (wcol * WN + jj) * 32 + r;
+      const int rbase = (wrow * WM + i) * 32 + 4 * h;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + (wrow * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= pr.M) continue;
-        float v = acc[i][jj][e];
-        if (EPI == kBias) v += bias;
-        if (EPI == kBiasRelu) v = fmaxf(v + bias, 0.f);
-        if (EPI == kReluMask) v = pr.aux[(long long)m * pr.ldaux + n] > 0.f ? v : 0.f;
-        pr.C[slab + (long long)m * pr.ldc + n] = v;
+      for (int e = 0; e < 16; ++e) Cs[(rbase + (e & 3) + 8 * (e >> 2)) * CP + col] = acc[i][jj][e];
+    }
+  __syncthreads();
+  const bool vecC = VEC && ((ldc & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(gC) & 15) == 0) &&
+                    ((b.slab_stride & 3) == 0) &&
+                    (EPI != kReluMask || (((ldaux & 3) == 0) && ((reinterpret_cast<uintptr_t>(gaux) & 15) == 0)));
+#pragma unroll
+  for (int i = 0; i < BM * BN / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
+    const int row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
+    const int m = m0 + row, n = n0 + c4;
+    if (m >= M || n >= N) continue;
+    float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
+    if (vecC) {
+      if (EPI == kBias || EPI == kBiasRelu) {
+        const float4 bv = *reinterpret_cast<const float4*>(gbias + n);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      }
+      if (EPI == kBiasRelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (EPI == kReluMask) {
+        const float4 a = *reinterpret_cast<const float4*>(gaux + (long long)m * ldaux + n);
+        v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(gC + slab + (long long)m * ldc + n) = v;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (n + c >= N) break;
+        float x = c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
+        if (EPI == kBias || EPI == kBiasRelu) x += gbias[n + c];
+        if (EPI == kBiasRelu) x = fmaxf(x, 0.f);
+        if (EPI == kReluMask) x = gaux[(long long)m * ldaux + n + c] > 0.f ? x : 0.f;
+        gC[slab + (long long)m * ldc + n + c] = x;
       }
     }
-  if (do_colsum && tid < BM && m0 + tid < pr.M) pr.colsum[slab + m0 + tid] = csum;
+  }
+  if (do_colsum && tid < BM && m0 + tid < M) gcolsum[slab + m0 + tid] = csum;
+}
+
+// VEC requirements of one problem (see gload_kc / gload_ks)
+template <int LAYOUT>
+bool problem_vec_ok(const Problem& p) {
+  const bool base = tt_aligned16(p.A) && tt_aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
+  if (!base) return false;
+  if (LAYOUT == kNT) return p.K % 4 == 0 && p.K >= 4;                       // A, B K-contiguous
+  if (LAYOUT == kNN) return p.K % 4 == 0 && p.K >= 4 && p.N % 4 == 0 && p.N >= 4;  // B K-strided over N
+  return p.M % 4 == 0 && p.N % 4 == 0 && p.M >= 4 && p.N >= 4 && p.K >= 1;  // kTN: both K-strided
 }
 
 template <int LAYOUT, int EPI>
@@ -242,9 +304,12 @@ int launch_le(const Batch& b, int wm, int wn, hipStream_t st) {
   if (maxM == 0 || maxN == 0) return TT_OK;
   const int BM = 64 * wm, BN = 64 * wn;
   const dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count * b.nsplit), block(kThreads);
-  if (wm == 1 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1>), grid, block, 0, st, b);
-  else if (wm == 2 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 2, 1>), grid, block, 0, st, b);
-  else if (wm == 2 && wn == 2) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 2, 2>), grid, block, 0, st, b);
+  bool vec = true;
+  for (int i = 0; i < b.count; ++i) vec = vec && (b.p[i].M == 0 || problem_vec_ok<LAYOUT>(b.p[i]));
+  if (!vec) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1, false>), dim3((maxN + 63) / 64, (maxM + 63) / 64, b.count * b.nsplit), block, 0, st, b);
+  else if (wm == 1 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1, true>), grid, block, 0, st, b);
+  else if (wm == 2 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 2, 1, true>), grid, block, 0, st, b);
+  else if (wm == 2 && wn == 2) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 2, 2, true>), grid, block, 0, st, b);
   else return TT_ERR_UNSUPPORTED;
   TT_CHECK_LAUNCH();
   return TT_OK;

@@ -191,6 +191,15 @@ class TripletTrainer:
         """fwd+bwd of the pooled batch in `slot`, gradient exchange, optimizer; issues
         the NEXT batch's gather where it overlaps the exchange."""
         k = self.accumulation_steps
+        if self.side is not None and nxt is not None:
+            # the next batch's gather (HBM-bound, weight-independent) on a side stream,
+            # concurrent with this batch's MFMA-bound projection kernels
+            main = torch.cuda.current_stream(self.device)
+            self.side.wait_stream(main)  # slot^1 was last read by the previous fwd_bwd on `main`
+            with torch.cuda.stream(self.side):
+                self._pool(slot ^ 1, nxt)
+            nxt = None
+            self._side_pending = True
         self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B))
         self._micro += 1
         do_step = self._micro % k == 0
@@ -199,6 +208,7 @@ class TripletTrainer:
             self.engine.adam(self.step_count, self.lr, None, self.betas[0], self.betas[1], self.eps)
             if nxt is not None:
                 self._pool(slot ^ 1, nxt)
+            self._join_side()
             return
         self.engine.reduce_grads(self.bucket, accumulate=(k > 1 and self._micro % k != 1))
         work = None
@@ -211,6 +221,12 @@ class TripletTrainer:
         if do_step:
             self.step_count += 1
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
+        self._join_side()
+
+    def _join_side(self) -> None:
+        if self.side is not None and getattr(self, "_side_pending", False):
+            torch.cuda.current_stream(self.device).wait_stream(self.side)  # next fwd_bwd reads the prefetched slot
+            self._side_pending = False
 
     # -- public ------------------------------------------------------------------
     def train_step(self, batch: Batch, global_batch: Optional[int] = None) -> None:

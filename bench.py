@@ -179,6 +179,12 @@ def main():
 
     k1_ms = sum(a.elapsed_time(b) for a, b in k1_ev) / max(len(k1_ev), 1)
     alg = k1_algorithmic_bytes(3 * B, S, D)
+    traffic = None  # HBM-side bytes per K1 launch from the committed PMC passes of this same workload, if any
+    tpath = os.path.join(ROOT, "profiles", f"r01_k1_traffic_{args.config}.json")
+    if os.path.exists(tpath) and not args.zipf:
+        tj = json.load(open(tpath))
+        if int(tj.get("algorithmic_bytes_per_launch", -1)) == alg:
+            traffic = tj["traffic_bytes_per_launch"]
     achieved = alg / (k1_ms * 1e-3) / 1e9
     result = {
         "metric": "triplets/sec (q,pos,neg @ seq128/d384), full training step" if args.config == "c2"
@@ -195,7 +201,7 @@ def main():
                    "k1_only": bool(args.k1_only)},
         "roofline": {"kernel": "pool_norm_kernel (K1 gather + masked mean-pool + L2 normalise)", "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
                      "launches_timed": len(k1_ev)},
         "avg_loss": loss_avg,
     }

@@ -198,7 +198,10 @@ typedef struct {
   int32_t max_B;    /* max triplets per step on this replica */
   int32_t max_S;    /* max padded sequence length */
   int32_t device;   /* HIP device ordinal */
-  int32_t reserved;
+  int32_t k1_blocks_per_cu; /* 0 = no cap; >0 caps the K1 workgroups resident per CU (via dynamic
+                               LDS) so that tt_engine_pool can share the chip with the MFMA
+                               kernels of tt_engine_fwd_bwd running on another stream (2 is
+                               enough for ~97 % of K1's stand-alone bandwidth) */
 } tt_engine_config;
 
 /* Device bytes of activation + split-K workspace an engine of this config needs. */

@@ -38,7 +38,7 @@ class TTEngineConfig(C.Structure):
         ("max_B", C.c_int32),
         ("max_S", C.c_int32),
         ("device", C.c_int32),
-        ("reserved", C.c_int32),
+        ("k1_blocks_per_cu", C.c_int32),
     ]
 
 

@@ -10,6 +10,9 @@
 #include <new>
 #include "proj.h"
 
+int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                 const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                 int blocks_per_cu, hipStream_t st);
 int tt_launch_loss_mean(const float* hinge_rows, long long B, float denom, float* loss, double* acc_sum,
                         long long* acc_count, hipStream_t st);
 int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float margin, float grad_scale,
@@ -84,7 +87,8 @@ void carve(tt_engine* e, char* base, size_t* total) {
 
 static int fill_dims(tt_engine* e, const tt_engine_config* cfg) {
   TT_REQUIRE(cfg->V >= 1 && cfg->V <= 0x7fffffffLL && cfg->D >= 1 && cfg->P >= 1 && cfg->P <= 1024 &&
-                 cfg->max_B >= 1 && cfg->max_S >= 1 && (int64_t)cfg->max_B * 3 <= 0x7fffffffLL,
+                 cfg->max_B >= 1 && cfg->max_S >= 1 && (int64_t)cfg->max_B * 3 <= 0x7fffffffLL &&
+                 cfg->k1_blocks_per_cu >= 0,
              TT_ERR_BAD_SHAPE);
   e->cfg = *cfg;
   e->tower_n = (int64_t)cfg->P * cfg->D + cfg->P + (int64_t)cfg->P * cfg->P + cfg->P;
@@ -164,8 +168,8 @@ extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_d
   TT_REQUIRE(e->table, TT_ERR_NULL_POINTER);
   TT_REQUIRE(slot == 0 || slot == 1, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && S >= 1 && S <= e->cfg.max_S, TT_ERR_BAD_SHAPE);
-  return tt_gather_pool_norm_f32(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot],
-                                 3 * (int64_t)B, S, e->cfg.D, e->cfg.V, e->oob, stream);
+  return tt_k1_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], 3 * (int64_t)B, S,
+                      e->cfg.D, e->cfg.V, e->oob, e->cfg.k1_blocks_per_cu, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin, float grad_scale,

@@ -238,9 +238,21 @@ __global__ __launch_bounds__(kThreads) void embed_gather_kernel(const float* __r
   }
 }
 
+// Residency cap.  K1 keeps ~97 % of its bandwidth with only 2 workgroups (8 waves) per
+// CU — each wave has 8 rows (12 KB) in flight — so when it shares the chip with the MFMA
+// kernels on another stream it is launched with enough *dynamic* LDS that at most
+// `blocks_per_cu` of its workgroups fit on a CU, leaving wave slots / registers for them.
+static unsigned k1_dynamic_lds(int blocks_per_cu, unsigned static_lds) {
+  if (blocks_per_cu <= 0 || blocks_per_cu >= 16) return 0;
+  const unsigned per_block = (160u * 1024u) / (unsigned)blocks_per_cu;
+  // one granule (1 KB) of slack so that blocks_per_cu still fit, blocks_per_cu + 1 do not
+  const unsigned want = per_block - 1024u;
+  return want > static_lds ? want - static_lds : 0;
+}
+
 template <typename IdT, typename MaskT, bool DENSE>
 int launch_pool(const float* src, const void* ids, const void* mask, const int32_t* lens, float* out,
-                int64_t N, int S, int D, int64_t V, int32_t* oob, hipStream_t st) {
+                int64_t N, int S, int D, int64_t V, int32_t* oob, int blocks_per_cu, hipStream_t st) {
   const IdT* ids_t = static_cast<const IdT*>(ids);
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
   const dim3 grid(static_cast<unsigned>(N)), block(kThreads);
@@ -252,9 +264,10 @@ int launch_pool(const float* src, const void* ids, const void* mask, const int32
     return TT_OK;
   }
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
-#define TT_POOL_CASE(CC, UU)                                                                       \
-  hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, CC, UU, DENSE>), grid, block, 0, st, src, ids_t, \
-                     mask_t, lens, out, S, D, (long long)V, oob)
+#define TT_POOL_CASE(CC, UU)                                                                      \
+  hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, CC, UU, DENSE>), grid, block,                    \
+                     k1_dynamic_lds(blocks_per_cu, CC * 4096u + 16u), st, src, ids_t, mask_t, lens, out, S, D, \
+                     (long long)V, oob)
   switch (C) {
     case 1: TT_POOL_CASE(1, 8); break;
     case 2: TT_POOL_CASE(2, 8); break;
@@ -269,29 +282,37 @@ int launch_pool(const float* src, const void* ids, const void* mask, const int32
 template <bool DENSE>
 int dispatch_pool(const float* src, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                   const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob,
-                  hipStream_t st) {
+                  int blocks_per_cu, hipStream_t st) {
   // without a mask the MaskT instantiation is irrelevant: use int32
   const int md = mask ? mask_dtype : TT_I32;
-  if (ids_dtype == TT_I32 && md == TT_I32) return launch_pool<int32_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, st);
-  if (ids_dtype == TT_I32 && md == TT_I64) return launch_pool<int32_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, st);
-  if (ids_dtype == TT_I64 && md == TT_I32) return launch_pool<int64_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, st);
-  if (ids_dtype == TT_I64 && md == TT_I64) return launch_pool<int64_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, st);
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_pool<int32_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, blocks_per_cu, st);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_pool<int32_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, blocks_per_cu, st);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_pool<int64_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, blocks_per_cu, st);
+  if (ids_dtype == TT_I64 && md == TT_I64) return launch_pool<int64_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, blocks_per_cu, st);
   return TT_ERR_BAD_DTYPE;
 }
 
 }  // namespace
 
-extern "C" int tt_gather_pool_norm_f32(const float* table, const void* ids, int ids_dtype,
-                                       const void* mask, int mask_dtype, const int32_t* lens,
-                                       float* out, int64_t N, int S, int D, int64_t V,
-                                       int32_t* oob_flag, tt_stream_t stream) {
+// internal (engine.hip): K1 with a residency cap (0 = none)
+int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                 const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                 int blocks_per_cu, hipStream_t st) {
   TT_REQUIRE(table && ids && out, TT_ERR_NULL_POINTER);
   TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x7fffffffLL, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   if (N == 0) return TT_OK;
   return dispatch_pool<false>(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag,
-                              static_cast<hipStream_t>(stream));
+                              blocks_per_cu, st);
+}
+
+extern "C" int tt_gather_pool_norm_f32(const float* table, const void* ids, int ids_dtype,
+                                       const void* mask, int mask_dtype, const int32_t* lens,
+                                       float* out, int64_t N, int S, int D, int64_t V,
+                                       int32_t* oob_flag, tt_stream_t stream) {
+  return tt_k1_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, 0,
+                      static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tt_pool_norm_dense_f32(const float* hidden, const void* mask, int mask_dtype,
@@ -302,7 +323,7 @@ extern "C" int tt_pool_norm_dense_f32(const float* hidden, const void* mask, int
   TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   if (N == 0) return TT_OK;
   // ids are unused in dense mode; pass the hidden pointer as a non-null placeholder
-  return dispatch_pool<true>(hidden, hidden, TT_I32, mask, mask_dtype, lens, out, N, S, D, 1, nullptr,
+  return dispatch_pool<true>(hidden, hidden, TT_I32, mask, mask_dtype, lens, out, N, S, D, 1, nullptr, 0,
                              static_cast<hipStream_t>(stream));
 }
 

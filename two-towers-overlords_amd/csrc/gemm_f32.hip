@@ -20,6 +20,7 @@
 // computes, bitwise), K-steps in ascending order; split-K (kTN) partials go to
 // separate slabs that are summed in fixed order later => run-to-run bitwise
 // reproducible, no float atomics.
+#include <type_traits>
 #include "gemm_f32.h"
 
 namespace ttg {
@@ -38,7 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // under the MFMAs of tile t.  The scalar path (any shape) is correct, not fast.
 //
 // K-contiguous operand: tile [R rows][BK], element (row, k) at P[(r0+row)*ld + k0+k].
-template <int R, bool VEC>
+template <int R, bool VEC, bool FULL>
 __device__ __forceinline__ void gload_kc(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
                                          int ld, int r0, int rmax, int k0, int kend, int tid) {
 #pragma unroll
@@ -46,7 +47,9 @@ __device__ __forceinline__ void gload_kc(float4 (&v)[R * BK / 4 / kThreads], con
     const int f = tid + i * kThreads;
     const int row = f >> 3, kq = f & 7;
     const int gr = r0 + row, gk = k0 + kq * 4;
-    if (VEC) {
+    if (FULL) {  // interior tile: nothing to guard, so the load stays unconditional and countable
+      v[i] = *reinterpret_cast<const float4*>(P + (long long)gr * ld + gk);
+    } else if (VEC) {
       const bool ok = gr < rmax && gk < kend;  // K % 4 == 0: a chunk is all in or all out
       const int cr = min(gr, rmax - 1), ck = min(gk, kend - 4);
       const float4 t = *reinterpret_cast<const float4*>(P + (long long)cr * ld + ck);
@@ -75,7 +78,7 @@ __device__ __forceinline__ void sstore_kc(const float4 (&v)[R * BK / 4 / kThread
 }
 // K-strided operand: tile [BK][R cols], element (k, col) at P[(k0+k)*ld + r0+col].
 // VEC additionally needs rmax % 4 == 0 (a 4-column chunk is all in or all out).
-template <int R, bool VEC>
+template <int R, bool VEC, bool FULL>
 __device__ __forceinline__ void gload_ks(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
                                          int ld, int r0, int rmax, int k0, int kend, int tid) {
   constexpr int RQ = R / 4;
@@ -84,7 +87,9 @@ __device__ __forceinline__ void gload_ks(float4 (&v)[R * BK / 4 / kThreads], con
     const int f = tid + i * kThreads;
     const int krow = f / RQ, rq = f % RQ;
     const int gk = k0 + krow, gr = r0 + rq * 4;
-    if (VEC) {
+    if (FULL) {
+      v[i] = *reinterpret_cast<const float4*>(P + (long long)gk * ld + gr);
+    } else if (VEC) {
       const bool ok = gk < kend && gr < rmax;
       const int ck = min(gk, kend - 1), cr = min(gr, rmax - 4);
       const float4 t = *reinterpret_cast<const float4*>(P + (long long)ck * ld + cr);
@@ -171,37 +176,32 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[NVA], rb[NVB];
+  // Two register staging sets: tile t+2 is requested while tile t is multiplied and
+  // tile t+1 (requested one step earlier) is written to LDS, so a global load has two
+  // K-steps to land (the K loop is unrolled by two so that both sets are static).
+  float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
   float csum = 0.f;  // kTN column sums of A (bias gradient), threads tid < BM of n-tile 0
   const bool do_colsum = (LAYOUT == kTN) && gcolsum != nullptr && blockIdx.x == 0;
 
-  auto gload = [&](int k0) {
-    if (A_KC) gload_kc<BM, VEC>(ra, gA, lda, m0, M, k0, kend, tid);
-    else      gload_ks<BM, VEC>(ra, gA, lda, m0, M, k0, kend, tid);
-    if (B_KC) gload_kc<BN, VEC>(rb, gB, ldb, n0, N, k0, kend, tid);
-    else      gload_ks<BN, VEC>(rb, gB, ldb, n0, N, k0, kend, tid);
+  // FULL: this block's tiles lie wholly inside A, B (rows and k) — true for every block of
+  // the batch shapes the trainer uses; edge blocks take the guarded loads.
+  const bool full = VEC && (m0 + BM <= M) && (n0 + BN <= N) && ((kend - kbeg) % BK == 0);
+  auto gload = [&](float4 (&ra)[NVA], float4 (&rb)[NVB], int k0, auto full_tag) {
+    constexpr bool F = decltype(full_tag)::value;
+    if (A_KC) gload_kc<BM, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+    else      gload_ks<BM, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+    if (B_KC) gload_kc<BN, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    else      gload_ks<BN, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](const float4 (&ra)[NVA], const float4 (&rb)[NVB], int buf) {
     float* As = lds + buf * (A_TILE + B_TILE);
     float* Bs = As + A_TILE;
     if (A_KC) sstore_kc<BM>(ra, As, tid); else sstore_ks<BM>(ra, As, tid);
     if (B_KC) sstore_kc<BN>(rb, Bs, tid); else sstore_ks<BN>(rb, Bs, tid);
   };
-
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk > 0) {
-    gload(kbeg);
-    sstore(0);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const float* __restrict__ As = lds + cur * (A_TILE + B_TILE);
+  auto compute = [&](int buf) {
+    const float* __restrict__ As = lds + buf * (A_TILE + B_TILE);
     const float* __restrict__ Bs = As + A_TILE;
-    const bool more = kt + 1 < nk;
-    if (more) gload(kbeg + (kt + 1) * BK);
-
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
       float4 fa[WM], fb[WN];
@@ -229,9 +229,50 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) csum += As[k * BM + tid];
     }
-    if (more) sstore(cur ^ 1);
+  };
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  auto kloop = [&](auto full_tag) {
+    if (nk > 0) {
+      gload(ra0, rb0, kbeg, full_tag);
+      if (nk > 1) gload(ra1, rb1, kbeg + BK, full_tag);
+      sstore(ra0, rb0, 0);
+    }
     __syncthreads();
-  }
+    int kt = 0;
+    // steady state, two K-steps per trip, no conditionals inside (so the compiler can keep
+    // the newest request in flight behind a counted vmcnt): on entry LDS 0 holds tile kt
+    // and set1 holds tile kt+1 (in flight).
+    for (; kt + 3 < nk; kt += 2) {
+      gload(ra0, rb0, kbeg + (kt + 2) * BK, full_tag);
+      compute(0);
+      sstore(ra1, rb1, 1);
+      __syncthreads();
+      gload(ra1, rb1, kbeg + (kt + 3) * BK, full_tag);
+      compute(1);
+      sstore(ra0, rb0, 0);
+      __syncthreads();
+    }
+    // tail: 1..3 tiles left (LDS 0 = tile kt; set1 = tile kt+1 if it exists)
+    if (kt < nk) {
+      const bool t1 = kt + 1 < nk, t2 = kt + 2 < nk;
+      if (t2) gload(ra0, rb0, kbeg + (kt + 2) * BK, full_tag);
+      compute(0);
+      if (t1) {
+        sstore(ra1, rb1, 1);
+        __syncthreads();
+        compute(1);
+        if (t2) {
+          sstore(ra0, rb0, 0);
+          __syncthreads();
+          compute(0);
+        }
+      }
+      __syncthreads();
+    }
+  };
+  if (VEC && full) kloop(std::true_type{});
+  else kloop(std::false_type{});
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*h.
   // The tile goes through LDS (free after the K loop's last barrier) so that global

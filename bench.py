@@ -147,26 +147,29 @@ def main():
         torch.cuda.synchronize(device)
 
     k1_ev = []
+    depth = trainer.SLOTS - 1 if trainer.side is not None else 1
 
     def run(n_steps, timed):
-        """n_steps batch bodies with the next batch's gather prefetched (TripletTrainer.train_epoch order)."""
-        slot = 0
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); trainer._pool(slot, batches[0]); e1.record(); k1_ev.append((e0, e1))
+        """n_steps batch bodies in TripletTrainer.train_epoch order: gathers run `depth` batches ahead."""
+        trainer.k1_events = k1_ev if timed else None
+        issued = 0
+
+        def feed():
+            nonlocal issued
+            while issued < n_steps and len(trainer._pending) < depth:
+                trainer.gather(batches[issued % n_distinct])
+                issued += 1
+
+        feed()
+        if args.k1_only:
+            while trainer._pending:  # gathers only: drop the pooled batches unprocessed
+                trainer._pending.popleft()
+                feed()
         else:
-            trainer._pool(slot, batches[0])
-        for i in range(n_steps):
-            nxt = batches[(i + 1) % n_distinct] if i + 1 < n_steps else None
-            if args.k1_only:
-                if nxt is not None:
-                    trainer._pool(slot ^ 1, nxt)
-            elif timed and nxt is not None:
-                # same sequence as TripletTrainer._apply, with HIP events around the K1 launch
-                _apply_with_events(trainer, B, B * world, slot, nxt, k1_ev)
-            else:
-                trainer._apply(B, B * world, slot, nxt)
-            slot ^= 1
+            while trainer._pending:
+                trainer.apply(B * world, issue_next=feed)
+                feed()
+        trainer.k1_events = None
 
     run(args.warmup, timed=False)
     barrier()
@@ -184,7 +187,7 @@ def main():
     iso_ev = []
     for i in range(20):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); trainer._pool(i & 1, batches[i % n_distinct]); e1.record()
+        e0.record(); trainer.engine.pool(i & 1, batches[i % n_distinct][0], None, None); e1.record()
         iso_ev.append((e0, e1))
     torch.cuda.synchronize(device)
     iso_ms = sum(a.elapsed_time(b) for a, b in iso_ev[4:]) / len(iso_ev[4:])
@@ -228,22 +231,6 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
-
-
-def _apply_with_events(trainer, B, gB, slot, nxt, k1_ev):
-    """TripletTrainer._apply with the K1 launch bracketed by HIP events on the launch stream."""
-    orig = trainer._pool
-
-    def timed_pool(s, b):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); orig(s, b); e1.record()
-        k1_ev.append((e0, e1))
-
-    trainer._pool = timed_pool
-    try:
-        trainer._apply(B, gB, slot, nxt)
-    finally:
-        trainer._pool = orig
 
 
 if __name__ == "__main__":

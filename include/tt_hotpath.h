@@ -191,6 +191,9 @@ int tt_reduce_slabs_f32(const float* slabs, int nslabs, int64_t slab_stride, flo
  */
 typedef struct tt_engine tt_engine;
 
+/* pooled-input slots: gathers may run up to TT_ENGINE_SLOTS - 1 batches ahead of fwd_bwd */
+#define TT_ENGINE_SLOTS 3
+
 typedef struct {
   int64_t V;        /* table rows */
   int32_t D;        /* embedding dim */
@@ -222,8 +225,8 @@ int tt_engine_bind(tt_engine* e, const float* table, float* params, float* exp_a
 
 /*
  * Phase A (weight-independent): K1 over the 3B texts of one batch into pooled
- * slot `slot` (0/1; two slots so the next batch's gather can overlap the
- * gradient all-reduce / optimizer of the current one).
+ * slot `slot` (0 .. TT_ENGINE_SLOTS-1, so that the gathers of the next batches can run on
+ * another stream under the projection kernels / gradient all-reduce of this one).
  *   ids  [3,B,S] (q, pos, neg — the call order of backend/training.py:40-42)
  *   mask [3,B,S] or NULL; lens [3,B] int32 or NULL
  */

@@ -14,7 +14,7 @@ class OracleEngine:
         self.P = projection_dim
         self.n_params = 2 * tower_param_count(self.D, self.P)
         self.n_slabs = 1
-        self.pooled = [None, None]
+        self.pooled = [None, None, None]
         self.loss_sum, self.count, self.last = 0.0, 0, 0.0
         self.grad = torch.zeros(self.n_params)
 

@@ -41,6 +41,16 @@ def _reference(accum=1):
 
 
 def _worker(rank, world, port, accum, q):
+    try:
+        _worker_body(rank, world, port, accum, q)
+    except Exception as e:  # surface the failure instead of leaving the parent waiting on the queue
+        import traceback
+
+        q.put(("error", f"rank {rank}: {e}\n{traceback.format_exc()}", None))
+        raise
+
+
+def _worker_body(rank, world, port, accum, q):
     from oracle_engine import OracleEngine
     from two_towers_overlords_amd.training import TripletTrainer, shard_batch
 
@@ -74,7 +84,8 @@ def _run(world, accum):
     out = q.get()
     for p in procs:
         p.join(120)
-        assert p.exitcode == 0
+    assert out[0] != "error", out[1]
+    assert all(p.exitcode == 0 for p in procs)
     return out
 
 

@@ -33,7 +33,7 @@ struct tt_engine {
   float* exp_avg_sq;
   // carved out of the caller's workspace
   char* arena;
-  float* pooled[2];
+  float* pooled[TT_ENGINE_SLOTS];
   float* H;
   float* emb;
   float* dOut;
@@ -67,8 +67,7 @@ struct Carver {
 void carve(tt_engine* e, char* base, size_t* total) {
   Carver c{base};
   const size_t rows = 3 * (size_t)e->cfg.max_B;
-  e->pooled[0] = c.take<float>(rows * e->cfg.D);
-  e->pooled[1] = c.take<float>(rows * e->cfg.D);
+  for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->pooled[i] = c.take<float>(rows * e->cfg.D);
   e->H = c.take<float>(rows * e->cfg.P);
   e->emb = c.take<float>(rows * e->cfg.P);
   e->dOut = c.take<float>(rows * e->cfg.P);
@@ -144,7 +143,7 @@ extern "C" int tt_engine_destroy(tt_engine* e) {
 extern "C" int64_t tt_engine_param_count(const tt_engine* e) { return ok(e) ? e->nparam : -1; }
 extern "C" int tt_engine_grad_slabs(const tt_engine* e) { return ok(e) ? e->nslabs : -1; }
 extern "C" const float* tt_engine_pooled(const tt_engine* e, int slot) {
-  return ok(e) && (slot == 0 || slot == 1) ? e->pooled[slot] : nullptr;
+  return ok(e) && slot >= 0 && slot < TT_ENGINE_SLOTS ? e->pooled[slot] : nullptr;
 }
 extern "C" const float* tt_engine_embeddings(const tt_engine* e) { return ok(e) ? e->emb : nullptr; }
 extern "C" const float* tt_engine_grad_slab0(const tt_engine* e) { return ok(e) ? e->slabs : nullptr; }
@@ -166,7 +165,7 @@ extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_d
                               int mask_dtype, const int32_t* lens, int32_t B, int32_t S, tt_stream_t stream) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(e->table, TT_ERR_NULL_POINTER);
-  TT_REQUIRE(slot == 0 || slot == 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && S >= 1 && S <= e->cfg.max_S, TT_ERR_BAD_SHAPE);
   return tt_k1_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], 3 * (int64_t)B, S,
                       e->cfg.D, e->cfg.V, e->oob, e->cfg.k1_blocks_per_cu, static_cast<hipStream_t>(stream));
@@ -176,7 +175,7 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin
                                  float loss_denominator, tt_stream_t stream) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
-  TT_REQUIRE(slot == 0 || slot == 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && loss_denominator > 0.f, TT_ERR_BAD_SHAPE);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int D = e->cfg.D, P = e->cfg.P;

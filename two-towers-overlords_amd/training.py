@@ -14,6 +14,7 @@ Two ways to run the batch body of backend/training.py:36-53:
 """
 from __future__ import annotations
 
+import collections
 import math
 from typing import Iterable, Optional, Sequence, Tuple
 
@@ -141,6 +142,8 @@ class TripletTrainer:
     an oracle-backed stand-in); the product default is the HIP engine.
     """
 
+    SLOTS = 3  # == TT_ENGINE_SLOTS (include/tt_hotpath.h)
+
     def __init__(self, model: Optional[TwoTowersModel] = None, *, table: Optional[torch.Tensor] = None,
                  params: Optional[dict] = None, max_batch: int, max_seq_len: int, margin: float = 0.3,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
@@ -187,79 +190,117 @@ class TripletTrainer:
         self.step_count = 0        # optimizer steps taken
         self._micro = 0            # batches since the last optimizer step (carried across epochs, like the reference)
         self.side = torch.cuda.Stream(self.device) if (overlap_streams and self.device.type == "cuda") else None
+        self._pending = collections.deque()   # gathered, not yet applied: (slot, ready event, local B)
+        self._next_slot = 0
+        self._slot_free = {}                  # slot -> event after the fwd_bwd that last read it
+        self.k1_events = None                 # set to a list to collect (start, end) HIP events per K1 launch
 
     # -- helpers ---------------------------------------------------------------
     def named_parameters(self) -> dict:
         return {name: self.flat[off: off + int(math.prod(shape))].view(shape)
                 for name, off, shape in flat_param_slices(self.D, self.P)}
 
-    def _pool(self, slot: int, batch: Batch) -> None:
+    # -- pipeline: gathers run ahead of the weight-dependent part ---------------------
+    def gather(self, batch: Batch) -> None:
+        """Enqueue K1 (gather + pool + normalise) for a batch that a later `apply()` will
+        consume.  Weight-independent, so it may run up to SLOTS-1 batches ahead; with a side
+        stream it runs concurrently with the projection kernels of earlier batches."""
+        if len(self._pending) >= self.SLOTS:
+            raise RuntimeError("gather(): all pooled-input slots are in use; call apply() first")
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % self.SLOTS
         ids, mask, lens = batch
-        self.engine.pool(slot, ids, mask, lens)
+        if self.side is None:
+            self._timed_pool(slot, ids, mask, lens)
+            self._pending.append((slot, None, ids.shape[1]))
+            return
+        free = self._slot_free.get(slot)
+        if free is not None:
+            self.side.wait_event(free)  # the fwd_bwd that last read this slot (on the main stream)
+        with torch.cuda.stream(self.side):
+            self._timed_pool(slot, ids, mask, lens)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self._pending.append((slot, ev, ids.shape[1]))
 
-    def _apply(self, local_B: int, global_B: int, slot: int, nxt: Optional[Batch]) -> None:
-        """fwd+bwd of the pooled batch in `slot`, gradient exchange, optimizer; issues
-        the NEXT batch's gather where it overlaps the exchange."""
+    def _timed_pool(self, slot, ids, mask, lens) -> None:
+        if self.k1_events is None:
+            self.engine.pool(slot, ids, mask, lens)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.engine.pool(slot, ids, mask, lens)
+        e1.record()
+        self.k1_events.append((e0, e1))
+
+    def apply(self, global_B: Optional[int] = None, issue_next=None) -> None:
+        """fwd + bwd of the oldest gathered batch, gradient exchange, optimizer.
+        `issue_next()` (optional) is called where enqueueing further gathers overlaps best:
+        before the projection kernels when gathers have their own stream, else right after
+        the gradient all-reduce has been launched."""
+        slot, ev, local_B = self._pending.popleft()
+        global_B = global_B or local_B * self.world
         k = self.accumulation_steps
-        if self.side is not None and nxt is not None:
-            # the next batch's gather (HBM-bound, weight-independent) on a side stream,
-            # concurrent with this batch's MFMA-bound projection kernels
-            main = torch.cuda.current_stream(self.device)
-            self.side.wait_stream(main)  # slot^1 was last read by the previous fwd_bwd on `main`
-            with torch.cuda.stream(self.side):
-                self._pool(slot ^ 1, nxt)
-            nxt = None
-            self._side_pending = True
+        if self.side is not None:
+            if issue_next is not None:
+                issue_next()
+                issue_next = None
+            torch.cuda.current_stream(self.device).wait_event(ev)
         self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B))
+        if self.side is not None:
+            done = torch.cuda.Event()
+            done.record()
+            self._slot_free[slot] = done
         self._micro += 1
         do_step = self._micro % k == 0
         if self.bucket is None:  # single replica, no accumulation: Adam folds the slab sum
             self.step_count += 1
             self.engine.adam(self.step_count, self.lr, None, self.betas[0], self.betas[1], self.eps)
-            if nxt is not None:
-                self._pool(slot ^ 1, nxt)
-            self._join_side()
+            if issue_next is not None:
+                issue_next()
             return
         self.engine.reduce_grads(self.bucket, accumulate=(k > 1 and self._micro % k != 1))
         work = None
         if do_step and self.world > 1:
             work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        if nxt is not None:
-            self._pool(slot ^ 1, nxt)  # weight-independent: runs under the all-reduce
+        if issue_next is not None:
+            issue_next()  # weight-independent: runs under the all-reduce
         if work is not None:
             work.wait()
         if do_step:
             self.step_count += 1
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
-        self._join_side()
-
-    def _join_side(self) -> None:
-        if self.side is not None and getattr(self, "_side_pending", False):
-            torch.cuda.current_stream(self.device).wait_stream(self.side)  # next fwd_bwd reads the prefetched slot
-            self._side_pending = False
 
     # -- public ------------------------------------------------------------------
     def train_step(self, batch: Batch, global_batch: Optional[int] = None) -> None:
         """One batch (this rank's shard).  No host synchronisation."""
-        B = batch[0].shape[1]
-        self._pool(0, batch)
-        self._apply(B, global_batch or B * self.world, 0, None)
+        self.gather(batch)
+        self.apply(global_batch)
 
     def train_epoch(self, batches: Iterable[Batch], global_batch_sizes: Optional[Sequence[int]] = None) -> float:
         """All batches of an epoch; returns the mean of the per-batch (global) losses
         like backend/training.py:63.  One host sync at the end."""
         it = iter(batches)
-        cur = next(it, None)
-        if cur is None:
+        depth = self.SLOTS - 1 if self.side is not None else 1
+        state = {"done": False}
+
+        def feed():
+            while not state["done"] and len(self._pending) < depth:
+                b = next(it, None)
+                if b is None:
+                    state["done"] = True
+                else:
+                    self.gather(b)
+
+        feed()
+        if not self._pending:
             return float("nan")
-        slot, i = 0, 0
-        self._pool(slot, cur)
-        while cur is not None:
-            nxt = next(it, None)
-            B = cur[0].shape[1]
-            gB = global_batch_sizes[i] if global_batch_sizes is not None else B * self.world
-            self._apply(B, gB, slot, nxt)
-            cur, slot, i = nxt, slot ^ 1, i + 1
+        i = 0
+        while self._pending:
+            gB = global_batch_sizes[i] if global_batch_sizes is not None else None
+            self.apply(gB, issue_next=feed)
+            feed()
+            i += 1
         return self.epoch_loss()
 
     def epoch_loss(self) -> float:

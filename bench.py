@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the gather of batch i+1 after (not under) the projection kernels of batch i")
     ap.add_argument("--k1-blocks-per-cu", type=int, default=None)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the multi-process "
+                         "path with several ranks sharing one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,11 +113,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP library is the only implementation of the hot path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev  # gloo rehearsal: several ranks may share one GPU
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import two_towers_overlords_amd as pkg
     from two_towers_overlords_amd.training import TripletTrainer

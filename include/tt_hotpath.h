@@ -227,12 +227,26 @@ int tt_engine_bind(tt_engine* e, const float* table, float* params, float* exp_a
  * Phase A (weight-independent): K1 over the 3B texts of one batch into pooled
  * slot `slot` (0 .. TT_ENGINE_SLOTS-1, so that the gathers of the next batches can run on
  * another stream under the projection kernels / gradient all-reduce of this one).
- *   ids  [3,B,S] (q, pos, neg — the call order of backend/training.py:40-42)
- *   mask [3,B,S] or NULL; lens [3,B] int32 or NULL
+ *   ids  [roles,B,S] (q, pos[, neg] — the call order of backend/training.py:40-42)
+ *   mask [roles,B,S] or NULL; lens [roles,B] int32 or NULL
+ *   roles 3: independent negatives.  roles 2: negatives are in-batch positives and will be
+ *   given to tt_engine_fwd_bwd as an index (no third gather) — backend/data.py:113-137 builds
+ *   negatives exactly that way (`negatives[i] = batch[neg_idx]["positive"]`).
  */
 int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask,
-                   int mask_dtype, const int32_t* lens, int32_t B, int32_t S,
+                   int mask_dtype, const int32_t* lens, int32_t roles, int32_t B, int32_t S,
                    tt_stream_t stream);
+
+/*
+ * Phase A from a frozen-feature cache.  The encoder is frozen (backend/model.py:29-30,51), so
+ * the pooled-normalised vector of a text never changes: compute it once for every unique text
+ * with tt_gather_pool_norm_f32 (`embed` mode) or encoder + tt_pool_norm_dense_f32 (`bert`
+ * mode) into cache [cache_rows, D]; every later use of the text is one row copy.
+ *   rows [roles,B] int32/int64: cache row of each text.
+ */
+int tt_engine_pool_cached(tt_engine* e, int slot, const float* cache, int64_t cache_rows,
+                          const void* rows, int rows_dtype, int32_t roles, int32_t B,
+                          tt_stream_t stream);
 
 /*
  * Phase B: projection forward (both towers), triplet loss, backward.  Leaves
@@ -245,9 +259,13 @@ int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const
  *   loss_denominator: the logged batch loss is (sum_b hinge_b) / loss_denominator —
  *               B for the reference semantics; B_global on a data-parallel shard,
  *               so that the per-rank values add up to the global batch loss.
+ *   neg_index:  NULL (slot holds q, pos, neg), or int32[B] with values in [0,B) (slot holds q,
+ *               pos): negative i is positive neg_index[i].  The document tower then runs on B
+ *               rows instead of 2B and each row's gradient is dp[j] + sum_{i: neg_index[i]=j} dn[i]
+ *               — the same numbers as the three-encode form up to fp32 summation order.
  */
-int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin, float grad_scale,
-                      float loss_denominator, tt_stream_t stream);
+int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_t* neg_index, float margin,
+                      float grad_scale, float loss_denominator, tt_stream_t stream);
 
 /* grad_out[param_count] (+)= sum of slabs — the flat bucket handed to the RCCL all-reduce. */
 int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumulate, tt_stream_t stream);
@@ -267,8 +285,8 @@ int tt_engine_train_step(tt_engine* e, const void* ids, int ids_dtype, const voi
 
 /* Device pointers into the engine's activations for the last fwd_bwd on `slot`
  * (rows: [q(B); pos(B); neg(B)]).  Valid until the next call on that slot. */
-const float* tt_engine_pooled(const tt_engine* e, int slot);   /* [3B, D] */
-const float* tt_engine_embeddings(const tt_engine* e);         /* [3B, P] projected */
+const float* tt_engine_pooled(const tt_engine* e, int slot);   /* [roles*B, D] */
+const float* tt_engine_embeddings(const tt_engine* e);         /* [roles*B, P] projected */
 const float* tt_engine_grad_slab0(const tt_engine* e);         /* [slabs, param_count] */
 
 /* Host-side read of {sum of batch losses, number of batches, last loss}; synchronises

@@ -37,17 +37,23 @@ class OracleEngine:
                 mask = torch.ones_like(ids, dtype=torch.int64)
             else:
                 mask = (torch.arange(S).view(1, 1, S) < lens.unsqueeze(-1)).long()
-        self.pooled[slot] = [orc.gather_pool_normalize(self.table, ids[r].long(), mask[r].long()) for r in range(3)]
+        self.pooled[slot] = [orc.gather_pool_normalize(self.table, ids[r].long(), mask[r].long()) for r in range(ids.shape[0])]
 
-    def fwd_bwd(self, slot, B, margin, grad_scale=None, loss_denominator=None):
+    def pool_cached(self, slot, cache, rows):
+        self.pooled[slot] = [cache[rows[r].long()] for r in range(rows.shape[0])]
+
+    def fwd_bwd(self, slot, B, margin, grad_scale=None, loss_denominator=None, neg_index=None):
         gs = 1.0 / B if grad_scale is None else grad_scale
         den = float(B) if loss_denominator is None else loss_denominator
         leaves = {k: v.detach().clone().requires_grad_(True) for k, v in self._named(self.params).items()}
         embs = []
-        for r, tower in enumerate(("query_tower", "document_tower", "document_tower")):
+        towers = ("query_tower", "document_tower", "document_tower")[: len(self.pooled[slot])]
+        for r, tower in enumerate(towers):
             k = tower + ".projection."
             embs.append(orc.projection(self.pooled[slot][r], leaves[k + "0.weight"], leaves[k + "0.bias"],
                                        leaves[k + "2.weight"], leaves[k + "2.bias"]))
+        if neg_index is not None:
+            embs.append(embs[1][neg_index.long()])  # negatives are in-batch positives
         pd = orc.cosine_distance(embs[0], embs[1])
         nd = orc.cosine_distance(embs[0], embs[2])
         hinge_sum = torch.relu(pd - nd + margin).sum()

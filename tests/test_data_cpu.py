@@ -72,3 +72,27 @@ def test_token_loader_negatives_are_in_batch_positives():
             # positions past the length are padding zeros
             assert int(ids[2, i, lens[2, i]:].abs().sum()) == 0
     assert total == 23
+
+
+def test_token_loader_emit_modes_describe_the_same_triplets():
+    """`index` / `cache` batches carry the same triplets as `ids3` under the same seed."""
+    ds = _DS(23, 6)
+    a = list(TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit="ids3"))
+    b = list(TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit="index"))
+    ld = TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit="cache")
+    c = list(ld)
+    all_ids, all_lens = ld.all_texts()
+    assert all_ids.shape[0] == 2 * 23
+    for (ids3, lens3), bi, bc in zip(a, b, c):
+        e = bi.expand_negatives()
+        S = e.ids.shape[2]
+        assert torch.equal(e.lens, lens3)
+        assert torch.equal(e.ids, ids3[:, :, :S]) and int(ids3[:, :, S:].abs().sum()) == 0
+        assert torch.equal(bc.neg_index, bi.neg_index)
+        ec = bc.expand_negatives()
+        for r in range(3):  # cache rows point at the same token rows
+            rows = ec.cache_rows[r].long()
+            assert torch.equal(all_lens[rows], lens3[r])
+            for i in range(rows.numel()):
+                L = int(lens3[r, i])
+                assert torch.equal(all_ids[rows[i], :L], ids3[r, i, :L])

@@ -297,3 +297,66 @@ def test_engine_vs_oracle_metric_shape(tt):
     for k, pt in _unflat(flat, D, P).items():
         assert_params_close(pt.cpu().numpy(), params[k].numpy(), 1e-3, 3)
     eng.close()
+
+
+# --------------------------------------------------------------------------- f1: negatives by index, feature cache
+def test_engine_neg_index_equals_three_encodes(tt):
+    """In-batch negatives by index (2 gathers, document tower on B rows, scatter-added gradient)
+    == the reference's three-encode form with negatives = positives[neg_index]."""
+    _, engine = tt
+    V, D, P, B, S = 3000, 384, 64, 200, 40
+    table = orc.synthetic_table(V, D, seed=7) * 30
+    params = orc.init_params(D, P, seed=8)
+    gen = torch.Generator().manual_seed(9)
+    q_b, p_b, _ = orc.synthetic_batch(B, S, V, seed=33, ragged=True)
+    neg = torch.randint(0, B, (B,), generator=gen)
+    neg[:10] = 3  # one positive drawn as the negative of many triplets
+    batch3 = (q_b, p_b, (p_b[0][neg], p_b[1][neg]))
+    loss, grads, embs = orc.loss_and_grads(table, batch3, params, 0.3)
+
+    eng = engine.HotPathEngine(table.cuda(), P, B, S)
+    flat = _flat(params).cuda()
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    eng.bind(flat, m, v)
+    ids2 = torch.stack([q_b[0], p_b[0]]).int().cuda()
+    lens2 = torch.stack([q_b[1].sum(1), p_b[1].sum(1)]).int().cuda()
+    eng.pool(0, ids2, lens=lens2)
+    eng.fwd_bwd(0, B, 0.3, neg_index=neg.int().cuda())
+    emb = eng.embeddings(B, roles=2)
+    close(emb[0], embs[0])
+    close(emb[1], embs[1])
+    g = torch.empty_like(flat)
+    eng.reduce_grads(g)
+    close(g, _flat(grads), rel_to_max=True)
+    _, _, last = eng.read_stats()
+    assert abs(last - loss.item()) <= TOL
+    eng.close()
+
+
+def test_feature_cache_is_bitwise_the_gather(tt):
+    """pool_cached copies rows of K1's own output: pooled inputs (hence everything after) are bit-identical."""
+    ops, engine = tt
+    from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
+
+    V, D, P, B, S, N = 2000, 128, 32, 64, 24, 500
+    table = orc.synthetic_table(V, D, seed=1) * 30
+    params = {k: v.cuda() for k, v in orc.init_params(D, P, seed=2).items()}
+    gen = torch.Generator().manual_seed(3)
+    ids_all = torch.randint(0, V, (N, S), generator=gen).int().cuda()
+    lens_all = torch.randint(1, S + 1, (N,), generator=gen).int().cuda()
+    rows = torch.randint(0, N, (4, 3, B), generator=gen).int().cuda()
+    out = {}
+    for mode in ("ids", "cache"):
+        tr = TripletTrainer(table=table.cuda(), params={k: v.clone() for k, v in params.items()}, max_batch=B,
+                            max_seq_len=S, margin=0.3, lr=1e-3)
+        if mode == "cache":
+            cache = tr.build_feature_cache(ids_all, lens=lens_all)
+            assert torch.equal(cache, ops.gather_pool_norm(table.cuda(), ids_all, lens=lens_all))
+            batches = [TripletBatch(cache_rows=rows[i].contiguous()) for i in range(4)]
+        else:
+            batches = [TripletBatch(ids=ids_all[rows[i].long()].contiguous(), lens=lens_all[rows[i].long()].contiguous())
+                       for i in range(4)]
+        avg = tr.train_epoch(batches)
+        out[mode] = (avg, tr.flat.clone())
+    assert out["ids"][0] == out["cache"][0]
+    assert torch.equal(out["ids"][1], out["cache"][1])

@@ -108,3 +108,43 @@ def test_shard_batch_partition():
     assert [g[0][0].shape[1] for g in got] == [3, 3, 2, 2] and all(g[1] == 10 for g in got)
     assert torch.equal(torch.cat([g[0][0] for g in got], dim=1), ids)
     assert torch.equal(torch.cat([g[0][2] for g in got], dim=1), lens)
+
+
+def test_neg_index_and_feature_cache_equal_three_encodes():
+    """roles-2 batches (negatives by in-batch index) and frozen-feature-cache batches give the
+    same epoch as the reference-shaped three-encode batches (trainer logic, oracle engine)."""
+    from oracle_engine import OracleEngine
+    from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
+
+    torch.set_num_threads(1)
+    table, params, _ = _setup()
+    g = torch.Generator().manual_seed(11)
+    runs = {}
+    q_ids = torch.randint(1, V, (NB, B, S), generator=g)
+    p_ids = torch.randint(1, V, (NB, B, S), generator=g)
+    lens = torch.randint(1, S + 1, (NB, 2, B), generator=g).int()
+    neg = torch.stack([torch.tensor([(i + 1 + int(k)) % B for i, k in enumerate(torch.randint(0, B - 1, (B,), generator=g))])
+                       for _ in range(NB)]).int()
+    for mode in ("ids3", "index", "cache"):
+        tr = TripletTrainer(table=table, params={k: v.clone() for k, v in params.items()}, max_batch=B, max_seq_len=S,
+                            margin=0.3, lr=1e-3, engine=OracleEngine(table, P, B, S))
+        if mode == "cache":
+            flat_ids = torch.cat([q_ids.reshape(-1, S), p_ids.reshape(-1, S)])
+            flat_lens = torch.cat([lens[:, 0].reshape(-1), lens[:, 1].reshape(-1)])
+            mask = (torch.arange(S).unsqueeze(0) < flat_lens.unsqueeze(1)).long()
+            tr.feature_cache = orc.gather_pool_normalize(table, flat_ids, mask)  # what build_feature_cache computes
+        batches = []
+        for i in range(NB):
+            ids2 = torch.stack([q_ids[i], p_ids[i]])
+            if mode == "cache":
+                rows = torch.stack([torch.arange(B) + i * B, torch.arange(B) + NB * B + i * B]).int()
+                batches.append(TripletBatch(cache_rows=rows, neg_index=neg[i]))
+            else:
+                tb = TripletBatch(ids=ids2, lens=lens[i], neg_index=neg[i])
+                batches.append(tb.expand_negatives() if mode == "ids3" else tb)
+        avg = tr.train_epoch(batches)
+        runs[mode] = (avg, {k: v.clone() for k, v in tr.named_parameters().items()})
+    for mode in ("index", "cache"):
+        assert abs(runs[mode][0] - runs["ids3"][0]) < 1e-6
+        for k in orc.PARAM_KEYS:
+            np.testing.assert_allclose(runs[mode][1][k].numpy(), runs["ids3"][1][k].numpy(), atol=2e-6, rtol=0)

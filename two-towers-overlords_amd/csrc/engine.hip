@@ -17,7 +17,7 @@ int tt_launch_loss_mean(const float* hinge_rows, long long B, float denom, float
                         long long* acc_count, hipStream_t st);
 int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float margin, float grad_scale,
                            long long B, int P, float* pos_dist, float* neg_dist, float* hinge_rows,
-                           float* dq, float* dp, float* dn, hipStream_t st);
+                           float* dq, float* dp, float* dn, const int* neg_index, hipStream_t st);
 
 struct tt_engine {
   uint32_t magic;
@@ -162,17 +162,29 @@ extern "C" int tt_engine_bind(tt_engine* e, const float* table, float* params, f
 }
 
 extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask,
-                              int mask_dtype, const int32_t* lens, int32_t B, int32_t S, tt_stream_t stream) {
+                              int mask_dtype, const int32_t* lens, int32_t roles, int32_t B, int32_t S,
+                              tt_stream_t stream) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(e->table, TT_ERR_NULL_POINTER);
-  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (roles == 2 || roles == 3), TT_ERR_BAD_SHAPE);
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && S >= 1 && S <= e->cfg.max_S, TT_ERR_BAD_SHAPE);
-  return tt_k1_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], 3 * (int64_t)B, S,
+  return tt_k1_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B, S,
                       e->cfg.D, e->cfg.V, e->oob, e->cfg.k1_blocks_per_cu, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin, float grad_scale,
-                                 float loss_denominator, tt_stream_t stream) {
+extern "C" int tt_engine_pool_cached(tt_engine* e, int slot, const float* cache, int64_t cache_rows,
+                                     const void* rows, int rows_dtype, int32_t roles, int32_t B,
+                                     tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(cache && rows, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (roles == 2 || roles == 3), TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && cache_rows >= 1, TT_ERR_BAD_SHAPE);
+  return tt_embed_gather_f32(cache, rows, rows_dtype, e->pooled[slot], roles * (int64_t)B, e->cfg.D, cache_rows,
+                             e->oob, stream);
+}
+
+extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_t* neg_index, float margin,
+                                 float grad_scale, float loss_denominator, tt_stream_t stream) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
   TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
@@ -184,7 +196,7 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin
     const int64_t row0 = i == 0 ? 0 : B;
     float* w = e->params + i * e->tower_n;
     float* g = e->slabs + i * e->tower_n;
-    t[i].M = i == 0 ? B : 2 * B;
+    t[i].M = i == 0 ? B : (neg_index ? B : 2 * B);
     t[i].X = e->pooled[slot] + row0 * D;
     t[i].W1 = w;
     t[i].b1 = w + (int64_t)P * D;
@@ -203,9 +215,10 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, float margin
   if (rc != TT_OK) return rc;
   const float* q = e->emb;
   const float* p = e->emb + (int64_t)B * P;
-  const float* n = e->emb + 2 * (int64_t)B * P;
+  // with neg_index the negatives ARE rows of the positives' embeddings (no third encode)
+  const float* n = neg_index ? p : e->emb + 2 * (int64_t)B * P;
   rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
-                              e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, st);
+                              e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st);
   if (rc != TT_OK) return rc;
   rc = tt_launch_loss_mean(e->hinge, B, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
   if (rc != TT_OK) return rc;
@@ -230,9 +243,9 @@ extern "C" int tt_engine_adam(tt_engine* e, const float* grads, double lr, doubl
 extern "C" int tt_engine_train_step(tt_engine* e, const void* ids, int ids_dtype, const void* mask,
                                     int mask_dtype, const int32_t* lens, int32_t B, int32_t S, float margin,
                                     double lr, int64_t step, tt_stream_t stream) {
-  int rc = tt_engine_pool(e, 0, ids, ids_dtype, mask, mask_dtype, lens, B, S, stream);
+  int rc = tt_engine_pool(e, 0, ids, ids_dtype, mask, mask_dtype, lens, 3, B, S, stream);
   if (rc != TT_OK) return rc;
-  rc = tt_engine_fwd_bwd(e, 0, B, margin, 1.0f / (float)B, (float)B, stream);
+  rc = tt_engine_fwd_bwd(e, 0, B, nullptr, margin, 1.0f / (float)B, (float)B, stream);
   if (rc != TT_OK) return rc;
   return tt_engine_adam(e, nullptr, lr, 0.9, 0.999, 1e-8, step, stream);
 }

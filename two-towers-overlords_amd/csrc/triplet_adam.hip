@@ -16,12 +16,16 @@ template <int NC>
 __global__ __launch_bounds__(kThreads) void triplet_kernel(
     const float* __restrict__ q, const float* __restrict__ p, const float* __restrict__ n, float margin,
     float grad_scale, long long B, int P, float* __restrict__ pos_dist, float* __restrict__ neg_dist,
-    float* __restrict__ hinge_rows, float* __restrict__ dq, float* __restrict__ dp, float* __restrict__ dn) {
+    float* __restrict__ hinge_rows, float* __restrict__ dq, float* __restrict__ dp, float* __restrict__ dn,
+    const int* __restrict__ neg_index) {
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const long long row = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (row >= B) return;
   const float eps = 1e-8f;
   const long long o = row * (long long)P;
+  // in-batch negatives (backend/data.py:113-137): negative i is positive neg_index[i]; `n` then
+  // points at the positives' embeddings
+  const long long on = neg_index ? (long long)min(max(neg_index[row], 0), (int)B - 1) * P : o;
 
   float xq[NC], xp[NC], xn[NC];
   float sq = 0.f, sp = 0.f, sn = 0.f;
@@ -31,7 +35,7 @@ __global__ __launch_bounds__(kThreads) void triplet_kernel(
     const bool ok = col < P;
     xq[c] = ok ? q[o + col] : 0.f;
     xp[c] = ok ? p[o + col] : 0.f;
-    xn[c] = ok ? n[o + col] : 0.f;
+    xn[c] = ok ? n[on + col] : 0.f;
     sq = fmaf(xq[c], xq[c], sq);
     sp = fmaf(xp[c], xp[c], sp);
     sn = fmaf(xn[c], xn[c], sn);
@@ -72,6 +76,28 @@ __global__ __launch_bounds__(kThreads) void triplet_kernel(
       dq[o + col] = g * (dcn_dq - dcp_dq);
       dp[o + col] = -g * ((u - vp * kp) / cp);
       dn[o + col] = g * ((u - vn * kn) / cn);
+    }
+  }
+}
+
+// In-batch negatives: the document-tower output row j takes part in its own triplet (as the
+// positive) and in every triplet that drew it as the negative, so its gradient is
+// dp[j] + sum_{i: neg_index[i]==j} dn[i].  One wave per destination row j scans neg_index in
+// ascending i (fixed order => reproducible), no atomics.
+__global__ __launch_bounds__(kThreads) void scatter_neg_grad_kernel(float* __restrict__ dp,
+                                                                    const float* __restrict__ dn,
+                                                                    const int* __restrict__ neg_index,
+                                                                    int B, int P) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const int j = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (j >= B) return;
+  for (int base = 0; base < B; base += TT_WAVE) {
+    const int i = base + lane;
+    unsigned long long hit = __ballot(i < B && neg_index[i] == j);
+    while (hit) {
+      const int src = base + __builtin_ctzll(hit);
+      hit &= hit - 1;
+      for (int c = lane; c < P; c += TT_WAVE) dp[(long long)j * P + c] += dn[(long long)src * P + c];
     }
   }
 }
@@ -167,12 +193,12 @@ int tt_launch_loss_mean(const float* hinge_rows, long long B, float denom, float
 // internal: triplet rows only (no mean)
 int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float margin, float grad_scale,
                            long long B, int P, float* pos_dist, float* neg_dist, float* hinge_rows,
-                           float* dq, float* dp, float* dn, hipStream_t st) {
+                           float* dq, float* dp, float* dn, const int* neg_index, hipStream_t st) {
   const dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
   const int nc = (P + TT_WAVE - 1) / TT_WAVE;
 #define TT_TRIP(NC)                                                                                     \
   hipLaunchKernelGGL(triplet_kernel<NC>, grid, block, 0, st, q, p, n, margin, grad_scale, B, P, pos_dist, \
-                     neg_dist, hinge_rows, dq, dp, dn)
+                     neg_dist, hinge_rows, dq, dp, dn, neg_index)
   if (nc <= 1) TT_TRIP(1);
   else if (nc <= 2) TT_TRIP(2);
   else if (nc <= 4) TT_TRIP(4);
@@ -183,6 +209,10 @@ int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float
   else return TT_ERR_UNSUPPORTED;  // P > 1024
 #undef TT_TRIP
   TT_CHECK_LAUNCH();
+  if (neg_index && dp && dn) {
+    hipLaunchKernelGGL(scatter_neg_grad_kernel, grid, block, 0, st, dp, dn, neg_index, (int)B, P);
+    TT_CHECK_LAUNCH();
+  }
   return TT_OK;
 }
 
@@ -194,7 +224,7 @@ extern "C" int tt_triplet_fwd_bwd_f32(const float* q, const float* p, const floa
   TT_REQUIRE((dq && dp && dn) || (!dq && !dp && !dn), TT_ERR_NULL_POINTER);
   TT_REQUIRE(B >= 1 && P >= 1 && P <= 1024, TT_ERR_BAD_SHAPE);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, pos_dist, neg_dist, hinge_rows, dq, dp, dn, st);
+  int rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, pos_dist, neg_dist, hinge_rows, dq, dp, dn, nullptr, st);
   if (rc != TT_OK) return rc;
   if (loss) return tt_launch_loss_mean(hinge_rows, B, static_cast<float>(B), loss, nullptr, nullptr, st);
   return TT_OK;

@@ -89,7 +89,15 @@ class TokenTripletLoader:
     """
 
     def __init__(self, dataset, tokenizer: Callable, batch_size: int, device, max_length: int = 512,
-                 seed: Optional[int] = None, shuffle: bool = True):
+                 seed: Optional[int] = None, shuffle: bool = True, emit: str = "ids3"):
+        """emit: "ids3"  -> (ids [3,B,S], lens [3,B])                      three gathers per batch
+                 "index" -> TripletBatch(ids [2,B,S], lens, neg_index)     negatives by in-batch index
+                 "cache" -> TripletBatch(cache_rows [2,B], neg_index)      rows of a frozen-feature cache
+                            laid out [queries (N); positives (N)] — build it with
+                            `trainer.build_feature_cache(*loader.all_texts())`"""
+        if emit not in ("ids3", "index", "cache"):
+            raise ValueError("emit must be 'ids3', 'index' or 'cache'")
+        self.emit = emit
         self.batch_size = batch_size
         self.device = torch.device(device)
         self.shuffle = shuffle
@@ -111,6 +119,12 @@ class TokenTripletLoader:
     def __len__(self) -> int:
         return (len(self.query_ids) + self.batch_size - 1) // self.batch_size
 
+    def all_texts(self):
+        """(ids [2N, S], lens [2N]) of every query then every positive — the input of the feature cache."""
+        S = max(self.q_ids.shape[1], self.p_ids.shape[1])
+        pad = lambda t: torch.nn.functional.pad(t, (0, S - t.shape[1]))
+        return torch.cat([pad(self.q_ids), pad(self.p_ids)]).contiguous(), torch.cat([self.q_lens, self.p_lens]).contiguous()
+
     def __iter__(self):
         n = len(self.query_ids)
         order = list(range(n))
@@ -120,7 +134,25 @@ class TokenTripletLoader:
             idx = order[s: s + self.batch_size]
             neg = sample_negative_indices([self.query_ids[i] for i in idx], self.rng)
             it = torch.tensor(idx, device=self.device)
-            nt = it[torch.tensor(neg, device=self.device)]
+            neg_t = torch.tensor(neg, device=self.device)
+            if self.emit != "ids3":
+                from .training import TripletBatch
+
+                ni = neg_t.to(torch.int32)
+                if self.emit == "cache":
+                    n_items = len(self.query_ids)
+                    rows = torch.stack([it, it + n_items]).to(torch.int32).contiguous()
+                    yield TripletBatch(cache_rows=rows, neg_index=ni)
+                    continue
+                q, ql = self.q_ids[it], self.q_lens[it]
+                p, pl = self.p_ids[it], self.p_lens[it]
+                S = int(max(int(ql.max()), int(pl.max())))
+                ids = torch.zeros((2, len(idx), S), dtype=torch.int32, device=self.device)
+                ids[0, :, : min(S, q.shape[1])] = q[:, :S]
+                ids[1, :, : min(S, p.shape[1])] = p[:, :S]
+                yield TripletBatch(ids=ids, lens=torch.stack([ql, pl]), neg_index=ni)
+                continue
+            nt = it[neg_t]
             q, ql = self.q_ids[it], self.q_lens[it]
             p, pl = self.p_ids[it], self.p_lens[it]
             ng, nl = self.p_ids[nt], self.p_lens[nt]

@@ -81,32 +81,48 @@ class HotPathEngine:
         call("tt_engine_bind", self._h, self.table.data_ptr(), params.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr())
 
     # ------------------------------------------------------------------ phases
-    def _ids_args(self, ids, mask, lens) -> Tuple[int, int, Optional[int], int, Optional[int], int, int]:
+    def _ids_args(self, ids, mask, lens):
         _req(ids, "ids", ndim=3)
-        if ids.dtype not in _INT_WIDTH or ids.shape[0] != 3 or ids.device != self.device:
-            raise ValueError("ids: expected an int32/int64 [3, B, S] tensor (q, pos, neg) on the engine device")
-        _, B, S = ids.shape
+        if ids.dtype not in _INT_WIDTH or ids.shape[0] not in (2, 3) or ids.device != self.device:
+            raise ValueError("ids: expected an int32/int64 [roles, B, S] tensor (q, pos[, neg]) on the engine device")
+        R, B, S = ids.shape
         mw = 8
         if mask is not None:
             _req(mask, "mask", ndim=3)
-            if mask.dtype not in _INT_WIDTH or tuple(mask.shape) != (3, B, S) or mask.device != self.device:
-                raise ValueError("mask: expected an int32/int64 [3, B, S] tensor")
+            if mask.dtype not in _INT_WIDTH or tuple(mask.shape) != (R, B, S) or mask.device != self.device:
+                raise ValueError("mask: expected an int32/int64 [roles, B, S] tensor")
             mw = _INT_WIDTH[mask.dtype]
             lens = None
         elif lens is not None:
             _req(lens, "lens", torch.int32, 2)
-            if tuple(lens.shape) != (3, B) or lens.device != self.device:
-                raise ValueError("lens: expected an int32 [3, B] tensor")
+            if tuple(lens.shape) != (R, B) or lens.device != self.device:
+                raise ValueError("lens: expected an int32 [roles, B] tensor")
         return (ids.data_ptr(), _INT_WIDTH[ids.dtype], None if mask is None else mask.data_ptr(), mw,
-                None if lens is None else lens.data_ptr(), B, S)
+                None if lens is None else lens.data_ptr(), R, B, S)
 
     def pool(self, slot: int, ids, mask=None, lens=None) -> None:
+        """K1 over ids [roles, B, S] (roles = 3: q, pos, neg; 2: q, pos with in-batch negatives by index)."""
         a = self._ids_args(ids, mask, lens)
-        call("tt_engine_pool", self._h, slot, a[0], a[1], a[2], a[3], a[4], a[5], a[6], self._stream())
+        call("tt_engine_pool", self._h, slot, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], self._stream())
+
+    def pool_cached(self, slot: int, cache: torch.Tensor, rows: torch.Tensor) -> None:
+        """Phase A from a frozen-feature cache: pooled[slot] = cache[rows], rows [roles, B]."""
+        _req(cache, "cache", torch.float32, 2)
+        _req(rows, "rows", ndim=2)
+        if cache.shape[1] != self.D or rows.dtype not in _INT_WIDTH or rows.shape[0] not in (2, 3):
+            raise ValueError("pool_cached: cache must be [N, D] float32 and rows an int [roles, B] tensor")
+        call("tt_engine_pool_cached", self._h, slot, cache.data_ptr(), cache.shape[0], rows.data_ptr(),
+             _INT_WIDTH[rows.dtype], rows.shape[0], rows.shape[1], self._stream())
 
     def fwd_bwd(self, slot: int, B: int, margin: float, grad_scale: Optional[float] = None,
-                loss_denominator: Optional[float] = None) -> None:
-        call("tt_engine_fwd_bwd", self._h, slot, B, margin, (1.0 / B) if grad_scale is None else grad_scale,
+                loss_denominator: Optional[float] = None, neg_index: Optional[torch.Tensor] = None) -> None:
+        ni = None
+        if neg_index is not None:
+            _req(neg_index, "neg_index", torch.int32, 1)
+            if neg_index.numel() != B or neg_index.device != self.device:
+                raise ValueError("neg_index: expected an int32 [B] tensor on the engine device")
+            ni = neg_index.data_ptr()
+        call("tt_engine_fwd_bwd", self._h, slot, B, ni, margin, (1.0 / B) if grad_scale is None else grad_scale,
              float(B) if loss_denominator is None else loss_denominator, self._stream())
 
     def reduce_grads(self, out: torch.Tensor, accumulate: bool = False) -> None:
@@ -124,7 +140,9 @@ class HotPathEngine:
 
     def train_step(self, ids, mask=None, lens=None, *, margin: float, lr: float, step: int) -> None:
         a = self._ids_args(ids, mask, lens)
-        call("tt_engine_train_step", self._h, a[0], a[1], a[2], a[3], a[4], a[5], a[6], margin, lr, step, self._stream())
+        if a[5] != 3:
+            raise ValueError("train_step: ids must be [3, B, S]")
+        call("tt_engine_train_step", self._h, a[0], a[1], a[2], a[3], a[4], a[6], a[7], margin, lr, step, self._stream())
 
     def read_stats(self, reset: bool = True) -> Tuple[float, int, float]:
         """(sum of batch losses, batches, last batch loss); synchronises the stream."""
@@ -138,11 +156,11 @@ class HotPathEngine:
         assert 0 <= off and off + 4 * numel <= self.workspace.numel()
         return self.workspace[off: off + 4 * numel].view(torch.float32)
 
-    def pooled(self, slot: int, B: int) -> torch.Tensor:
-        return self._view(_lib.load().tt_engine_pooled(self._h, slot), 3 * B * self.D).view(3, B, self.D)
+    def pooled(self, slot: int, B: int, roles: int = 3) -> torch.Tensor:
+        return self._view(_lib.load().tt_engine_pooled(self._h, slot), roles * B * self.D).view(roles, B, self.D)
 
-    def embeddings(self, B: int) -> torch.Tensor:
-        return self._view(_lib.load().tt_engine_embeddings(self._h), 3 * B * self.P).view(3, B, self.P)
+    def embeddings(self, B: int, roles: int = 3) -> torch.Tensor:
+        return self._view(_lib.load().tt_engine_embeddings(self._h), roles * B * self.P).view(roles, B, self.P)
 
     def grad_slabs(self) -> torch.Tensor:
         stride = (self.n_params + 3) // 4 * 4

@@ -15,6 +15,7 @@ Two ways to run the batch body of backend/training.py:36-53:
 from __future__ import annotations
 
 import collections
+import dataclasses
 import math
 from typing import Iterable, Optional, Sequence, Tuple
 
@@ -128,6 +129,36 @@ def train_epoch_optimized(model: TwoTowersModel, dataloader, criterion: TripletL
 Batch = Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]  # ids[3,B,S], mask[3,B,S]|None, lens[3,B]|None
 
 
+@dataclasses.dataclass
+class TripletBatch:
+    """One batch for the fused engine.  Either token ids (`ids` [roles,B,S] + `mask` or `lens`)
+    or rows of the trainer's frozen-feature cache (`cache_rows` [roles,B]).  roles = 3: query,
+    positive, negative.  roles = 2 + `neg_index` (int32 [B]): the negatives are in-batch
+    positives (backend/data.py:113-137), negative i = positive neg_index[i] — no third encode."""
+
+    ids: Optional[torch.Tensor] = None
+    mask: Optional[torch.Tensor] = None
+    lens: Optional[torch.Tensor] = None
+    neg_index: Optional[torch.Tensor] = None
+    cache_rows: Optional[torch.Tensor] = None
+
+    @property
+    def size(self) -> int:
+        return (self.ids if self.ids is not None else self.cache_rows).shape[1]
+
+    def expand_negatives(self) -> "TripletBatch":
+        """roles 2 + neg_index -> roles 3 (negatives materialised by a row gather)."""
+        if self.neg_index is None:
+            return self
+        ni = self.neg_index.long()
+        cat = lambda t: None if t is None else torch.cat([t, t[1:2].index_select(1, ni)], dim=0).contiguous()
+        return TripletBatch(cat(self.ids), cat(self.mask), cat(self.lens), None, cat(self.cache_rows))
+
+
+def as_batch(b) -> TripletBatch:
+    return b if isinstance(b, TripletBatch) else TripletBatch(*b)
+
+
 class TripletTrainer:
     """The batch body of backend/training.py:36-53 on the fused engine.
 
@@ -194,6 +225,8 @@ class TripletTrainer:
         self._next_slot = 0
         self._slot_free = {}                  # slot -> event after the fwd_bwd that last read it
         self.k1_events = None                 # set to a list to collect (start, end) HIP events per K1 launch
+        self.feature_cache = None             # [N_texts, D] pooled-normalised vectors (build_feature_cache)
+        self.table = table
 
     # -- helpers ---------------------------------------------------------------
     def named_parameters(self) -> dict:
@@ -209,36 +242,57 @@ class TripletTrainer:
             raise RuntimeError("gather(): all pooled-input slots are in use; call apply() first")
         slot = self._next_slot
         self._next_slot = (slot + 1) % self.SLOTS
-        ids, mask, lens = batch
+        batch = as_batch(batch)
+        if batch.neg_index is not None and self.world > 1:
+            batch = batch.expand_negatives()  # an in-batch index does not survive sharding across ranks
         if self.side is None:
-            self._timed_pool(slot, ids, mask, lens)
-            self._pending.append((slot, None, ids.shape[1]))
+            self._timed_pool(slot, batch)
+            self._pending.append((slot, None, batch.size, batch.neg_index))
             return
         free = self._slot_free.get(slot)
         if free is not None:
             self.side.wait_event(free)  # the fwd_bwd that last read this slot (on the main stream)
         with torch.cuda.stream(self.side):
-            self._timed_pool(slot, ids, mask, lens)
+            self._timed_pool(slot, batch)
             ev = torch.cuda.Event()
             ev.record(self.side)
-        self._pending.append((slot, ev, ids.shape[1]))
+        self._pending.append((slot, ev, batch.size, batch.neg_index))
 
-    def _timed_pool(self, slot, ids, mask, lens) -> None:
-        if self.k1_events is None:
-            self.engine.pool(slot, ids, mask, lens)
-            return
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        self.engine.pool(slot, ids, mask, lens)
-        e1.record()
-        self.k1_events.append((e0, e1))
+    def _timed_pool(self, slot, batch: TripletBatch) -> None:
+        if self.k1_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if batch.cache_rows is not None:
+            if self.feature_cache is None:
+                raise RuntimeError("batch carries cache_rows but build_feature_cache() has not been called")
+            self.engine.pool_cached(slot, self.feature_cache, batch.cache_rows)
+        else:
+            self.engine.pool(slot, batch.ids, batch.mask, batch.lens)
+        if self.k1_events is not None:
+            e1.record()
+            self.k1_events.append((e0, e1))
+
+    @torch.no_grad()
+    def build_feature_cache(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                            lens: Optional[torch.Tensor] = None, chunk: int = 65536) -> torch.Tensor:
+        """Frozen-feature cache: the encoder is frozen (backend/model.py:29-30,51),
+        so every text's pooled-normalised vector is computed ONCE here (K1 over ids [N,S]) and later
+        batches only copy rows (`TripletBatch.cache_rows`).  Returns the [N, D] cache."""
+        N = ids.shape[0]
+        out = torch.empty((N, self.D), dtype=torch.float32, device=self.device)
+        for s in range(0, N, chunk):
+            e = min(N, s + chunk)
+            ops.gather_pool_norm(self.table, ids[s:e].contiguous(), None if mask is None else mask[s:e].contiguous(),
+                                 None if lens is None else lens[s:e].contiguous(), out=out[s:e])
+        self.feature_cache = out
+        return out
 
     def apply(self, global_B: Optional[int] = None, issue_next=None) -> None:
         """fwd + bwd of the oldest gathered batch, gradient exchange, optimizer.
         `issue_next()` (optional) is called where enqueueing further gathers overlaps best:
         before the projection kernels when gathers have their own stream, else right after
         the gradient all-reduce has been launched."""
-        slot, ev, local_B = self._pending.popleft()
+        slot, ev, local_B, neg_index = self._pending.popleft()
         global_B = global_B or local_B * self.world
         k = self.accumulation_steps
         if self.side is not None:
@@ -246,7 +300,7 @@ class TripletTrainer:
                 issue_next()
                 issue_next = None
             torch.cuda.current_stream(self.device).wait_event(ev)
-        self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B))
+        self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B), neg_index=neg_index)
         if self.side is not None:
             done = torch.cuda.Event()
             done.record()
@@ -315,13 +369,16 @@ class TripletTrainer:
 def shard_batch(batch: Batch, rank: int, world: int) -> Tuple[Batch, int]:
     """Contiguous split of a global batch over `world` ranks; the
     last ranks get one triplet fewer when B % world != 0.  Returns (shard, B_global)."""
-    ids, mask, lens = batch
-    B = ids.shape[1]
+    tb = as_batch(batch).expand_negatives() if world > 1 else as_batch(batch)
+    B = tb.size
     base, rem = divmod(B, world)
     lo = rank * base + min(rank, rem)
     hi = lo + base + (1 if rank < rem else 0)
     cut = lambda t: None if t is None else t[:, lo:hi].contiguous()
-    return (cut(ids), cut(mask), cut(lens)), B
+    if isinstance(batch, TripletBatch):
+        ni = tb.neg_index if world == 1 else None
+        return TripletBatch(cut(tb.ids), cut(tb.mask), cut(tb.lens), ni, cut(tb.cache_rows)), B
+    return (cut(tb.ids), cut(tb.mask), cut(tb.lens)), B
 
 
 def _proj_dim(params: dict) -> int:

@@ -292,25 +292,46 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   const bool vecC = VEC && ((ldc & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(gC) & 15) == 0) &&
                     ((b.slab_stride & 3) == 0) &&
                     (EPI != kReluMask || (((ldaux & 3) == 0) && ((reinterpret_cast<uintptr_t>(gaux) & 15) == 0)));
+  constexpr int NI = BM * BN / 4 / kThreads;  // 16-byte chunks of the C tile per thread
+  static_assert(kThreads % (BN / 4) == 0, "every chunk of a thread lies in the same 4 columns");
+  const int c4 = (tid % (BN / 4)) * 4, n = n0 + c4;
+  const int row_first = tid / (BN / 4);
+  constexpr int ROW_STEP = kThreads / (BN / 4);
+  if (vecC) {
+    // All loads first (tile chunks from LDS, bias once, ReLU-mask rows), then the stores back
+    // to back: a load between two stores would make each store wait for the previous one
+    // (vmcnt counts loads and stores together).
+    float4 v[NI], am[NI];
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool col_ok = n < N;
+    if ((EPI == kBias || EPI == kBiasRelu) && col_ok) bv = *reinterpret_cast<const float4*>(gbias + n);
 #pragma unroll
-  for (int i = 0; i < BM * BN / 4 / kThreads; ++i) {
-    const int f = tid + i * kThreads;
-    const int row = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
-    const int m = m0 + row, n = n0 + c4;
-    if (m >= M || n >= N) continue;
-    float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
-    if (vecC) {
-      if (EPI == kBias || EPI == kBiasRelu) {
-        const float4 bv = *reinterpret_cast<const float4*>(gbias + n);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-      }
-      if (EPI == kBiasRelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    for (int i = 0; i < NI; ++i) {
+      const int row = row_first + i * ROW_STEP;
+      v[i] = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
       if (EPI == kReluMask) {
-        const float4 a = *reinterpret_cast<const float4*>(gaux + (long long)m * ldaux + n);
-        v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+        const int m = min(m0 + row, M - 1);
+        am[i] = col_ok ? *reinterpret_cast<const float4*>(gaux + (long long)m * ldaux + n) : v[i];
       }
-      *reinterpret_cast<float4*>(gC + slab + (long long)m * ldc + n) = v;
-    } else {
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int m = m0 + row_first + i * ROW_STEP;
+      float4 x = v[i];
+      if (EPI == kBias || EPI == kBiasRelu) { x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w; }
+      if (EPI == kBiasRelu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+      if (EPI == kReluMask) {
+        x.x = am[i].x > 0.f ? x.x : 0.f; x.y = am[i].y > 0.f ? x.y : 0.f;
+        x.z = am[i].z > 0.f ? x.z : 0.f; x.w = am[i].w > 0.f ? x.w : 0.f;
+      }
+      if (m < M && col_ok) *reinterpret_cast<float4*>(gC + slab + (long long)m * ldc + n) = x;
+    }
+  } else {
+    for (int i = 0; i < NI; ++i) {
+      const int row = row_first + i * ROW_STEP;
+      const int m = m0 + row;
+      if (m >= M) continue;
+      const float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (n + c >= N) break;

@@ -46,6 +46,9 @@ struct tt_engine {
   double* loss_sum;
   long long* loss_cnt;
   int32_t* oob;
+  // second stream for the work that is off the critical path of a step (loss mean, dW2/db2)
+  hipStream_t aux;
+  hipEvent_t ev_fork, ev_join;
 };
 
 namespace {
@@ -128,6 +131,13 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
   }
   e->arena = static_cast<char*>(workspace);
   carve(e, e->arena, &total);
+  // the fork/join stream is optional: without it everything runs on the caller's stream
+  if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) e->aux = nullptr;
+  if (e->aux && (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                 hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)) {
+    (void)hipStreamDestroy(e->aux);
+    e->aux = nullptr;
+  }
   e->magic = kMagic;
   *out = e;
   return TT_OK;
@@ -135,6 +145,12 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
 
 extern "C" int tt_engine_destroy(tt_engine* e) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  if (e->aux) {
+    (void)hipStreamSynchronize(e->aux);
+    (void)hipEventDestroy(e->ev_fork);
+    (void)hipEventDestroy(e->ev_join);
+    (void)hipStreamDestroy(e->aux);
+  }
   e->magic = 0;
   delete e;
   return TT_OK;
@@ -220,9 +236,27 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
   rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
                               e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st);
   if (rc != TT_OK) return rc;
-  rc = tt_launch_loss_mean(e->hinge, B, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
+  if (!e->aux) {
+    rc = tt_launch_loss_mean(e->hinge, B, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
+    if (rc != TT_OK) return rc;
+    return ttp::backward(t, 2, D, P, e->nslabs, e->slab_stride, st);
+  }
+  // fork: the loss mean and dW2/db2 only need what the triplet kernel produced; they run on the
+  // engine's second stream under the dH -> dW1/db1 chain, and join before the caller's next
+  // stream-ordered call (reduce_grads / adam / the next fwd_bwd).
+  TT_HIP(hipEventRecord(e->ev_fork, st));
+  TT_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+  rc = tt_launch_loss_mean(e->hinge, B, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, e->aux);
   if (rc != TT_OK) return rc;
-  return ttp::backward(t, 2, D, P, e->nslabs, e->slab_stride, st);
+  rc = ttp::backward_dw2(t, 2, D, P, e->nslabs, e->slab_stride, e->aux);
+  if (rc != TT_OK) return rc;
+  TT_HIP(hipEventRecord(e->ev_join, e->aux));
+  rc = ttp::backward_dh(t, 2, D, P, st);
+  if (rc != TT_OK) return rc;
+  rc = ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
+  if (rc != TT_OK) return rc;
+  TT_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
+  return TT_OK;
 }
 
 extern "C" int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumulate, tt_stream_t stream) {

@@ -297,26 +297,22 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   const int c4 = (tid % (BN / 4)) * 4, n = n0 + c4;
   const int row_first = tid / (BN / 4);
   constexpr int ROW_STEP = kThreads / (BN / 4);
-  if (vecC) {
-    // All loads first (tile chunks from LDS, bias once, ReLU-mask rows), then the stores back
-    // to back: a load between two stores would make each store wait for the previous one
-    // (vmcnt counts loads and stores together).
+  if (vecC && full) {
+    // Interior tile: no guards, so nothing splits the stores into exec-masked branches
+    // (each of which the compiler fences with vmcnt(0)).  All loads first (tile chunks from
+    // LDS, bias once, ReLU-mask rows), then NI stores back to back.
     float4 v[NI], am[NI];
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool col_ok = n < N;
-    if ((EPI == kBias || EPI == kBiasRelu) && col_ok) bv = *reinterpret_cast<const float4*>(gbias + n);
+    if (EPI == kBias || EPI == kBiasRelu) bv = *reinterpret_cast<const float4*>(gbias + n);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int row = row_first + i * ROW_STEP;
       v[i] = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
-      if (EPI == kReluMask) {
-        const int m = min(m0 + row, M - 1);
-        am[i] = col_ok ? *reinterpret_cast<const float4*>(gaux + (long long)m * ldaux + n) : v[i];
-      }
+      if (EPI == kReluMask) am[i] = *reinterpret_cast<const float4*>(gaux + (long long)(m0 + row) * ldaux + n);
     }
+    float* __restrict__ cbase = gC + slab + (long long)(m0 + row_first) * ldc + n;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int m = m0 + row_first + i * ROW_STEP;
       float4 x = v[i];
       if (EPI == kBias || EPI == kBiasRelu) { x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w; }
       if (EPI == kBiasRelu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
@@ -324,7 +320,24 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
         x.x = am[i].x > 0.f ? x.x : 0.f; x.y = am[i].y > 0.f ? x.y : 0.f;
         x.z = am[i].z > 0.f ? x.z : 0.f; x.w = am[i].w > 0.f ? x.w : 0.f;
       }
-      if (m < M && col_ok) *reinterpret_cast<float4*>(gC + slab + (long long)m * ldc + n) = x;
+      *reinterpret_cast<float4*>(cbase + (long long)i * ROW_STEP * ldc) = x;
+    }
+  } else if (vecC) {
+    const bool col_ok = n < N;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((EPI == kBias || EPI == kBiasRelu) && col_ok) bv = *reinterpret_cast<const float4*>(gbias + n);
+    for (int i = 0; i < NI; ++i) {
+      const int row = row_first + i * ROW_STEP;
+      const int m = m0 + row;
+      if (m >= M || !col_ok) continue;
+      float4 x = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
+      if (EPI == kBias || EPI == kBiasRelu) { x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w; }
+      if (EPI == kBiasRelu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+      if (EPI == kReluMask) {
+        const float4 a = *reinterpret_cast<const float4*>(gaux + (long long)m * ldaux + n);
+        x.x = a.x > 0.f ? x.x : 0.f; x.y = a.y > 0.f ? x.y : 0.f; x.z = a.z > 0.f ? x.z : 0.f; x.w = a.w > 0.f ? x.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(gC + slab + (long long)m * ldc + n) = x;
     }
   } else {
     for (int i = 0; i < NI; ++i) {

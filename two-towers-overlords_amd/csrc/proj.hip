@@ -48,36 +48,57 @@ int forward(const Tower* t, int count, int D, int P, hipStream_t st) {
   return ttg::launch(ttg::kNT, ttg::kBias, b2, wm, wn, st);
 }
 
-int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
-  ttg::Batch g2{}, gh{}, g1{};
-  g2.count = gh.count = g1.count = count;
-  g2.nsplit = g1.nsplit = nsplit;
-  gh.nsplit = 1;
-  g2.slab_stride = g1.slab_stride = slab_stride;
-  long long rows = 0;
+int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
+  ttg::Batch g2{};
+  g2.count = count;
+  g2.nsplit = nsplit;
+  g2.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
-    rows += t[i].M;
-    const int kps = k_per_split(t[i].M, nsplit);
     // dW2[i,j] = sum_m dOut[m,i] H[m,j];  db2[i] = sum_m dOut[m,i]
     ttg::Problem& a = g2.p[i];
     a.A = t[i].dOut; a.B = t[i].H; a.C = t[i].gW2; a.colsum = t[i].gb2;
-    a.M = P; a.N = P; a.K = t[i].M; a.lda = P; a.ldb = P; a.ldc = P; a.k_per_split = kps;
+    a.M = P; a.N = P; a.K = t[i].M; a.lda = P; a.ldb = P; a.ldc = P; a.k_per_split = k_per_split(t[i].M, nsplit);
+  }
+  return ttg::launch(ttg::kTN, ttg::kStore, g2, 1, 1, st);
+}
+
+int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st) {
+  ttg::Batch gh{};
+  gh.count = count;
+  gh.nsplit = 1;
+  long long rows = 0;
+  for (int i = 0; i < count; ++i) {
+    rows += t[i].M;
     // dH = (dOut W2) * [H > 0]
     ttg::Problem& h = gh.p[i];
     h.A = t[i].dOut; h.B = t[i].W2; h.C = t[i].dH; h.aux = t[i].H;
     h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
+  }
+  int wm, wn;
+  pick_tile(rows, P, wm, wn);
+  return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st);
+}
+
+int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
+  ttg::Batch g1{};
+  g1.count = count;
+  g1.nsplit = nsplit;
+  g1.slab_stride = slab_stride;
+  for (int i = 0; i < count; ++i) {
     // dW1[i,j] = sum_m dH[m,i] X[m,j];  db1[i] = sum_m dH[m,i]
     ttg::Problem& c = g1.p[i];
     c.A = t[i].dH; c.B = t[i].X; c.C = t[i].gW1; c.colsum = t[i].gb1;
-    c.M = P; c.N = D; c.K = t[i].M; c.lda = P; c.ldb = D; c.ldc = D; c.k_per_split = kps;
+    c.M = P; c.N = D; c.K = t[i].M; c.lda = P; c.ldb = D; c.ldc = D; c.k_per_split = k_per_split(t[i].M, nsplit);
   }
-  int wm, wn;
-  int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, 1, 1, st);
-  if (rc != TT_OK) return rc;
-  pick_tile(rows, P, wm, wn);
-  rc = ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st);
-  if (rc != TT_OK) return rc;
   return ttg::launch(ttg::kTN, ttg::kStore, g1, 1, 1, st);
+}
+
+int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
+  int rc = backward_dw2(t, count, D, P, nsplit, slab_stride, st);
+  if (rc != TT_OK) return rc;
+  rc = backward_dh(t, count, D, P, st);
+  if (rc != TT_OK) return rc;
+  return backward_dw1(t, count, D, P, nsplit, slab_stride, st);
 }
 
 }  // namespace ttp

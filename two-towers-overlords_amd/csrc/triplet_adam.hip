@@ -88,16 +88,25 @@ __global__ __launch_bounds__(kThreads) void scatter_neg_grad_kernel(float* __res
                                                                     const float* __restrict__ dn,
                                                                     const int* __restrict__ neg_index,
                                                                     int B, int P) {
+  constexpr int G = 8;  // index chunks requested together (one dependent load latency per G*64 rows)
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const int j = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (j >= B) return;
-  for (int base = 0; base < B; base += TT_WAVE) {
-    const int i = base + lane;
-    unsigned long long hit = __ballot(i < B && neg_index[i] == j);
-    while (hit) {
-      const int src = base + __builtin_ctzll(hit);
-      hit &= hit - 1;
-      for (int c = lane; c < P; c += TT_WAVE) dp[(long long)j * P + c] += dn[(long long)src * P + c];
+  for (int base = 0; base < B; base += G * TT_WAVE) {
+    int idx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int i = base + g * TT_WAVE + lane;
+      idx[g] = i < B ? neg_index[i] : -1;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      unsigned long long hit = __ballot(idx[g] == j);
+      while (hit) {
+        const int src = base + g * TT_WAVE + __builtin_ctzll(hit);
+        hit &= hit - 1;
+        for (int c = lane; c < P; c += TT_WAVE) dp[(long long)j * P + c] += dn[(long long)src * P + c];
+      }
     }
   }
 }

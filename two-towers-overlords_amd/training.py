@@ -224,7 +224,9 @@ class TripletTrainer:
         self._pending = collections.deque()   # gathered, not yet applied: (slot, ready event, local B)
         self._next_slot = 0
         self._slot_free = {}                  # slot -> event after the fwd_bwd that last read it
-        self.k1_events = None                 # set to a list to collect (start, end) HIP events per K1 launch
+        self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
+        self.k1_event_every = 4               # ... of every 4th launch
+        self._k1_count = 0
         self.feature_cache = None             # [N_texts, D] pooled-normalised vectors (build_feature_cache)
         self.table = table
 
@@ -259,7 +261,11 @@ class TripletTrainer:
         self._pending.append((slot, ev, batch.size, batch.neg_index))
 
     def _timed_pool(self, slot, batch: TripletBatch) -> None:
+        timed = False
         if self.k1_events is not None:
+            self._k1_count += 1
+            timed = self._k1_count % self.k1_event_every == 0  # events cost ~5 us of stream time each
+        if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if batch.cache_rows is not None:
@@ -268,7 +274,7 @@ class TripletTrainer:
             self.engine.pool_cached(slot, self.feature_cache, batch.cache_rows)
         else:
             self.engine.pool(slot, batch.ids, batch.mask, batch.lens)
-        if self.k1_events is not None:
+        if timed:
             e1.record()
             self.k1_events.append((e0, e1))
 

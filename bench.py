@@ -222,12 +222,13 @@ def main():
     torch.cuda.synchronize(device)
     iso_ms = sum(a.elapsed_time(b) for a, b in iso_ev[4:]) / len(iso_ev[4:])
     k1_ms = sum(a.elapsed_time(b) for a, b in k1_ev) / max(len(k1_ev), 1)
-    alg = k1_algorithmic_bytes(3 * B, S, D)
+    roles = 3 if args.inputs == "ids3" else 2
+    alg = k1_algorithmic_bytes(roles * B, S, D)
     traffic = None  # HBM-side bytes per K1 launch from the committed PMC passes of this same workload, if any
     tpath = os.path.join(ROOT, "profiles", f"r01_k1_traffic_{args.config}.json")
     if os.path.exists(tpath) and not args.zipf:
         tj = json.load(open(tpath))
-        if int(tj.get("algorithmic_bytes_per_launch", -1)) == alg:
+        if int(tj.get("algorithmic_bytes_per_launch", -1)) == alg and args.inputs == "ids3":
             traffic = tj["traffic_bytes_per_launch"]
     achieved = alg / (k1_ms * 1e-3) / 1e9
     result = {
@@ -256,6 +257,8 @@ def main():
                                "frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "avg_loss": loss_avg,
     }
+    if args.inputs == "cache":  # no gather in the step: the K1 roofline does not apply
+        result["roofline"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:

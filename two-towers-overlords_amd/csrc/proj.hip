@@ -2,6 +2,8 @@
 // gradients, as grouped exact-fp32 MFMA GEMMs (both towers in one launch).
 // Replaces backend/model.py:33-38,59 and the part of loss.backward()
 // (backend/training.py:50) that runs through it.
+#include <cstdio>
+#include <cstdlib>
 #include "proj.h"
 
 namespace ttp {
@@ -21,6 +23,9 @@ int choose_nsplit(long long M) {
 
 // block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
 static void pick_tile(long long total_rows, int N, int& wm, int& wn) {
+  if (const char* e = getenv("TT_GEMM_TILE")) {  // experiments only: "wm,wn"
+    if (sscanf(e, "%d,%d", &wm, &wn) == 2) return;
+  }
   const long long tiles64 = ((total_rows + 63) / 64) * ((N + 63) / 64);
   if (tiles64 >= 2048 && N >= 128) { wm = 2; wn = 2; }
   else if (tiles64 >= 1024) { wm = 2; wn = 1; }

@@ -227,7 +227,8 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
     t[i].gW2 = t[i].gb1 + P;
     t[i].gb2 = t[i].gW2 + (int64_t)P * P;
   }
-  int rc = ttp::forward(t, 2, D, P, st);
+  const bool shared = e->cfg.k1_blocks_per_cu > 0;  // gathers run beside these kernels on another stream
+  int rc = ttp::forward(t, 2, D, P, st, shared);
   if (rc != TT_OK) return rc;
   const float* q = e->emb;
   const float* p = e->emb + (int64_t)B * P;
@@ -251,7 +252,7 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
   rc = ttp::backward_dw2(t, 2, D, P, e->nslabs, e->slab_stride, e->aux);
   if (rc != TT_OK) return rc;
   TT_HIP(hipEventRecord(e->ev_join, e->aux));
-  rc = ttp::backward_dh(t, 2, D, P, st);
+  rc = ttp::backward_dh(t, 2, D, P, st, shared);
   if (rc != TT_OK) return rc;
   rc = ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
   if (rc != TT_OK) return rc;

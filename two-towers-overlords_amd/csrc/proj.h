@@ -27,13 +27,15 @@ int k_per_split(int M, int nsplit);
 // split count used for a standalone backward over M rows
 int choose_nsplit(long long M);
 
-int forward(const Tower* t, int count, int D, int P, hipStream_t st);
+// low_traffic: prefer 128x64 block tiles (half the weight re-reads) — for when the GEMMs share
+// the chip with the gather kernel, whose bandwidth their operand traffic eats into.
+int forward(const Tower* t, int count, int D, int P, hipStream_t st, bool low_traffic = false);
 // writes nsplit partial slabs of (dW1, db1, dW2, db2) per tower; dH is scratch
 int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
 // The three launches of `backward`, separately (dW2/db2 is independent of the dH -> dW1/db1
 // chain, so a caller may run it on another stream):
 int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
-int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st);
+int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, bool low_traffic = false);
 int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
 
 }  // namespace ttp

@@ -2,8 +2,6 @@
 // gradients, as grouped exact-fp32 MFMA GEMMs (both towers in one launch).
 // Replaces backend/model.py:33-38,59 and the part of loss.backward()
 // (backend/training.py:50) that runs through it.
-#include <cstdio>
-#include <cstdlib>
 #include "proj.h"
 
 namespace ttp {
@@ -22,17 +20,14 @@ int choose_nsplit(long long M) {
 }
 
 // block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
-static void pick_tile(long long total_rows, int N, int& wm, int& wn) {
-  if (const char* e = getenv("TT_GEMM_TILE")) {  // experiments only: "wm,wn"
-    if (sscanf(e, "%d,%d", &wm, &wn) == 2) return;
-  }
+static void pick_tile(long long total_rows, int N, int& wm, int& wn, bool low_traffic = false) {
   const long long tiles64 = ((total_rows + 63) / 64) * ((N + 63) / 64);
   if (tiles64 >= 2048 && N >= 128) { wm = 2; wn = 2; }
-  else if (tiles64 >= 1024) { wm = 2; wn = 1; }
+  else if (tiles64 >= 1024 || (low_traffic && tiles64 >= 512)) { wm = 2; wn = 1; }
   else { wm = 1; wn = 1; }
 }
 
-int forward(const Tower* t, int count, int D, int P, hipStream_t st) {
+int forward(const Tower* t, int count, int D, int P, hipStream_t st, bool low_traffic) {
   ttg::Batch b1{}, b2{};
   b1.count = b2.count = count;
   b1.nsplit = b2.nsplit = 1;
@@ -47,7 +42,7 @@ int forward(const Tower* t, int count, int D, int P, hipStream_t st) {
     q.M = t[i].M; q.N = P; q.K = P; q.lda = P; q.ldb = P; q.ldc = P;
   }
   int wm, wn;
-  pick_tile(rows, P, wm, wn);
+  pick_tile(rows, P, wm, wn, low_traffic);
   int rc = ttg::launch(ttg::kNT, ttg::kBiasRelu, b1, wm, wn, st);
   if (rc != TT_OK) return rc;
   return ttg::launch(ttg::kNT, ttg::kBias, b2, wm, wn, st);
@@ -67,7 +62,7 @@ int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long 
   return ttg::launch(ttg::kTN, ttg::kStore, g2, 1, 1, st);
 }
 
-int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st) {
+int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, bool low_traffic) {
   ttg::Batch gh{};
   gh.count = count;
   gh.nsplit = 1;
@@ -80,7 +75,7 @@ int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st) {
     h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
   }
   int wm, wn;
-  pick_tile(rows, P, wm, wn);
+  pick_tile(rows, P, wm, wn, low_traffic);
   return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st);
 }
 

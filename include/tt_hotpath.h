@@ -278,6 +278,17 @@ int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumulate, tt_str
 int tt_engine_adam(tt_engine* e, const float* grads, double lr, double beta1, double beta2,
                    double eps, int64_t step, tt_stream_t stream);
 
+/*
+ * Phase C with the step counter on the device: every call advances it by one and derives the
+ * bias corrections there (in double, like torch does on the host), so the launch sequence has
+ * no step-dependent argument and can be captured once in a hipGraph and replayed.
+ * tt_engine_set_step sets the counter (0 = fresh optimizer) — e.g. after steps taken with
+ * tt_engine_adam, which does not touch it.
+ */
+int tt_engine_adam_auto(tt_engine* e, const float* grads, double lr, double beta1, double beta2,
+                        double eps, tt_stream_t stream);
+int tt_engine_set_step(tt_engine* e, int64_t step, tt_stream_t stream);
+
 /* A+B+C on one stream: one reference batch body.  */
 int tt_engine_train_step(tt_engine* e, const void* ids, int ids_dtype, const void* mask,
                          int mask_dtype, const int32_t* lens, int32_t B, int32_t S,

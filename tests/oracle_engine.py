@@ -30,7 +30,7 @@ class OracleEngine:
             out[name] = flat[off: off + n].view(shape)
         return out
 
-    def pool(self, slot, ids, mask=None, lens=None):
+    def pool(self, slot, ids, mask=None, lens=None, stream=None):
         S = ids.shape[2]
         if mask is None:
             if lens is None:
@@ -39,7 +39,7 @@ class OracleEngine:
                 mask = (torch.arange(S).view(1, 1, S) < lens.unsqueeze(-1)).long()
         self.pooled[slot] = [orc.gather_pool_normalize(self.table, ids[r].long(), mask[r].long()) for r in range(ids.shape[0])]
 
-    def pool_cached(self, slot, cache, rows):
+    def pool_cached(self, slot, cache, rows, stream=None):
         self.pooled[slot] = [cache[rows[r].long()] for r in range(rows.shape[0])]
 
     def fwd_bwd(self, slot, B, margin, grad_scale=None, loss_denominator=None, neg_index=None):

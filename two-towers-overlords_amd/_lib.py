@@ -68,6 +68,8 @@ SIGNATURES = {
     "tt_engine_fwd_bwd": (_i, [_vp, _i, _i32, _vp, _f, _f, _f, _vp]),
     "tt_engine_reduce_grads": (_i, [_vp, _vp, _i, _vp]),
     "tt_engine_adam": (_i, [_vp, _vp, _d, _d, _d, _d, _i64, _vp]),
+    "tt_engine_adam_auto": (_i, [_vp, _vp, _d, _d, _d, _d, _vp]),
+    "tt_engine_set_step": (_i, [_vp, _i64, _vp]),
     "tt_engine_train_step": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i32, _i32, _f, _d, _i64, _vp]),
     "tt_engine_pooled": (_vp, [_vp, _i]),
     "tt_engine_embeddings": (_vp, [_vp]),

@@ -13,6 +13,10 @@
 int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                  const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
                  int blocks_per_cu, hipStream_t st);
+int tt_launch_adam_auto(float* params, const float* grads, int nslabs, long long slab_stride, float* exp_avg,
+                        float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
+                        long long* dev_step, float* dev_scal, hipStream_t st);
+int tt_launch_set_step(long long* dev_step, long long value, hipStream_t st);
 int tt_launch_loss_mean(const float* hinge_rows, long long B, float denom, float* loss, double* acc_sum,
                         long long* acc_count, hipStream_t st);
 int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float margin, float grad_scale,
@@ -46,6 +50,8 @@ struct tt_engine {
   double* loss_sum;
   long long* loss_cnt;
   int32_t* oob;
+  long long* dev_step;  // optimizer steps taken, device copy (tt_engine_adam_auto)
+  float* dev_scal;      // {step_size, bc2_sqrt} of the current device step
   // second stream for the work that is off the critical path of a step (loss mean, dW2/db2)
   hipStream_t aux;
   hipEvent_t ev_fork, ev_join;
@@ -83,6 +89,8 @@ void carve(tt_engine* e, char* base, size_t* total) {
   e->loss_sum = c.take<double>(2);
   e->loss_cnt = c.take<long long>(2);
   e->oob = c.take<int32_t>(4);
+  e->dev_step = c.take<long long>(2);
+  e->dev_scal = c.take<float>(4);
   *total = c.off;
 }
 }  // namespace
@@ -273,6 +281,26 @@ extern "C" int tt_engine_adam(tt_engine* e, const float* grads, double lr, doubl
   if (grads) return tt_adam_f32(e->params, grads, 1, 0, e->exp_avg, e->exp_avg_sq, e->nparam, lr, beta1, beta2, eps, step, 1.f, stream);
   return tt_adam_f32(e->params, e->slabs, e->nslabs, e->slab_stride, e->exp_avg, e->exp_avg_sq, e->nparam, lr,
                      beta1, beta2, eps, step, 1.f, stream);
+}
+
+extern "C" int tt_engine_adam_auto(tt_engine* e, const float* grads, double lr, double beta1, double beta2,
+                                   double eps, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (grads) {
+    TT_REQUIRE(tt_aligned16(grads), TT_ERR_ALIGNMENT);
+    return tt_launch_adam_auto(e->params, grads, 1, 0, e->exp_avg, e->exp_avg_sq, e->nparam, lr, beta1, beta2, eps,
+                               e->dev_step, e->dev_scal, st);
+  }
+  return tt_launch_adam_auto(e->params, e->slabs, e->nslabs, e->slab_stride, e->exp_avg, e->exp_avg_sq, e->nparam,
+                             lr, beta1, beta2, eps, e->dev_step, e->dev_scal, st);
+}
+
+extern "C" int tt_engine_set_step(tt_engine* e, int64_t step, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(step >= 0, TT_ERR_BAD_SHAPE);
+  return tt_launch_set_step(e->dev_step, step, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tt_engine_train_step(tt_engine* e, const void* ids, int ids_dtype, const void* mask,

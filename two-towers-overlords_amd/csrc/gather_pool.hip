@@ -89,7 +89,9 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
   for (int c = 0; c < C; ++c) acc[c] = f4_zero();
   float wtot = 0.f;
 
-  for (int seg = 0; seg < S; seg += TT_WAVE) {
+  // with prefix lengths nothing lies beyond `len`: do not even scan the padding
+  const int send = (mask == nullptr && len < S) ? max(len, 0) : S;
+  for (int seg = 0; seg < send; seg += TT_WAVE) {
     const int tok = seg + lane;
     int id = 0;
     float w = 0.f;

@@ -143,14 +143,31 @@ __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g,
   p = __fadd_rn(p, __fmul_rn(-step_size, __fdiv_rn(m, denom)));                      // p.addcdiv_(m, denom, -step_size)
 }
 
+// Device-side step counter for graph replay: one thread bumps the step and derives the two
+// step-dependent scalars in double, like torch does on the host for a Python-float step.
+__global__ void adam_prep_kernel(long long* __restrict__ step, float* __restrict__ scal, double lr, double b1,
+                                 double b2) {
+  const long long s = *step + 1;
+  *step = s;
+  scal[0] = static_cast<float>(lr / (1.0 - pow(b1, static_cast<double>(s))));   // step_size
+  scal[1] = static_cast<float>(sqrt(1.0 - pow(b2, static_cast<double>(s))));    // bc2_sqrt
+}
+
+__global__ void set_step_kernel(long long* __restrict__ step, long long value) { *step = value; }
+
 __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         int nslabs, long long slab_stride,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         long long n, float one_minus_b1, float b2,
                                                         float one_minus_b2, float step_size,
-                                                        float bc2_sqrt, float eps, float grad_scale) {
+                                                        float bc2_sqrt, float eps, float grad_scale,
+                                                        const float* __restrict__ scal) {
   const long long i4 = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;
   if (i4 >= n) return;
+  if (scal) {  // step-dependent scalars produced on the device (adam_prep_kernel)
+    step_size = scal[0];
+    bc2_sqrt = scal[1];
+  }
   if (i4 + 3 < n) {
     float4 gs = *reinterpret_cast<const float4*>(g + i4);
     for (int z = 1; z < nslabs; ++z) {
@@ -257,7 +274,29 @@ extern "C" int tt_adam_f32(float* params, const float* grads, int nslabs, int64_
   const dim3 grid((unsigned)((nthreads + kThreads - 1) / kThreads)), block(kThreads);
   hipLaunchKernelGGL(adam_kernel, grid, block, 0, static_cast<hipStream_t>(stream), params, grads, nslabs,
                      (long long)slab_stride, exp_avg, exp_avg_sq, (long long)n, (float)(1.0 - beta1), (float)beta2,
-                     (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps, grad_scale);
+                     (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps, grad_scale,
+                     static_cast<const float*>(nullptr));
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
+// internal (engine.hip): Adam whose step lives on the device (graph-replayable)
+int tt_launch_adam_auto(float* params, const float* grads, int nslabs, long long slab_stride, float* exp_avg,
+                        float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
+                        long long* dev_step, float* dev_scal, hipStream_t st) {
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, st, dev_step, dev_scal, lr, beta1, beta2);
+  TT_CHECK_LAUNCH();
+  const long long nthreads = (n + 3) / 4;
+  const dim3 grid((unsigned)((nthreads + kThreads - 1) / kThreads)), block(kThreads);
+  hipLaunchKernelGGL(adam_kernel, grid, block, 0, st, params, grads, nslabs, slab_stride, exp_avg, exp_avg_sq, n,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, 1.f, (float)eps, 1.f,
+                     static_cast<const float*>(dev_scal));
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
+int tt_launch_set_step(long long* dev_step, long long value, hipStream_t st) {
+  hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, dev_step, value);
   TT_CHECK_LAUNCH();
   return TT_OK;
 }

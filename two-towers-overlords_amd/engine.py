@@ -100,19 +100,21 @@ class HotPathEngine:
         return (ids.data_ptr(), _INT_WIDTH[ids.dtype], None if mask is None else mask.data_ptr(), mw,
                 None if lens is None else lens.data_ptr(), R, B, S)
 
-    def pool(self, slot: int, ids, mask=None, lens=None) -> None:
-        """K1 over ids [roles, B, S] (roles = 3: q, pos, neg; 2: q, pos with in-batch negatives by index)."""
+    def pool(self, slot: int, ids, mask=None, lens=None, stream: Optional[int] = None) -> None:
+        """K1 over ids [roles, B, S] (roles = 3: q, pos, neg; 2: q, pos with in-batch negatives by index).
+        `stream`: raw hipStream_t to launch on (default: torch's current stream)."""
         a = self._ids_args(ids, mask, lens)
-        call("tt_engine_pool", self._h, slot, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], self._stream())
+        call("tt_engine_pool", self._h, slot, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7],
+             self._stream() if stream is None else stream)
 
-    def pool_cached(self, slot: int, cache: torch.Tensor, rows: torch.Tensor) -> None:
+    def pool_cached(self, slot: int, cache: torch.Tensor, rows: torch.Tensor, stream: Optional[int] = None) -> None:
         """Phase A from a frozen-feature cache: pooled[slot] = cache[rows], rows [roles, B]."""
         _req(cache, "cache", torch.float32, 2)
         _req(rows, "rows", ndim=2)
         if cache.shape[1] != self.D or rows.dtype not in _INT_WIDTH or rows.shape[0] not in (2, 3):
             raise ValueError("pool_cached: cache must be [N, D] float32 and rows an int [roles, B] tensor")
         call("tt_engine_pool_cached", self._h, slot, cache.data_ptr(), cache.shape[0], rows.data_ptr(),
-             _INT_WIDTH[rows.dtype], rows.shape[0], rows.shape[1], self._stream())
+             _INT_WIDTH[rows.dtype], rows.shape[0], rows.shape[1], self._stream() if stream is None else stream)
 
     def fwd_bwd(self, slot: int, B: int, margin: float, grad_scale: Optional[float] = None,
                 loss_denominator: Optional[float] = None, neg_index: Optional[torch.Tensor] = None) -> None:
@@ -137,6 +139,17 @@ class HotPathEngine:
             _req(grads, "grads", torch.float32, 1)
             g = grads.data_ptr()
         call("tt_engine_adam", self._h, g, lr, beta1, beta2, eps, step, self._stream())
+
+    def adam_auto(self, lr: float, grads: Optional[torch.Tensor] = None, beta1=0.9, beta2=0.999, eps=1e-8) -> None:
+        """Adam with the step counter on the device (graph-replayable); see `set_step`."""
+        g = None
+        if grads is not None:
+            _req(grads, "grads", torch.float32, 1)
+            g = grads.data_ptr()
+        call("tt_engine_adam_auto", self._h, g, lr, beta1, beta2, eps, self._stream())
+
+    def set_step(self, step: int) -> None:
+        call("tt_engine_set_step", self._h, int(step), self._stream())
 
     def train_step(self, ids, mask=None, lens=None, *, margin: float, lr: float, step: int) -> None:
         a = self._ids_args(ids, mask, lens)

@@ -179,7 +179,7 @@ class TripletTrainer:
                  params: Optional[dict] = None, max_batch: int, max_seq_len: int, margin: float = 0.3,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
                  process_group=None, engine=None, overlap_streams: Optional[bool] = None,
-                 k1_blocks_per_cu: Optional[int] = None):
+                 k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None):
         if model is not None:
             if model.query_tower.encoder_mode != "embed":
                 raise ValueError("the fused engine implements the `embed` encoder mode; use train_epoch for `bert`")
@@ -223,12 +223,30 @@ class TripletTrainer:
         self.side = torch.cuda.Stream(self.device) if (overlap_streams and self.device.type == "cuda") else None
         self._pending = collections.deque()   # gathered, not yet applied: (slot, ready event, local B)
         self._next_slot = 0
-        self._slot_free = {}                  # slot -> event after the fwd_bwd that last read it
+        self._slot_free = [None] * self.SLOTS  # slot -> event after the fwd_bwd that last read it
+        if self.side is not None:             # events are reused: one "ready" and one "done" per slot
+            self._slot_ready = [torch.cuda.Event() for _ in range(self.SLOTS)]
+            self._slot_done = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
         self.k1_event_every = 4               # ... of every 4th launch
         self._k1_count = 0
         self.feature_cache = None             # [N_texts, D] pooled-normalised vectors (build_feature_cache)
         self.table = table
+        # hipGraph replay of whole steps (single replica, no accumulation): one graph launch per
+        # step instead of ~12 kernel launches + 4 event operations, i.e. ~4x less host time per
+        # step, which is what keeps a busy host from starving the GPU.
+        if use_graphs is None:
+            use_graphs = self.side is not None and self.world == 1 and self.accumulation_steps == 1 and engine is None
+        self.use_graphs = bool(use_graphs) and self.side is not None and self.world == 1 and self.accumulation_steps == 1
+        self.eager_every = None               # if set (bench), every n-th step is run eagerly (for K1 event timing)
+        self._graphs = {}
+        self._ring_ids = self._ring_lens = None
+        self._ring_fill = [None] * self.SLOTS
+        self._steps_done = 0
+        self._main_dirty = False              # a graph ran on the main stream since the last side-stream fence
+        self._auto_step = self.bucket is None and hasattr(self.engine, "adam_auto")
+        if self._auto_step:
+            self.engine.set_step(0)
 
     # -- helpers ---------------------------------------------------------------
     def named_parameters(self) -> dict:
@@ -248,34 +266,39 @@ class TripletTrainer:
         if batch.neg_index is not None and self.world > 1:
             batch = batch.expand_negatives()  # an in-batch index does not survive sharding across ranks
         if self.side is None:
-            self._timed_pool(slot, batch)
+            self._timed_pool(slot, batch, None)
             self._pending.append((slot, None, batch.size, batch.neg_index))
             return
-        free = self._slot_free.get(slot)
+        if self._main_dirty:  # graph replays are ordered by the main stream only: fence once
+            self.side.wait_stream(torch.cuda.current_stream(self.device))
+            self._main_dirty = False
+            self._slot_free = [None] * self.SLOTS
+        free = self._slot_free[slot]
         if free is not None:
             self.side.wait_event(free)  # the fwd_bwd that last read this slot (on the main stream)
-        with torch.cuda.stream(self.side):
-            self._timed_pool(slot, batch)
-            ev = torch.cuda.Event()
-            ev.record(self.side)
+        # launch on the side stream by handle (no stream context switch on the host)
+        self._timed_pool(slot, batch, self.side)
+        ev = self._slot_ready[slot]
+        ev.record(self.side)
         self._pending.append((slot, ev, batch.size, batch.neg_index))
 
-    def _timed_pool(self, slot, batch: TripletBatch) -> None:
+    def _timed_pool(self, slot, batch: TripletBatch, stream) -> None:
         timed = False
         if self.k1_events is not None:
             self._k1_count += 1
             timed = self._k1_count % self.k1_event_every == 0  # events cost ~5 us of stream time each
+        raw = None if stream is None else stream.cuda_stream
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0.record(stream)
         if batch.cache_rows is not None:
             if self.feature_cache is None:
                 raise RuntimeError("batch carries cache_rows but build_feature_cache() has not been called")
-            self.engine.pool_cached(slot, self.feature_cache, batch.cache_rows)
+            self.engine.pool_cached(slot, self.feature_cache, batch.cache_rows, stream=raw)
         else:
-            self.engine.pool(slot, batch.ids, batch.mask, batch.lens)
+            self.engine.pool(slot, batch.ids, batch.mask, batch.lens, stream=raw)
         if timed:
-            e1.record()
+            e1.record(stream)
             self.k1_events.append((e0, e1))
 
     @torch.no_grad()
@@ -301,21 +324,26 @@ class TripletTrainer:
         slot, ev, local_B, neg_index = self._pending.popleft()
         global_B = global_B or local_B * self.world
         k = self.accumulation_steps
+        self._steps_done += 1
         if self.side is not None:
             if issue_next is not None:
                 issue_next()
                 issue_next = None
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
         self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B), neg_index=neg_index)
         if self.side is not None:
-            done = torch.cuda.Event()
+            done = self._slot_done[slot]
             done.record()
             self._slot_free[slot] = done
         self._micro += 1
         do_step = self._micro % k == 0
         if self.bucket is None:  # single replica, no accumulation: Adam folds the slab sum
             self.step_count += 1
-            self.engine.adam(self.step_count, self.lr, None, self.betas[0], self.betas[1], self.eps)
+            if self._auto_step:  # step counter on the device: the same call sequence is graph-replayable
+                self.engine.adam_auto(self.lr, None, self.betas[0], self.betas[1], self.eps)
+            else:
+                self.engine.adam(self.step_count, self.lr, None, self.betas[0], self.betas[1], self.eps)
             if issue_next is not None:
                 issue_next()
             return
@@ -331,6 +359,86 @@ class TripletTrainer:
             self.step_count += 1
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
 
+    # -- hipGraph replay ---------------------------------------------------------------
+    def _graphable(self, entry, nxt: Optional[TripletBatch]) -> bool:
+        if not self.use_graphs:
+            return False
+        if self.eager_every and self._steps_done % self.eager_every == self.eager_every - 1:
+            return False
+        _, _, B, neg_index = entry
+        if neg_index is not None or B != self.engine.max_B:
+            return False
+        if nxt is None:
+            return True
+        return (nxt.ids is not None and nxt.ids.shape[0] == 3 and nxt.ids.shape[1] == B
+                and nxt.ids.shape[2] <= self.engine.max_S and nxt.mask is None and nxt.neg_index is None
+                and nxt.cache_rows is None)
+
+    def _ring_load(self, slot: int, nxt: TripletBatch) -> None:
+        """Stage a batch's ids in the fixed ring buffer the captured K1 launch reads (main stream)."""
+        if self._ring_ids is None:
+            B, S = self.engine.max_B, self.engine.max_S
+            self._ring_ids = torch.zeros((self.SLOTS, 3, B, S), dtype=torch.int32, device=self.device)
+            self._ring_lens = torch.zeros((self.SLOTS, 3, B), dtype=torch.int32, device=self.device)
+        S = nxt.ids.shape[2]
+        if nxt.ids.data_ptr() != self._ring_ids[slot].data_ptr():  # a caller may fill the ring slot itself
+            self._ring_ids[slot][:, :, :S].copy_(nxt.ids)
+        if nxt.lens is not None:
+            self._ring_lens[slot].copy_(nxt.lens)
+            self._ring_fill[slot] = None
+        elif self._ring_fill[slot] != S:
+            self._ring_lens[slot].fill_(S)
+            self._ring_fill[slot] = S
+
+    def _graph(self, slot_fb: int, slot_k1: Optional[int]):
+        key = (slot_fb, slot_k1)
+        g = self._graphs.get(key)
+        if g is not None:
+            return g
+        B = self.engine.max_B
+        if self._ring_ids is None and slot_k1 is not None:
+            raise RuntimeError("ring not initialised")
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream(self.device)
+        with torch.cuda.graph(g, stream=cap):
+            if slot_k1 is not None:  # branch: the gather of the batch two steps ahead
+                self.side.wait_stream(cap)
+                self.engine.pool(slot_k1, self._ring_ids[slot_k1], None, self._ring_lens[slot_k1],
+                                 stream=self.side.cuda_stream)
+            self.engine.fwd_bwd(slot_fb, B, self.margin, 1.0 / B, float(B))
+            self.engine.adam_auto(self.lr, None, self.betas[0], self.betas[1], self.eps)
+            if slot_k1 is not None:
+                cap.wait_stream(self.side)
+        self._graphs[key] = g
+        return g
+
+    def advance(self, nxt: Optional[Batch] = None, global_B: Optional[int] = None) -> None:
+        """One step of the pipeline: weight-dependent part of the oldest gathered batch, and the
+        gather of `nxt` (the batch that enters the pipeline now, if any) — as one hipGraph replay
+        when both are eligible, else eagerly (`apply` + `gather`)."""
+        nxt = None if nxt is None else as_batch(nxt)
+        entry = self._pending[0]
+        if not self._graphable(entry, nxt):
+            self.apply(global_B, issue_next=(lambda: self.gather(nxt)) if nxt is not None else None)
+            return
+        slot_fb, ev, B, _ = self._pending.popleft()
+        slot_k1 = None
+        if nxt is not None:
+            slot_k1 = self._next_slot
+            self._next_slot = (slot_k1 + 1) % self.SLOTS
+            self._ring_load(slot_k1, nxt)
+        g = self._graph(slot_fb, slot_k1)
+        if ev is not None:  # pooled by an eager K1 on the side stream
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        g.replay()
+        self._main_dirty = True
+        self._steps_done += 1
+        self._micro += 1
+        self.step_count += 1
+        if slot_k1 is not None:
+            self._pending.append((slot_k1, None, B, None))
+
     # -- public ------------------------------------------------------------------
     def train_step(self, batch: Batch, global_batch: Optional[int] = None) -> None:
         """One batch (this rank's shard).  No host synchronisation."""
@@ -342,24 +450,17 @@ class TripletTrainer:
         like backend/training.py:63.  One host sync at the end."""
         it = iter(batches)
         depth = self.SLOTS - 1 if self.side is not None else 1
-        state = {"done": False}
-
-        def feed():
-            while not state["done"] and len(self._pending) < depth:
-                b = next(it, None)
-                if b is None:
-                    state["done"] = True
-                else:
-                    self.gather(b)
-
-        feed()
+        while len(self._pending) < depth:  # prime the pipeline
+            b = next(it, None)
+            if b is None:
+                break
+            self.gather(b)
         if not self._pending:
             return float("nan")
         i = 0
         while self._pending:
             gB = global_batch_sizes[i] if global_batch_sizes is not None else None
-            self.apply(gB, issue_next=feed)
-            feed()
+            self.advance(next(it, None), gB)
             i += 1
         return self.epoch_loss()
 

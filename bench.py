@@ -99,7 +99,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the gather of batch i+1 after (not under) the projection kernels of batch i")
     ap.add_argument("--k1-blocks-per-cu", type=int, default=None)
-    ap.add_argument("--no-graphs", action="store_true", help="launch every step kernel by kernel (no hipGraph replay)")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay each step as one hipGraph (opt-in: slower on ROCm 7.2, see DESIGN.md)")
     ap.add_argument("--inputs", default="ids3", choices=["ids3", "index", "cache"],
                     help="ids3 (headline): three token-id gathers per triplet batch, the reference's three encodes. "
                          "index: negatives as in-batch indices of the positives (2 gathers). cache: rows of a "
@@ -150,7 +151,7 @@ def main():
         params[name] = ((torch.rand(*shape, generator=gp) * 2 - 1) * bound).to(device)
     trainer = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
                              overlap_streams=(False if (args.no_overlap or args.k1_only) else None),
-                             k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=(False if args.no_graphs else None))
+                             k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs))
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1

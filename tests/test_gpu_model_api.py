@@ -199,7 +199,7 @@ def test_graph_replay_equals_eager_and_oracle():
     for mode, kw in (("eager", dict(use_graphs=False)), ("graph", dict(use_graphs=True)), ("mixed", dict(use_graphs=True))):
         tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B,
                             max_seq_len=S, margin=0.3, lr=1e-3, **kw)
-        assert tr.use_graphs == (mode != "eager")
+        assert tr.use_graphs == (mode != "eager")  # opt-in
         if mode == "mixed":
             tr.eager_every = 3
         avg = tr.train_epoch(dev_batches(use_mask_at=6 if mode == "mixed" else None))

@@ -232,11 +232,10 @@ class TripletTrainer:
         self._k1_count = 0
         self.feature_cache = None             # [N_texts, D] pooled-normalised vectors (build_feature_cache)
         self.table = table
-        # hipGraph replay of whole steps (single replica, no accumulation): one graph launch per
-        # step instead of ~12 kernel launches + 4 event operations, i.e. ~4x less host time per
-        # step, which is what keeps a busy host from starving the GPU.
-        if use_graphs is None:
-            use_graphs = self.side is not None and self.world == 1 and self.accumulation_steps == 1 and engine is None
+        # hipGraph replay of whole steps (single replica, no accumulation; opt-in).  Measured on
+        # ROCm 7.2 / MI355X it does NOT pay: replaying the 3-stream, ~15-node step graph costs the
+        # host ~280 us per replay (vs ~70 us for the same launches issued one by one), so the
+        # step becomes host-bound (289 vs 233 us).  Kept for runtimes whose graph launch is O(1).
         self.use_graphs = bool(use_graphs) and self.side is not None and self.world == 1 and self.accumulation_steps == 1
         self.eager_every = None               # if set (bench), every n-th step is run eagerly (for K1 event timing)
         self._graphs = {}
@@ -244,7 +243,9 @@ class TripletTrainer:
         self._ring_fill = [None] * self.SLOTS
         self._steps_done = 0
         self._main_dirty = False              # a graph ran on the main stream since the last side-stream fence
-        self._auto_step = self.bucket is None and hasattr(self.engine, "adam_auto")
+        # device-side Adam step counter only where replay needs it: its one-thread prep kernel
+        # (two double pow) sits on the critical chain and costs ~20 us per step
+        self._auto_step = self.use_graphs and self.bucket is None and hasattr(self.engine, "adam_auto")
         if self._auto_step:
             self.engine.set_step(0)
 

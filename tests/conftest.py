@@ -42,10 +42,12 @@ def assert_params_close(actual, desired, lr, nsteps, tight=1e-6, frac_loose=0.00
     for elements whose gradient is at rounding-noise level (|g| ~ 1e-8: a 1e-10
     reassociation difference moves the update by ~1 % of lr), so the check is
     two-tier: all but max(3, 0.2 %) of the elements agree to `tight`, and every
-    element agrees to 5 % of the total distance Adam can move it (lr * nsteps)."""
+    element agrees to 10 % of the total distance Adam can move it (lr * nsteps):
+    at |g| ~ eps = 1e-8 the first update is lr*g/(|g|+eps), so a 2e-9 difference
+    in g already moves it by 5 % of lr."""
     a = np.asarray(actual, dtype=np.float64).ravel()
     d = np.asarray(desired, dtype=np.float64).ravel()
     err = np.abs(a - d)
-    assert err.max() <= 0.05 * lr * nsteps + tight, f"max err {err.max():.3e}"
+    assert err.max() <= 0.10 * lr * nsteps + tight, f"max err {err.max():.3e}"
     n_loose = int((err > tight).sum())
     assert n_loose <= max(3, frac_loose * err.size), f"{n_loose} of {err.size} elements beyond {tight}"

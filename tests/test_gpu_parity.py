@@ -360,3 +360,84 @@ def test_feature_cache_is_bitwise_the_gather(tt):
         out[mode] = (avg, tr.flat.clone())
     assert out["ids"][0] == out["cache"][0]
     assert torch.equal(out["ids"][1], out["cache"][1])
+
+
+# --------------------------------------------------------------------------- engine on awkward shapes
+@pytest.mark.parametrize("V,D,P,B,S,idt,use_mask", [
+    (50, 100, 37, 1, 1, torch.int64, True),      # one triplet, one token, nothing divisible by anything
+    (300, 8, 4, 3, 512, torch.int32, False),     # max_length-long rows (model.py:44 truncates at 512)
+    (1000, 384, 128, 65, 33, torch.int64, True), # B, S straddle tile/wave boundaries; holey int64 masks
+    (200, 6, 5, 9, 7, torch.int32, True),        # D % 4 != 0 -> generic gather kernel, scalar GEMM path
+    (4000, 768, 512, 130, 20, torch.int32, False),
+])
+def test_engine_awkward_shapes_vs_oracle(tt, V, D, P, B, S, idt, use_mask):
+    _, engine = tt
+    gen = torch.Generator().manual_seed(V + D + P + B + S)
+    table = torch.randn(V, D, generator=gen)
+    params = orc.init_params(D, P, seed=B)
+    ids = torch.randint(0, V, (3, B, S), generator=gen)
+    if use_mask:
+        mask = (torch.rand(3, B, S, generator=gen) < 0.7).long()
+        mask[:, :, 0] = 1
+        if B > 2:
+            mask[1, 2] = 0  # an all-padding positive: zero pooled vector -> projection of zeros
+    else:
+        lens = torch.randint(1, S + 1, (3, B), generator=gen)
+        mask = (torch.arange(S).view(1, 1, S) < lens.unsqueeze(-1)).long()
+    batch = tuple((ids[r], mask[r]) for r in range(3))
+    loss, grads, embs = orc.loss_and_grads(table, batch, params, 0.25)
+    eng = engine.HotPathEngine(table.cuda(), P, B, S)
+    flat = _flat(params).cuda()
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    eng.bind(flat, m, v)
+    if use_mask:
+        eng.pool(0, ids.to(idt).cuda(), mask.to(idt).cuda())
+    else:
+        eng.pool(0, ids.to(idt).cuda(), lens=lens.int().cuda())
+    eng.fwd_bwd(0, B, 0.25)
+    for r in range(3):
+        close(eng.embeddings(B)[r], embs[r])
+    g = torch.empty_like(flat)
+    eng.reduce_grads(g)
+    hinge = (orc.cosine_distance(embs[0], embs[1]) - orc.cosine_distance(embs[0], embs[2]) + 0.25).abs()
+    if float(hinge.min()) > 1e-5:  # no triplet sits on the hinge's kink
+        close(g, _flat(grads), rel_to_max=True)
+    _, _, last = eng.read_stats()
+    assert abs(last - loss.item()) <= TOL
+    eng.adam(1, 1e-3)
+    st = orc.AdamState(lr=1e-3)
+    orc.adam_step(params, grads, st)
+    if float(hinge.min()) > 1e-5:
+        for k, pt in _unflat(flat, D, P).items():
+            assert_params_close(pt.cpu().numpy(), params[k].numpy(), 1e-3, 1)
+    eng.close()
+
+
+def test_engine_rejects_bad_arguments(tt):
+    _, engine = tt
+    from two_towers_overlords_amd import TTError
+
+    table = torch.randn(100, 16).cuda()
+    eng = engine.HotPathEngine(table, 8, 4, 6)
+    flat = torch.zeros(eng.n_params).cuda()
+    eng.bind(flat, flat.clone(), flat.clone())
+    ids = torch.zeros(3, 4, 6, dtype=torch.int32).cuda()
+    with pytest.raises(TTError):
+        eng.pool(3, ids)                       # slot out of range
+    with pytest.raises(TTError):
+        eng.pool(0, torch.zeros(3, 5, 6, dtype=torch.int32).cuda())  # B > max_B
+    with pytest.raises(TTError):
+        eng.pool(0, torch.zeros(3, 4, 7, dtype=torch.int32).cuda())  # S > max_S
+    with pytest.raises(ValueError):
+        eng.pool(0, ids.float())               # not an integer tensor
+    with pytest.raises(ValueError):
+        eng.pool(0, ids.cpu())                 # wrong device
+    with pytest.raises(ValueError):
+        eng.bind(flat[:-1], flat, flat)
+    eng.pool(0, ids)
+    eng.fwd_bwd(0, 4, 0.3)
+    bad = torch.full((3, 4, 6), 100, dtype=torch.int32).cuda()        # id == V: clamped + flagged
+    eng.pool(1, bad)
+    with pytest.raises(TTError):
+        eng.read_stats()
+    eng.close()

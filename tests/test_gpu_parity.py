@@ -430,7 +430,7 @@ def test_engine_rejects_bad_arguments(tt):
         eng.pool(0, torch.zeros(3, 4, 7, dtype=torch.int32).cuda())  # S > max_S
     with pytest.raises(ValueError):
         eng.pool(0, ids.float())               # not an integer tensor
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         eng.pool(0, ids.cpu())                 # wrong device
     with pytest.raises(ValueError):
         eng.bind(flat[:-1], flat, flat)

@@ -175,6 +175,32 @@ int tt_reduce_slabs_f32(const float* slabs, int nslabs, int64_t slab_stride, flo
                         int64_t n, int accumulate, tt_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
+/* Evaluation — the arithmetic of evaluate_model on the device */
+/* ------------------------------------------------------------------------- */
+
+size_t tt_cosine_scores_workspace_bytes(int64_t Q, int64_t N, int P);
+/*
+ * out[i,j] = cosine_similarity(q[i,:], d[j,:]) (eps 1e-8: rows are divided by max(|x|, eps),
+ * then dotted) for every (query, document) pair: two row-normalisation launches and one
+ * exact-fp32 MFMA GEMM.  Replaces, for all queries at once,
+ *   torch.cosine_similarity(query_embed.cpu(), doc_embeds.cpu(), dim=1)   (backend/training.py:297-299)
+ *   q [Q,P], d [N,P], out [Q,N]; workspace: tt_cosine_scores_workspace_bytes(), 16-byte aligned.
+ */
+int tt_cosine_scores_f32(const float* q, const float* d, float* out, int64_t Q, int64_t N, int P,
+                         void* workspace, size_t workspace_bytes, tt_stream_t stream);
+
+/*
+ * out[i, t] = sklearn.metrics.ndcg_score(gains[i:i+1], scores[i:i+1], k=ks[t]) (ignore_ties=False:
+ * tied scores share the average gain of their tie group) — backend/training.py:301-311.
+ *   scores, gains [Q,N] f32 (gains = true relevance, >= 0); valid [Q,N] u8 or NULL restricts
+ *   row i to its candidate pool; ks_host: nk <= 8 cut-offs (host array); ks_device: int32[nk]
+ *   device scratch; out [Q,nk].  A row without any positive gain scores 0, as in sklearn.
+ */
+int tt_ndcg_at_k_f32(const float* scores, const float* gains, const uint8_t* valid, int64_t Q,
+                     int64_t N, const int32_t* ks_host, int nk, int32_t* ks_device, float* out,
+                     tt_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
 /* Engine — the whole train_epoch batch body as one host call                  */
 /* ------------------------------------------------------------------------- */
 

@@ -373,3 +373,32 @@ def synthetic_batch(B: int, S: int, V: int, seed: int, ragged: bool = False, dty
         mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).to(torch.int64)
         out.append(((ids * mask).to(dtype), mask))
     return tuple(out)
+
+
+# --------------------------------------------------------------------------- #
+# Evaluation arithmetic (backend/training.py:281-311)
+# --------------------------------------------------------------------------- #
+
+
+def cosine_scores(q: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    """Row i = torch.cosine_similarity(q[i:i+1], d, dim=1) — backend/training.py:297-299 for every query."""
+    return torch.stack([F.cosine_similarity(q[i: i + 1], d, dim=1) for i in range(q.shape[0])])
+
+
+def ndcg_rows(scores, gains, k: int, valid=None):
+    """sklearn.metrics.ndcg_score(true_relevance.reshape(1,-1), similarities.reshape(1,-1), k=k) per row
+    (backend/training.py:301-311); `valid` restricts a row to its candidate pool.  sklearn is the
+    third-party implementation the reference calls (scikit-learn, pinned in backend/uv.lock)."""
+    import numpy as np
+    from sklearn.metrics import ndcg_score
+
+    scores, gains = np.asarray(scores, dtype=np.float64), np.asarray(gains, dtype=np.float64)
+    out = []
+    for i in range(scores.shape[0]):
+        sel = slice(None) if valid is None else np.asarray(valid[i]).astype(bool)
+        s, g = scores[i][sel], gains[i][sel]
+        if len(s) < 2:  # sklearn refuses a single document; the score is 1 if it is relevant else 0
+            out.append(float(g.sum() > 0))
+            continue
+        out.append(float(ndcg_score(g.reshape(1, -1), s.reshape(1, -1), k=k)))
+    return np.array(out)

@@ -311,6 +311,86 @@ def g_triplets():
     print("triplets.npz written")
 
 
+class _IntTokenizer:
+    """Deterministic stand-in for the WordPiece tokenizer: a text is a space-separated list of
+    token ids; `padding=True` pads to the longest text of the call with 0 / mask 0."""
+
+    def __call__(self, texts, **kw):
+        rows = [[int(w) for w in t.split()] for t in texts]
+        S = max(len(r) for r in rows)
+        ids = torch.zeros(len(rows), S, dtype=torch.int64)
+        mask = torch.zeros(len(rows), S, dtype=torch.int64)
+        for i, r in enumerate(rows):
+            ids[i, : len(r)] = torch.tensor(r)
+            mask[i, : len(r)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+class _EvalDataset:
+    """map-style {"query_id","query","positive"} + get_unique_passages(), like MSMarcoDataset."""
+
+    def __init__(self, items):
+        self.items = items
+        self.docs = list(dict.fromkeys(it["positive"] for it in items))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+    def get_unique_passages(self):
+        return self.docs
+
+
+def g_eval():
+    """`evaluate_model` (training.py:136-380) of the reference itself, CPU, on a synthetic corpus:
+    NDCG@{1,5,10} for the all-documents mode (candidate_pool_size=-1) and the per-query pool mode
+    (pool larger than the irrelevant set, so no hash-order-dependent sampling is involved)."""
+    rng = random.Random(77)
+    V, D, P = 400, 48, 32
+    table = orc.synthetic_table(V, D, seed=41) * 50.0
+    params = orc.init_params(D, P, seed=42)
+    n_queries, items = 40, []
+    for qid in range(n_queries):
+        q_tokens = [rng.randrange(1, V) for _ in range(rng.randint(3, 8))]
+        query = " ".join(map(str, q_tokens))
+        for _ in range(rng.randint(1, 6)):
+            # a relevant passage shares some tokens with its query
+            doc = [rng.choice(q_tokens) if rng.random() < 0.5 else rng.randrange(1, V) for _ in range(rng.randint(5, 30))]
+            items.append({"query_id": 1000 + qid, "query": query, "positive": " ".join(map(str, doc))})
+    items.append(dict(items[3]))  # an exact duplicate pair -> tied scores in the all-documents mode
+    items[-1]["query_id"], items[-1]["query"] = items[20]["query_id"], items[20]["query"]
+    ds = _EvalDataset(items)
+    model = build_ref_model(table, params, _IntTokenizer())
+    out = {
+        "table": np_(table),
+        "items_query_id": np.array([it["query_id"] for it in items], dtype=np.int64),
+        "items_query": np.array([it["query"] for it in items]),
+        "items_positive": np.array([it["positive"] for it in items]),
+    }
+    for k, v in params.items():
+        out["init/" + k] = np_(v)
+    cases = [  # (seed, sample_size, min_query_groups, candidate_pool_size)
+        (5, 60, 12, -1),
+        (6, 80, 15, 10_000),
+        (7, 30, 40, -1),  # asks for more query groups than one sample holds -> the multiplier loop runs
+    ]
+    out["cases"] = np.array(cases, dtype=np.int64)
+    for c, (seed, ss, mq, pool) in enumerate(cases):
+        random.seed(seed)
+        res = ref_training.evaluate_model(model, ds, sample_size=ss, min_query_groups=mq, candidate_pool_size=pool,
+                                          comprehensive=True, log_wandb=False, wandb_prefix="t_", batch_size=64)
+        for k, v in res.items():
+            out[f"case{c}/{k}"] = np.float64(v)
+        random.seed(seed)
+        out[f"case{c}/simple_ndcg10"] = np.float64(
+            ref_training.evaluate_model(model, ds, sample_size=ss, min_query_groups=mq, candidate_pool_size=pool,
+                                        comprehensive=False, batch_size=64))
+        print(f"eval case {c}: ndcg@10 {res['t_ndcg_10']:.6f} ndcg@1 {res['t_ndcg_1']:.6f} queries {res['t_queries_evaluated']}")
+    np.savez_compressed(os.path.join(HERE, "eval.npz"), **out)
+
+
 if __name__ == "__main__":
     r = g_kat0()
     g_step_mid()
@@ -319,6 +399,7 @@ if __name__ == "__main__":
     g_loss_edges()
     g_bert_mode()
     g_triplets()
+    g_eval()
     with open(os.path.join(HERE, "VERSIONS.txt"), "w") as f:
         import transformers
 

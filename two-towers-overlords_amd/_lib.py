@@ -57,6 +57,9 @@ SIGNATURES = {
     "tt_triplet_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _f, _f, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_adam_f32": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i64, _d, _d, _d, _d, _i64, _f, _vp]),
     "tt_reduce_slabs_f32": (_i, [_vp, _i, _i64, _vp, _i64, _i, _vp]),
+    "tt_cosine_scores_workspace_bytes": (_sz, [_i64, _i64, _i]),
+    "tt_cosine_scores_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
+    "tt_ndcg_at_k_f32": (_i, [_vp, _vp, _vp, _i64, _i64, C.POINTER(_i32), _i, _vp, _vp, _vp]),
     "tt_engine_workspace_bytes": (_sz, [C.POINTER(TTEngineConfig)]),
     "tt_engine_create": (_i, [C.POINTER(TTEngineConfig), _vp, _sz, _vp, C.POINTER(_vp)]),
     "tt_engine_destroy": (_i, [_vp]),

@@ -211,3 +211,50 @@ def adam_step_flat(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, bet
     with torch.cuda.device(params.device):
         call("tt_adam_f32", params.data_ptr(), grads.data_ptr(), 1, 0, exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
              lr, beta1, beta2, eps, step, grad_scale, _stream())
+
+
+def cosine_scores(q: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    """out[i, j] = cosine_similarity(q[i], d[j]) for all pairs -> [Q, N] (MFMA GEMM on unit rows).
+    Replaces the per-query `torch.cosine_similarity(query_embed.cpu(), doc_embeds.cpu(), dim=1)`
+    of backend/training.py:297-299."""
+    _req(q, "q", torch.float32, 2)
+    _req(d, "d", torch.float32, 2)
+    Q, P = q.shape
+    N = d.shape[0]
+    if d.shape[1] != P or d.device != q.device:
+        raise ValueError("cosine_scores: q [Q,P] and d [N,P] must share P and the device")
+    out = torch.empty((Q, N), dtype=torch.float32, device=q.device)
+    nbytes = _lib.load().tt_cosine_scores_workspace_bytes(Q, N, P)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        call("tt_cosine_scores_f32", q.data_ptr(), d.data_ptr(), out.data_ptr(), Q, N, P, ws.data_ptr(), nbytes, _stream())
+    return out
+
+
+def ndcg_at_k(scores: torch.Tensor, relevance: torch.Tensor, ks=(10,), valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[Q, len(ks)] NDCG@k per query row with sklearn.metrics.ndcg_score semantics (tie-averaged
+    DCG, ideal DCG from the sorted gains) — backend/training.py:301-311.  `valid` (bool/uint8 [Q,N])
+    restricts each row to its candidate pool."""
+    import ctypes as C
+
+    _req(scores, "scores", torch.float32, 2)
+    Q, N = scores.shape
+    gains = relevance.to(torch.float32).contiguous()
+    if tuple(gains.shape) != (Q, N) or gains.device != scores.device:
+        raise ValueError("ndcg_at_k: relevance must be [Q, N] on the scores' device")
+    vm = None
+    if valid is not None:
+        vm = valid.to(torch.uint8).contiguous()
+        if tuple(vm.shape) != (Q, N) or vm.device != scores.device:
+            raise ValueError("ndcg_at_k: valid must be [Q, N] on the scores' device")
+    ks = [int(k) for k in ks]
+    if not 1 <= len(ks) <= 8 or min(ks) < 1:
+        raise ValueError("ndcg_at_k: 1..8 cut-offs, each >= 1")
+    out = torch.empty((Q, len(ks)), dtype=torch.float32, device=scores.device)
+    ks_dev = torch.empty(len(ks), dtype=torch.int32, device=scores.device)
+    ks_host = (C.c_int32 * len(ks))(*ks)
+    with torch.cuda.device(scores.device):
+        call("tt_ndcg_at_k_f32", scores.data_ptr(), gains.data_ptr(), _ptr(vm), Q, N, ks_host, len(ks), ks_dev.data_ptr(),
+             out.data_ptr(), _stream())
+        torch.cuda.current_stream().synchronize()  # ks_host must outlive the async H2D copy
+    return out

@@ -57,5 +57,33 @@ def main():
     print(f"triplet B={M // 3} P={P}: {t:8.1f} us")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--eval" not in sys.argv:
     main()
+
+
+def eval_bench():
+    """f2: Q queries x N documents, P=384: cosine-score GEMM + NDCG@{10,5,1} on the device vs the
+    reference's per-query torch.cosine_similarity + sklearn ndcg_score on the CPU."""
+    import time
+
+    from oracle import two_towers_oracle as orc
+
+    Q, N, P = 200, 10000, 384
+    g = torch.Generator().manual_seed(0)
+    q, d = torch.randn(Q, P, generator=g), torch.randn(N, P, generator=g)
+    rel = (torch.rand(Q, N, generator=g) < 0.001).float()
+    qd, dd, rd = q.cuda(), d.cuda(), rel.cuda()
+    t_s = timeit(lambda: ops.cosine_scores(qd, dd), n=20)
+    sc = ops.cosine_scores(qd, dd)
+    t_n = timeit(lambda: ops.ndcg_at_k(sc, rd, ks=(10, 5, 1)), n=20)
+    t0 = time.perf_counter()
+    s_cpu = orc.cosine_scores(q, d)
+    for k in (10, 5, 1):
+        orc.ndcg_rows(s_cpu.numpy(), rel.numpy(), k)
+    t_cpu = (time.perf_counter() - t0) * 1e6
+    print(f"eval Q={Q} N={N} P={P}: cosine_scores {t_s:8.1f} us, ndcg@10/5/1 {t_n:8.1f} us (incl. sync); "
+          f"CPU torch+sklearn {t_cpu:10.0f} us  ({t_cpu / (t_s + t_n):.0f}x)")
+
+
+if __name__ == "__main__" and "--eval" in sys.argv:
+    eval_bench()

@@ -501,8 +501,9 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
                  project_name: str = "two-towers-retrieval", use_wandb: bool = True,
                  wandb_config: Optional[dict] = None, accumulation_steps: int = 2,
                  use_mixed_precision: bool = True, num_workers: int = 4,
-                 run_comprehensive_test: bool = True, *, train_dataset=None, tokenizer=None,
-                 pretrained_model=None, model_name: Optional[str] = None, seed: Optional[int] = None) -> TwoTowersModel:
+                 run_comprehensive_test: bool = True, *, train_dataset=None, val_dataset=None, test_dataset=None,
+                 tokenizer=None, pretrained_model=None, model_name: Optional[str] = None,
+                 seed: Optional[int] = None, feature_cache: bool = True) -> TwoTowersModel:
     """Same keyword surface and defaults as backend/training.py:383-397; builds the
     model / criterion / Adam exactly like :433-436 and runs `num_epochs` epochs on
     the fused engine.  Differences, all outside the hot path: the dataset is passed
@@ -527,8 +528,31 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
     max_S = int(max(loader.q_ids.shape[1], loader.p_ids.shape[1]))
     trainer = TripletTrainer(model, max_batch=batch_size, max_seq_len=max_S, margin=margin, lr=learning_rate,
                              accumulation_steps=accumulation_steps)
+    if feature_cache:
+        # the encoder is frozen: pool every query / passage once, every epoch then only copies rows and
+        # takes its negatives by in-batch index
+        loader.emit = "cache"
+        trainer.build_feature_cache(*_ids_lens(loader.all_texts()))
     print(f"Starting training for {num_epochs} epochs...")
     for epoch in range(num_epochs):
-        avg = trainer.train_epoch((ids, None, lens) for ids, lens in loader)
+        if feature_cache:
+            avg = trainer.train_epoch(loader)
+        else:
+            avg = trainer.train_epoch((ids, None, lens) for ids, lens in loader)
         print(f"Epoch {epoch + 1}/{num_epochs}  avg_train_loss {avg:.6f}")
+        if val_dataset is not None:  # per-epoch validation NDCG@10 (training.py:490)
+            from .evaluation import evaluate_model
+
+            val_ndcg = evaluate_model(model, val_dataset, batch_size=batch_size)
+            print(f"Validation NDCG@10: {val_ndcg:.4f}")
+    if test_dataset is not None and run_comprehensive_test:  # final comprehensive test (training.py:505-521)
+        from .evaluation import evaluate_model
+
+        evaluate_model(model, test_dataset, sample_size=len(test_dataset), min_query_groups=200, candidate_pool_size=-1,
+                       comprehensive=True, log_wandb=False, wandb_prefix="final_", batch_size=batch_size)
     return model
+
+
+def _ids_lens(t):
+    ids, lens = t
+    return ids, None, lens

@@ -96,3 +96,47 @@ def test_token_loader_emit_modes_describe_the_same_triplets():
             for i in range(rows.numel()):
                 L = int(lens3[r, i])
                 assert torch.equal(all_ids[rows[i], :L], ids3[r, i, :L])
+
+
+def test_device_sampler_distribution():
+    from two_towers_overlords_amd.data import sample_negative_indices_device
+
+    g = torch.Generator().manual_seed(1)
+    qids = torch.tensor([0, 0, 1, 2, 2, 2, 3, 0])
+    counts = torch.zeros(8, 8)
+    for _ in range(4000):
+        neg = sample_negative_indices_device(qids, g)
+        assert torch.all(qids[neg] != qids)           # never the same query (hence never itself)
+        counts[torch.arange(8), neg] += 1
+    # uniform over the admissible items of each row (backend/data.py:124-128's rejection loop)
+    for i in range(8):
+        adm = (qids != qids[i])
+        p = counts[i][adm] / counts[i].sum()
+        assert counts[i][~adm].sum() == 0 and float((p - 1.0 / adm.sum()).abs().max()) < 0.03
+    # degenerate batches: the reference raises IndexError for B = 1 and never returns when all ids are equal
+    import pytest
+    with pytest.raises(IndexError):
+        sample_negative_indices_device(torch.tensor([5]), g)
+    with pytest.raises(RuntimeError):
+        sample_negative_indices_device(torch.tensor([5, 5, 5]), g)
+
+
+def test_packed_token_files_round_trip(tmp_path):
+    from two_towers_overlords_amd.data import PackedTokens
+
+    ds = _DS(23, 6)
+    a = TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit="index")
+    prefix = str(tmp_path / "marco")
+    a.save_packed(prefix)
+    b = TokenTripletLoader.from_packed(prefix, batch_size=8, device="cpu", seed=5, emit="index")
+    assert b.query_ids == a.query_ids and torch.equal(b.q_lens, a.q_lens) and torch.equal(b.p_lens, a.p_lens)
+    assert torch.equal(b.q_ids, a.q_ids[:, : b.q_ids.shape[1]]) and torch.equal(b.p_ids, a.p_ids[:, : b.p_ids.shape[1]])
+    for x, y in zip(a, b):  # same seed -> the same batches from the packed files
+        assert torch.equal(x.ids, y.ids) and torch.equal(x.lens, y.lens) and torch.equal(x.neg_index, y.neg_index)
+    pk = PackedTokens.load(prefix + ".p")
+    assert len(pk) == 23 and pk.max_len == int(a.p_lens.max())
+    # device sampler: same triplet structure, different draws
+    c = TokenTripletLoader.from_packed(prefix, batch_size=8, device="cpu", seed=5, emit="index", sampler="device")
+    for tb in c:
+        qid = torch.tensor(c.query_ids)
+        assert tb.neg_index.dtype == torch.int32 and tb.ids.shape[0] == 2

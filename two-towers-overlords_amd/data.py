@@ -41,6 +41,88 @@ def sample_negative_indices(query_ids: Sequence[int], rng=random) -> List[int]:
     return out
 
 
+def sample_negative_indices_device(query_ids: torch.Tensor, generator: Optional[torch.Generator] = None,
+                                   max_rounds: int = 64) -> torch.Tensor:
+    """Same distribution as `sample_negative_indices` (uniform over the other in-batch items,
+    redrawn while the query_id is equal — backend/data.py:113-137), drawn for the whole batch at
+    once with tensor ops on `query_ids`' device: O(B) per round instead of the reference's O(B^2)
+    Python list building per batch.  Not the same *draws* as the reference under a shared seed.
+    Raises if some item has no admissible negative (the reference would loop forever)."""
+    B = query_ids.numel()
+    if B < 2:
+        raise IndexError("cannot draw an in-batch negative from a batch of one")  # reference: random.choice([])
+    dev = query_ids.device
+    ar = torch.arange(B, device=dev)
+    neg = torch.empty(B, dtype=torch.long, device=dev)
+    todo = ar
+    for _ in range(max_rounds):
+        j = torch.randint(0, B - 1, (todo.numel(),), generator=generator, device=dev)
+        j = j + (j >= todo).long()          # uniform over the B-1 items other than i
+        ok = query_ids[j] != query_ids[todo]
+        neg[todo[ok]] = j[ok]
+        todo = todo[~ok]
+        if todo.numel() == 0:
+            return neg
+    # leftovers: items whose admissible set is tiny or empty — enumerate it exactly
+    for i in todo.tolist():
+        cand = ar[query_ids != query_ids[i]]
+        if cand.numel() == 0:
+            raise RuntimeError("every item of the batch shares one query_id: no admissible negative")
+        neg[i] = cand[torch.randint(0, cand.numel(), (1,), generator=generator, device=dev)]
+    return neg
+
+
+class PackedTokens:
+    """On-disk form of a tokenised text collection: `<prefix>.ids.bin` — all
+    token ids back to back, int32; `<prefix>.offsets.bin` — int64 [N+1] start offsets.  Written
+    once (tokenisation is the expensive host step), memory-mapped afterwards."""
+
+    def __init__(self, ids, offsets):
+        self.ids, self.offsets = ids, offsets
+
+    def __len__(self) -> int:
+        return len(self.offsets) - 1
+
+    @property
+    def max_len(self) -> int:
+        import numpy as np
+
+        return int(np.diff(self.offsets).max()) if len(self) else 0
+
+    @staticmethod
+    def write(prefix: str, input_ids: torch.Tensor, lens: torch.Tensor) -> "PackedTokens":
+        import numpy as np
+
+        ids = input_ids.cpu().numpy()
+        ln = lens.cpu().numpy().astype(np.int64)
+        offsets = np.zeros(len(ln) + 1, dtype=np.int64)
+        np.cumsum(ln, out=offsets[1:])
+        flat = np.empty(int(offsets[-1]), dtype=np.int32)
+        for i, n in enumerate(ln):
+            flat[offsets[i]: offsets[i + 1]] = ids[i, :n]
+        flat.tofile(prefix + ".ids.bin")
+        offsets.tofile(prefix + ".offsets.bin")
+        return PackedTokens.load(prefix)
+
+    @staticmethod
+    def load(prefix: str) -> "PackedTokens":
+        import numpy as np
+
+        offsets = np.fromfile(prefix + ".offsets.bin", dtype=np.int64)
+        ids = np.memmap(prefix + ".ids.bin", dtype=np.int32, mode="r") if offsets[-1] > 0 else np.zeros(0, np.int32)
+        return PackedTokens(ids, offsets)
+
+    def padded(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(ids [N, max_len] int32 zero-padded, lens [N] int32) on `device`."""
+        import numpy as np
+
+        ln = np.diff(self.offsets)
+        out = np.zeros((len(self), max(self.max_len, 1)), dtype=np.int32)
+        for i, n in enumerate(ln):
+            out[i, :n] = self.ids[self.offsets[i]: self.offsets[i + 1]]
+        return torch.from_numpy(out).to(device), torch.from_numpy(ln.astype(np.int32)).to(device)
+
+
 class TripletDataLoader:
     """Creates (queries, positives, negatives) string batches.  Mirrors backend/data.py:90-152."""
 
@@ -88,25 +170,42 @@ class TokenTripletLoader:
     shuffle=True, drop_last=False, negatives via `sample_negative_indices`).
     """
 
-    def __init__(self, dataset, tokenizer: Callable, batch_size: int, device, max_length: int = 512,
-                 seed: Optional[int] = None, shuffle: bool = True, emit: str = "ids3"):
-        """emit: "ids3"  -> (ids [3,B,S], lens [3,B])                      three gathers per batch
+    def __init__(self, dataset, tokenizer: Optional[Callable], batch_size: int, device, max_length: int = 512,
+                 seed: Optional[int] = None, shuffle: bool = True, emit: str = "ids3", sampler: str = "reference",
+                 packed: Optional[Tuple["PackedTokens", "PackedTokens", Sequence[int]]] = None):
+        """sampler: "reference" — `sample_negative_indices`, the reference's draws under the same seed
+                    (O(B^2) Python per batch, like backend/data.py:132-137); "device" — the same
+                    distribution drawn with tensor ops (`sample_negative_indices_device`).
+        packed: (queries, positives, query_ids) as PackedTokens instead of tokenising `dataset`.
+        emit: "ids3"  -> (ids [3,B,S], lens [3,B])                      three gathers per batch
                  "index" -> TripletBatch(ids [2,B,S], lens, neg_index)     negatives by in-batch index
                  "cache" -> TripletBatch(cache_rows [2,B], neg_index)      rows of a frozen-feature cache
                             laid out [queries (N); positives (N)] — build it with
                             `trainer.build_feature_cache(*loader.all_texts())`"""
         if emit not in ("ids3", "index", "cache"):
             raise ValueError("emit must be 'ids3', 'index' or 'cache'")
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' or 'device'")
         self.emit = emit
+        self.sampler = sampler
         self.batch_size = batch_size
         self.device = torch.device(device)
         self.shuffle = shuffle
         self.rng = random.Random(seed) if seed is not None else random
-        n = len(dataset)
-        items = [dataset[i] for i in range(n)]
-        self.query_ids = [int(it["query_id"]) for it in items]
-        self.q_ids, self.q_lens = self._tokenize(tokenizer, [it["query"] for it in items], max_length)
-        self.p_ids, self.p_lens = self._tokenize(tokenizer, [it["positive"] for it in items], max_length)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed if seed is not None else random.getrandbits(60))
+        if packed is not None:
+            pq, pp, qids = packed
+            self.query_ids = [int(x) for x in qids]
+            self.q_ids, self.q_lens = pq.padded(self.device)
+            self.p_ids, self.p_lens = pp.padded(self.device)
+        else:
+            n = len(dataset)
+            items = [dataset[i] for i in range(n)]
+            self.query_ids = [int(it["query_id"]) for it in items]
+            self.q_ids, self.q_lens = self._tokenize(tokenizer, [it["query"] for it in items], max_length)
+            self.p_ids, self.p_lens = self._tokenize(tokenizer, [it["positive"] for it in items], max_length)
+        self._qid_t = torch.tensor(self.query_ids, device=self.device)
 
     def _tokenize(self, tokenizer, texts, max_length):
         tok = tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=max_length)
@@ -118,6 +217,22 @@ class TokenTripletLoader:
 
     def __len__(self) -> int:
         return (len(self.query_ids) + self.batch_size - 1) // self.batch_size
+
+    def save_packed(self, prefix: str) -> None:
+        """Write `<prefix>.q.*`, `<prefix>.p.*` (PackedTokens) and `<prefix>.query_ids.bin` (int64)."""
+        import numpy as np
+
+        PackedTokens.write(prefix + ".q", self.q_ids, self.q_lens)
+        PackedTokens.write(prefix + ".p", self.p_ids, self.p_lens)
+        np.asarray(self.query_ids, dtype=np.int64).tofile(prefix + ".query_ids.bin")
+
+    @classmethod
+    def from_packed(cls, prefix: str, batch_size: int, device, **kw) -> "TokenTripletLoader":
+        import numpy as np
+
+        qids = np.fromfile(prefix + ".query_ids.bin", dtype=np.int64)
+        return cls(None, None, batch_size, device,
+                   packed=(PackedTokens.load(prefix + ".q"), PackedTokens.load(prefix + ".p"), qids), **kw)
 
     def all_texts(self):
         """(ids [2N, S], lens [2N]) of every query then every positive — the input of the feature cache."""
@@ -132,9 +247,11 @@ class TokenTripletLoader:
             self.rng.shuffle(order)
         for s in range(0, n, self.batch_size):
             idx = order[s: s + self.batch_size]
-            neg = sample_negative_indices([self.query_ids[i] for i in idx], self.rng)
             it = torch.tensor(idx, device=self.device)
-            neg_t = torch.tensor(neg, device=self.device)
+            if self.sampler == "device":
+                neg_t = sample_negative_indices_device(self._qid_t[it], self.gen)
+            else:
+                neg_t = torch.tensor(sample_negative_indices([self.query_ids[i] for i in idx], self.rng), device=self.device)
             if self.emit != "ids3":
                 from .training import TripletBatch
 

@@ -328,6 +328,7 @@ extern "C" int tt_engine_read_stats(tt_engine* e, double* loss_sum, int64_t* n_b
   if (reset) {
     TT_HIP(hipMemsetAsync(e->loss_sum, 0, sizeof(double), st));
     TT_HIP(hipMemsetAsync(e->loss_cnt, 0, sizeof(long long), st));
+    TT_HIP(hipMemsetAsync(e->oob, 0, sizeof(int32_t), st));  // the out-of-range flag is reported once
   }
   TT_HIP(hipStreamSynchronize(st));
   if (loss_sum) *loss_sum = s;

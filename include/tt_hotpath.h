@@ -175,6 +175,28 @@ int tt_reduce_slabs_f32(const float* slabs, int nslabs, int64_t slab_stride, flo
                         int64_t n, int accumulate, tt_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
+/* In-batch-negatives triplet loss (BASELINE.json configs[4])  */
+/* ------------------------------------------------------------------------- */
+
+size_t tt_inbatch_workspace_bytes(int64_t Bq, int64_t Bd, int P);
+/*
+ * Every other document of the batch is a negative for query i (the reference samples ONE in-batch
+ * positive per item as its negative, backend/data.py:113-137; it has no all-pairs loss, so this
+ * entry point is pinned only by this repo's own CPU oracle):
+ *   S[i,j] = cos(q_i, d_j)  (eps 1e-8);  positives: d row pos_index[i] (NULL: i, needs Bq == Bd)
+ *   *loss  = (sum_i sum_{j valid} relu(S[i,j] - S[i,pos_i] + margin)) / loss_denominator
+ *   valid j: j != pos_i and, if qid_q/qid_d are given, qid_d[j] != qid_q[i]
+ *   dq [Bq,P], dd [Bd,P] = grad_scale * d(sum of hinges)/d{q,d}   (dd is added to if accumulate_dd)
+ * The [Bq,Bd] similarity matrix, dS * d and dS^T * q are fp32 MFMA GEMMs.  Bq != Bd serves the
+ * data-parallel case: local queries against the all-gathered documents of every rank.
+ */
+int tt_inbatch_triplet_fwd_bwd_f32(const float* q, const float* d, const int32_t* pos_index,
+                                   const int64_t* qid_q, const int64_t* qid_d, float margin,
+                                   float grad_scale, float loss_denominator, int64_t Bq, int64_t Bd,
+                                   int P, float* loss, float* dq, float* dd, int accumulate_dd,
+                                   void* workspace, size_t workspace_bytes, tt_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
 /* Evaluation — the arithmetic of evaluate_model on the device */
 /* ------------------------------------------------------------------------- */
 

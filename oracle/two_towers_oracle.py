@@ -402,3 +402,24 @@ def ndcg_rows(scores, gains, k: int, valid=None):
             continue
         out.append(float(ndcg_score(g.reshape(1, -1), s.reshape(1, -1), k=k)))
     return np.array(out)
+
+
+# --------------------------------------------------------------------------- #
+# In-batch-negatives triplet loss — NO reference implementation: this is the
+# definition the HIP path is checked against ("parity unpinned").
+# --------------------------------------------------------------------------- #
+
+
+def inbatch_triplet_loss(q, d, margin, pos_index=None, qid_q=None, qid_d=None, denominator=None):
+    """sum_i sum_{j valid} relu(cos(q_i,d_j) - cos(q_i,d_pos_i) + margin) / denominator; valid j: j != pos_i
+    and (no ids or qid_d[j] != qid_q[i]).  Default denominator Bq*(Bd-1)."""
+    Bq, Bd = q.shape[0], d.shape[0]
+    pos = torch.arange(Bq) if pos_index is None else pos_index.long()
+    S = torch.stack([F.cosine_similarity(q[i: i + 1], d, dim=1) for i in range(Bq)])
+    s_pos = S[torch.arange(Bq), pos].unsqueeze(1)
+    valid = torch.ones(Bq, Bd, dtype=torch.bool)
+    valid[torch.arange(Bq), pos] = False
+    if qid_q is not None:
+        valid &= qid_d.unsqueeze(0) != qid_q.unsqueeze(1)
+    h = F.relu(S - s_pos + margin) * valid
+    return h.sum() / (float(Bq * (Bd - 1)) if denominator is None else denominator)

@@ -441,3 +441,30 @@ def test_engine_rejects_bad_arguments(tt):
     with pytest.raises(TTError):
         eng.read_stats()
     eng.close()
+
+
+# --------------------------------------------------------------------------- f4: in-batch negatives
+@pytest.mark.parametrize("Bq,Bd,P,ids", [(33, 33, 40, False), (64, 64, 384, True), (50, 130, 64, True), (512, 512, 128, False)])
+def test_inbatch_triplet_vs_oracle(tt, Bq, Bd, P, ids):
+    """No reference implementation (parity unpinned): checked against the oracle's definition + autograd."""
+    ops, _ = tt
+    gen = torch.Generator().manual_seed(Bq + Bd + P)
+    q = torch.randn(Bq, P, generator=gen)
+    d = torch.randn(Bd, P, generator=gen)
+    pos = None if Bq == Bd else torch.randint(0, Bd, (Bq,), generator=gen)
+    src = torch.arange(Bq) if pos is None else pos
+    d[src] = d[src] * 0.3 + q * 0.7  # positives resemble their queries
+    qid_q = torch.randint(0, max(2, Bq // 3), (Bq,), generator=gen) if ids else None
+    qid_d = None
+    if ids:
+        qid_d = torch.randint(0, max(2, Bq // 3), (Bd,), generator=gen)
+        qid_d[src] = qid_q
+    qq, dd_ = q.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    ref = orc.inbatch_triplet_loss(qq, dd_, 0.2, pos, qid_q, qid_d)
+    ref.backward()
+    loss, dq, dd = ops.inbatch_triplet_fwd_bwd(
+        q.cuda(), d.cuda(), 0.2, None if pos is None else pos.int().cuda(),
+        None if qid_q is None else qid_q.cuda(), None if qid_d is None else qid_d.cuda())
+    assert abs(loss.item() - ref.item()) <= TOL
+    close(dq, qq.grad, rel_to_max=True, atol=2e-5)
+    close(dd, dd_.grad, rel_to_max=True, atol=2e-5)

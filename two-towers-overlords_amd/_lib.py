@@ -57,6 +57,8 @@ SIGNATURES = {
     "tt_triplet_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _f, _f, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_adam_f32": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i64, _d, _d, _d, _d, _i64, _f, _vp]),
     "tt_reduce_slabs_f32": (_i, [_vp, _i, _i64, _vp, _i64, _i, _vp]),
+    "tt_inbatch_workspace_bytes": (_sz, [_i64, _i64, _i]),
+    "tt_inbatch_triplet_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i64, _i64, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "tt_cosine_scores_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "tt_cosine_scores_f32": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
     "tt_ndcg_at_k_f32": (_i, [_vp, _vp, _vp, _i64, _i64, C.POINTER(_i32), _i, _vp, _vp, _vp]),

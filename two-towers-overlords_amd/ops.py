@@ -258,3 +258,36 @@ def ndcg_at_k(scores: torch.Tensor, relevance: torch.Tensor, ks=(10,), valid: Op
              out.data_ptr(), _stream())
         torch.cuda.current_stream().synchronize()  # ks_host must outlive the async H2D copy
     return out
+
+
+def inbatch_triplet_fwd_bwd(q: torch.Tensor, d: torch.Tensor, margin: float, pos_index: Optional[torch.Tensor] = None,
+                            qid_q: Optional[torch.Tensor] = None, qid_d: Optional[torch.Tensor] = None,
+                            grad_scale: Optional[float] = None, loss_denominator: Optional[float] = None):
+    """In-batch-negatives triplet loss: returns (loss[1], dq [Bq,P], dd [Bd,P]).
+    Defaults: mean over the Bq*(Bd-1) (query, other document) pairs."""
+    _req(q, "q", torch.float32, 2)
+    _req(d, "d", torch.float32, 2)
+    Bq, P = q.shape
+    Bd = d.shape[0]
+    if d.shape[1] != P or d.device != q.device:
+        raise ValueError("inbatch: q [Bq,P] and d [Bd,P] must share P and the device")
+    if pos_index is None and Bq != Bd:
+        raise ValueError("inbatch: pos_index is required when Bq != Bd")
+    if pos_index is not None:
+        _req(pos_index, "pos_index", torch.int32, 1)
+    if (qid_q is None) != (qid_d is None):
+        raise ValueError("inbatch: give both qid_q and qid_d or neither")
+    if qid_q is not None:
+        _req(qid_q, "qid_q", torch.int64, 1)
+        _req(qid_d, "qid_d", torch.int64, 1)
+    z = float(Bq * (Bd - 1))
+    gs = (1.0 / z) if grad_scale is None else grad_scale
+    den = z if loss_denominator is None else loss_denominator
+    loss = torch.empty(1, dtype=torch.float32, device=q.device)
+    dq, dd = torch.empty_like(q), torch.empty_like(d)
+    nbytes = _lib.load().tt_inbatch_workspace_bytes(Bq, Bd, P)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        call("tt_inbatch_triplet_fwd_bwd_f32", q.data_ptr(), d.data_ptr(), _ptr(pos_index), _ptr(qid_q), _ptr(qid_d), margin,
+             gs, den, Bq, Bd, P, loss.data_ptr(), dq.data_ptr(), dd.data_ptr(), 0, ws.data_ptr(), nbytes, _stream())
+    return loss, dq, dd

@@ -315,6 +315,19 @@ int tt_engine_pool_cached(tt_engine* e, int slot, const float* cache, int64_t ca
 int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_t* neg_index, float margin,
                       float grad_scale, float loss_denominator, tt_stream_t stream);
 
+/*
+ * Phase B in two halves, for a loss computed by the caller between them (the in-batch-negatives
+ * loss, or any other function of the projected embeddings):
+ *   tt_engine_forward : projection forward of the slot's rows -> tt_engine_embeddings() [roles*B, P]
+ *   (caller writes d loss / d embeddings, same row layout, into tt_engine_dout())
+ *   tt_engine_backward: parameter gradients -> slabs, as tt_engine_fwd_bwd leaves them
+ * tt_engine_add_loss folds a device-side loss value into the engine's running loss statistics.
+ */
+int tt_engine_forward(tt_engine* e, int slot, int32_t B, int32_t roles, tt_stream_t stream);
+int tt_engine_backward(tt_engine* e, int slot, int32_t B, int32_t roles, tt_stream_t stream);
+float* tt_engine_dout(const tt_engine* e);                     /* [roles*B, P] */
+int tt_engine_add_loss(tt_engine* e, const float* loss_value, tt_stream_t stream);
+
 /* grad_out[param_count] (+)= sum of slabs — the flat bucket handed to the RCCL all-reduce. */
 int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumulate, tt_stream_t stream);
 

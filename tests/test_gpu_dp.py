@@ -77,3 +77,81 @@ def test_two_ranks_equal_one_rank_and_oracle():
 
     for k in orc.PARAM_KEYS:
         assert_params_close(params2[k], params[k].numpy(), 1e-3, NB)
+
+
+# --------------------------------------------------------------------------- f4 in-batch negatives
+def _inbatch_setup():
+    Vv, Dd, Pp, Bb, Ss, nb = 3000, 128, 48, 64, 24, 3
+    table = orc.synthetic_table(Vv, Dd, seed=13) * 30
+    params = orc.init_params(Dd, Pp, seed=14)
+    batches = [orc.synthetic_batch(Bb, Ss, Vv, seed=170 + i, ragged=True)[:2] for i in range(nb)]
+    g = torch.Generator().manual_seed(15)
+    qids = [torch.randint(0, Bb // 2, (Bb,), generator=g) for _ in range(nb)]
+    return table, params, batches, qids, (Vv, Dd, Pp, Bb, Ss, nb)
+
+
+def _inbatch_reference():
+    table, params, batches, qids, (_, _, _, Bb, _, nb) = _inbatch_setup()
+    st = orc.AdamState(lr=1e-3)
+    losses = []
+    for (qb, pb), qid in zip(batches, qids):
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        q = orc.encode(table, qb[0], qb[1], leaves, "query_tower")
+        d = orc.encode(table, pb[0], pb[1], leaves, "document_tower")
+        loss = orc.inbatch_triplet_loss(q, d, 0.2, None, qid, qid)
+        loss.backward()
+        orc.adam_step(params, {k: v.grad for k, v in leaves.items()}, st)
+        losses.append(loss.item())
+    return sum(losses) / nb, params
+
+
+def _inbatch_worker(rank, world, port, q):
+    try:
+        from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
+
+        if world > 1:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        table, params, batches, qids, (_, _, _, Bb, Ss, _) = _inbatch_setup()
+        n = Bb // world
+        tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=n,
+                            max_seq_len=Ss, margin=0.2, lr=1e-3, loss="inbatch")
+        sl = slice(rank * n, (rank + 1) * n)
+        shards = [TripletBatch(ids=torch.stack([qb[0][sl], pb[0][sl]]).int().cuda(),
+                               lens=torch.stack([qb[1][sl].sum(1), pb[1][sl].sum(1)]).int().cuda(),
+                               query_ids=qid[sl].cuda()) for (qb, pb), qid in zip(batches, qids)]
+        avg = tr.train_epoch(shards)
+        if rank == 0:
+            q.put(("ok", avg, {k: v.cpu().numpy().copy() for k, v in tr.named_parameters().items()}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put(("error", f"rank {rank}: {e}\\n{traceback.format_exc()}", None))
+        raise
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_inbatch_negatives_trainer_vs_oracle(world):
+    """In-batch-negatives loss through the trainer: one rank, and two ranks exchanging document
+    embeddings (all-gather) and their gradient (all-reduce), against the oracle's autograd."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29700 + os.getpid() % 1000 + world
+    procs = [ctx.Process(target=_inbatch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get()
+    for p in procs:
+        p.join(180)
+    assert out[0] == "ok", out[1]
+    _, avg, params = out
+    ref_avg, ref_params = _inbatch_reference()
+    assert abs(avg - ref_avg) <= 1e-5
+    from conftest import assert_params_close
+
+    for k in orc.PARAM_KEYS:
+        assert_params_close(params[k], ref_params[k].numpy(), 1e-3, 3)

@@ -71,6 +71,10 @@ SIGNATURES = {
     "tt_engine_pool": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i32, _i32, _i32, _vp]),
     "tt_engine_pool_cached": (_i, [_vp, _i, _vp, _i64, _vp, _i, _i32, _i32, _vp]),
     "tt_engine_fwd_bwd": (_i, [_vp, _i, _i32, _vp, _f, _f, _f, _vp]),
+    "tt_engine_forward": (_i, [_vp, _i, _i32, _i32, _vp]),
+    "tt_engine_backward": (_i, [_vp, _i, _i32, _i32, _vp]),
+    "tt_engine_dout": (_vp, [_vp]),
+    "tt_engine_add_loss": (_i, [_vp, _vp, _vp]),
     "tt_engine_reduce_grads": (_i, [_vp, _vp, _i, _vp]),
     "tt_engine_adam": (_i, [_vp, _vp, _d, _d, _d, _d, _i64, _vp]),
     "tt_engine_adam_auto": (_i, [_vp, _vp, _d, _d, _d, _d, _vp]),

@@ -207,20 +207,15 @@ extern "C" int tt_engine_pool_cached(tt_engine* e, int slot, const float* cache,
                              e->oob, stream);
 }
 
-extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_t* neg_index, float margin,
-                                 float grad_scale, float loss_denominator, tt_stream_t stream) {
-  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
-  TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
-  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
-  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && loss_denominator > 0.f, TT_ERR_BAD_SHAPE);
-  hipStream_t st = static_cast<hipStream_t>(stream);
+// The two towers' row ranges of a pooled slot: query rows [0,B), document rows [B, B + doc_rows).
+static void fill_towers(tt_engine* e, int slot, int32_t B, int32_t doc_rows, ttp::Tower (&t)[2]) {
   const int D = e->cfg.D, P = e->cfg.P;
-  ttp::Tower t[2] = {};
   for (int i = 0; i < 2; ++i) {
     const int64_t row0 = i == 0 ? 0 : B;
     float* w = e->params + i * e->tower_n;
     float* g = e->slabs + i * e->tower_n;
-    t[i].M = i == 0 ? B : (neg_index ? B : 2 * B);
+    t[i] = ttp::Tower{};
+    t[i].M = i == 0 ? B : doc_rows;
     t[i].X = e->pooled[slot] + row0 * D;
     t[i].W1 = w;
     t[i].b1 = w + (int64_t)P * D;
@@ -235,28 +230,28 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
     t[i].gW2 = t[i].gb1 + P;
     t[i].gb2 = t[i].gW2 + (int64_t)P * P;
   }
+}
+
+// dW2/db2 (+ optionally the loss mean) on the engine's second stream, under the dH -> dW1/db1
+// chain; joined before the caller's next stream-ordered call (reduce_grads / adam / next step).
+static int backward_forked(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_rows, float loss_denominator,
+                           hipStream_t st) {
+  const int D = e->cfg.D, P = e->cfg.P;
   const bool shared = e->cfg.k1_blocks_per_cu > 0;  // gathers run beside these kernels on another stream
-  int rc = ttp::forward(t, 2, D, P, st, shared);
-  if (rc != TT_OK) return rc;
-  const float* q = e->emb;
-  const float* p = e->emb + (int64_t)B * P;
-  // with neg_index the negatives ARE rows of the positives' embeddings (no third encode)
-  const float* n = neg_index ? p : e->emb + 2 * (int64_t)B * P;
-  rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
-                              e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st);
-  if (rc != TT_OK) return rc;
+  int rc;
   if (!e->aux) {
-    rc = tt_launch_loss_mean(e->hinge, B, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
-    if (rc != TT_OK) return rc;
+    if (loss_rows > 0) {
+      rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
+      if (rc != TT_OK) return rc;
+    }
     return ttp::backward(t, 2, D, P, e->nslabs, e->slab_stride, st);
   }
-  // fork: the loss mean and dW2/db2 only need what the triplet kernel produced; they run on the
-  // engine's second stream under the dH -> dW1/db1 chain, and join before the caller's next
-  // stream-ordered call (reduce_grads / adam / the next fwd_bwd).
   TT_HIP(hipEventRecord(e->ev_fork, st));
   TT_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
-  rc = tt_launch_loss_mean(e->hinge, B, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, e->aux);
-  if (rc != TT_OK) return rc;
+  if (loss_rows > 0) {
+    rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, e->aux);
+    if (rc != TT_OK) return rc;
+  }
   rc = ttp::backward_dw2(t, 2, D, P, e->nslabs, e->slab_stride, e->aux);
   if (rc != TT_OK) return rc;
   TT_HIP(hipEventRecord(e->ev_join, e->aux));
@@ -265,6 +260,66 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
   rc = ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
   if (rc != TT_OK) return rc;
   TT_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
+  return TT_OK;
+}
+
+extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_t* neg_index, float margin,
+                                 float grad_scale, float loss_denominator, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && loss_denominator > 0.f, TT_ERR_BAD_SHAPE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int D = e->cfg.D, P = e->cfg.P;
+  ttp::Tower t[2];
+  fill_towers(e, slot, B, neg_index ? B : 2 * B, t);
+  int rc = ttp::forward(t, 2, D, P, st, e->cfg.k1_blocks_per_cu > 0);
+  if (rc != TT_OK) return rc;
+  const float* q = e->emb;
+  const float* p = e->emb + (int64_t)B * P;
+  // with neg_index the negatives ARE rows of the positives' embeddings (no third encode)
+  const float* n = neg_index ? p : e->emb + 2 * (int64_t)B * P;
+  rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
+                              e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st);
+  if (rc != TT_OK) return rc;
+  return backward_forked(e, t, B, loss_denominator, st);
+}
+
+extern "C" int tt_engine_forward(tt_engine* e, int slot, int32_t B, int32_t roles, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (roles == 2 || roles == 3), TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B, TT_ERR_BAD_SHAPE);
+  ttp::Tower t[2];
+  fill_towers(e, slot, B, (roles - 1) * B, t);
+  return ttp::forward(t, 2, e->cfg.D, e->cfg.P, static_cast<hipStream_t>(stream), e->cfg.k1_blocks_per_cu > 0);
+}
+
+extern "C" int tt_engine_backward(tt_engine* e, int slot, int32_t B, int32_t roles, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(e->params, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (roles == 2 || roles == 3), TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B, TT_ERR_BAD_SHAPE);
+  ttp::Tower t[2];
+  fill_towers(e, slot, B, (roles - 1) * B, t);
+  return backward_forked(e, t, 0, 1.f, static_cast<hipStream_t>(stream));
+}
+
+extern "C" float* tt_engine_dout(const tt_engine* e) { return ok(e) ? e->dOut : nullptr; }
+
+__global__ void add_loss_kernel(const float* __restrict__ v, float* __restrict__ last, double* __restrict__ sum,
+                                long long* __restrict__ cnt) {
+  *last = *v;
+  *sum += static_cast<double>(*v);
+  *cnt += 1;
+}
+
+extern "C" int tt_engine_add_loss(tt_engine* e, const float* loss_value, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(loss_value, TT_ERR_NULL_POINTER);
+  hipLaunchKernelGGL(add_loss_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), loss_value, e->loss,
+                     e->loss_sum, e->loss_cnt);
+  TT_CHECK_LAUNCH();
   return TT_OK;
 }
 

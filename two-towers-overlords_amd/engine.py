@@ -127,6 +127,21 @@ class HotPathEngine:
         call("tt_engine_fwd_bwd", self._h, slot, B, ni, margin, (1.0 / B) if grad_scale is None else grad_scale,
              float(B) if loss_denominator is None else loss_denominator, self._stream())
 
+    def forward(self, slot: int, B: int, roles: int = 2) -> None:
+        """Projection forward only; the embeddings are then in `embeddings(B, roles)`."""
+        call("tt_engine_forward", self._h, slot, B, roles, self._stream())
+
+    def backward(self, slot: int, B: int, roles: int = 2) -> None:
+        """Parameter gradients from d loss / d embeddings written by the caller into `d_out(B, roles)`."""
+        call("tt_engine_backward", self._h, slot, B, roles, self._stream())
+
+    def add_loss(self, loss_value: torch.Tensor) -> None:
+        _req(loss_value, "loss_value", torch.float32)
+        call("tt_engine_add_loss", self._h, loss_value.data_ptr(), self._stream())
+
+    def d_out(self, B: int, roles: int = 2) -> torch.Tensor:
+        return self._view(_lib.load().tt_engine_dout(self._h), roles * B * self.P).view(roles, B, self.P)
+
     def reduce_grads(self, out: torch.Tensor, accumulate: bool = False) -> None:
         _req(out, "grad_out", torch.float32, 1)
         if out.numel() != self.n_params:

@@ -223,6 +223,36 @@ class TripletLoss(nn.Module):
         return _TripletLossFn.apply(anchor, positive, negative, self.margin)
 
 
+class _InBatchLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, documents, margin, query_ids):
+        loss, dq, dd = ops.inbatch_triplet_fwd_bwd(anchor.contiguous(), documents.contiguous(), float(margin),
+                                                   qid_q=query_ids, qid_d=query_ids)
+        ctx.save_for_backward(dq, dd)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dq, dd = ctx.saved_tensors
+        return g * dq, g * dd, None, None
+
+
+class InBatchTripletLoss(nn.Module):
+    """Triplet loss over ALL in-batch negatives (BASELINE.json configs[4]; not in the reference, whose
+    `TripletDataLoader` samples one in-batch positive per item as the negative): for query i, document i
+    is the positive and every other document j of the batch a negative,
+        mean_{i, j != i} relu((1 - cos(q_i, d_i)) - (1 - cos(q_i, d_j)) + margin);
+    with `query_ids`, documents of the same query are not used as negatives (like data.py:124-128)."""
+
+    def __init__(self, margin: float = 0.3):
+        super().__init__()
+        self.margin = margin
+
+    def forward(self, anchor: Tensor, documents: Tensor, query_ids: Optional[Tensor] = None) -> Tensor:
+        qid = None if query_ids is None else query_ids.to(torch.int64).contiguous()
+        return _InBatchLossFn.apply(anchor, documents, self.margin, qid)
+
+
 class EmbeddingOnlyEncoder(nn.Module):
     """A frozen `pretrained_model` that is just a word-embedding table — what the
     `embed` encoder mode needs, constructible offline (synthetic or loaded rows).

@@ -262,7 +262,8 @@ def ndcg_at_k(scores: torch.Tensor, relevance: torch.Tensor, ks=(10,), valid: Op
 
 def inbatch_triplet_fwd_bwd(q: torch.Tensor, d: torch.Tensor, margin: float, pos_index: Optional[torch.Tensor] = None,
                             qid_q: Optional[torch.Tensor] = None, qid_d: Optional[torch.Tensor] = None,
-                            grad_scale: Optional[float] = None, loss_denominator: Optional[float] = None):
+                            grad_scale: Optional[float] = None, loss_denominator: Optional[float] = None,
+                            dq_out: Optional[torch.Tensor] = None, dd_out: Optional[torch.Tensor] = None):
     """In-batch-negatives triplet loss: returns (loss[1], dq [Bq,P], dd [Bd,P]).
     Defaults: mean over the Bq*(Bd-1) (query, other document) pairs."""
     _req(q, "q", torch.float32, 2)
@@ -284,7 +285,10 @@ def inbatch_triplet_fwd_bwd(q: torch.Tensor, d: torch.Tensor, margin: float, pos
     gs = (1.0 / z) if grad_scale is None else grad_scale
     den = z if loss_denominator is None else loss_denominator
     loss = torch.empty(1, dtype=torch.float32, device=q.device)
-    dq, dd = torch.empty_like(q), torch.empty_like(d)
+    dq = torch.empty_like(q) if dq_out is None else _req(dq_out, "dq_out", torch.float32, 2)
+    dd = torch.empty_like(d) if dd_out is None else _req(dd_out, "dd_out", torch.float32, 2)
+    if tuple(dq.shape) != (Bq, P) or tuple(dd.shape) != (Bd, P):
+        raise ValueError("inbatch: dq_out / dd_out must match q / d")
     nbytes = _lib.load().tt_inbatch_workspace_bytes(Bq, Bd, P)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):

@@ -141,6 +141,7 @@ class TripletBatch:
     lens: Optional[torch.Tensor] = None
     neg_index: Optional[torch.Tensor] = None
     cache_rows: Optional[torch.Tensor] = None
+    query_ids: Optional[torch.Tensor] = None  # int64 [B]; in-batch-negatives loss: same-query documents are not negatives
 
     @property
     def size(self) -> int:
@@ -152,7 +153,7 @@ class TripletBatch:
             return self
         ni = self.neg_index.long()
         cat = lambda t: None if t is None else torch.cat([t, t[1:2].index_select(1, ni)], dim=0).contiguous()
-        return TripletBatch(cat(self.ids), cat(self.mask), cat(self.lens), None, cat(self.cache_rows))
+        return TripletBatch(cat(self.ids), cat(self.mask), cat(self.lens), None, cat(self.cache_rows), self.query_ids)
 
 
 def as_batch(b) -> TripletBatch:
@@ -179,7 +180,7 @@ class TripletTrainer:
                  params: Optional[dict] = None, max_batch: int, max_seq_len: int, margin: float = 0.3,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
                  process_group=None, engine=None, overlap_streams: Optional[bool] = None,
-                 k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None):
+                 k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet"):
         if model is not None:
             if model.query_tower.encoder_mode != "embed":
                 raise ValueError("the fused engine implements the `embed` encoder mode; use train_epoch for `bert`")
@@ -189,6 +190,9 @@ class TripletTrainer:
             if table is None or params is None:
                 raise ValueError("pass a TwoTowersModel or table= and params=")
             tensors = [params[name] for name, _, _ in flat_param_slices(table.shape[1], _proj_dim(params))]
+        if loss not in ("triplet", "inbatch"):
+            raise ValueError("loss must be 'triplet' (the reference's sampled-negative triplet loss) or 'inbatch'")
+        self.loss_kind = loss
         self.device = table.device
         self.D = table.shape[1]
         self.P = tensors[1].shape[0]
@@ -268,7 +272,7 @@ class TripletTrainer:
             batch = batch.expand_negatives()  # an in-batch index does not survive sharding across ranks
         if self.side is None:
             self._timed_pool(slot, batch, None)
-            self._pending.append((slot, None, batch.size, batch.neg_index))
+            self._pending.append((slot, None, batch.size, batch.neg_index, batch.query_ids))
             return
         if self._main_dirty:  # graph replays are ordered by the main stream only: fence once
             self.side.wait_stream(torch.cuda.current_stream(self.device))
@@ -281,7 +285,7 @@ class TripletTrainer:
         self._timed_pool(slot, batch, self.side)
         ev = self._slot_ready[slot]
         ev.record(self.side)
-        self._pending.append((slot, ev, batch.size, batch.neg_index))
+        self._pending.append((slot, ev, batch.size, batch.neg_index, batch.query_ids))
 
     def _timed_pool(self, slot, batch: TripletBatch, stream) -> None:
         timed = False
@@ -322,7 +326,7 @@ class TripletTrainer:
         `issue_next()` (optional) is called where enqueueing further gathers overlaps best:
         before the projection kernels when gathers have their own stream, else right after
         the gradient all-reduce has been launched."""
-        slot, ev, local_B, neg_index = self._pending.popleft()
+        slot, ev, local_B, neg_index, query_ids = self._pending.popleft()
         global_B = global_B or local_B * self.world
         k = self.accumulation_steps
         self._steps_done += 1
@@ -332,7 +336,10 @@ class TripletTrainer:
                 issue_next = None
             if ev is not None:
                 torch.cuda.current_stream(self.device).wait_event(ev)
-        self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B), neg_index=neg_index)
+        if self.loss_kind == "inbatch":
+            self._inbatch_fwd_bwd(slot, local_B, query_ids, k)
+        else:
+            self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B), neg_index=neg_index)
         if self.side is not None:
             done = self._slot_done[slot]
             done.record()
@@ -360,14 +367,45 @@ class TripletTrainer:
             self.step_count += 1
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
 
+    def _inbatch_fwd_bwd(self, slot: int, B: int, query_ids, k: int) -> None:
+        """In-batch-negatives loss between the two halves of the engine's phase B.  Data parallel
+        (SURVEY.md §8e/f4): the documents' embeddings (and query ids) are all-gathered, each rank
+        scores its queries against every document of the global batch, and the documents' gradient
+        is summed over ranks before each rank keeps its own rows — the one real exchange of
+        activations on this path."""
+        eng = self.engine
+        eng.forward(slot, B, 2)
+        emb, dout = eng.embeddings(B, 2), eng.d_out(B, 2)
+        qid = None if query_ids is None else query_ids.to(torch.int64).contiguous()
+        if self.world == 1:
+            z = float(B * (B - 1))
+            loss, _, _ = ops.inbatch_triplet_fwd_bwd(emb[0], emb[1], self.margin, None, qid, qid, 1.0 / (z * k), z,
+                                                     dq_out=dout[0], dd_out=dout[1])
+        else:
+            W, r = self.world, self.rank
+            d_all = torch.empty((W * B, self.P), dtype=torch.float32, device=self.device)
+            dist.all_gather_into_tensor(d_all, emb[1].contiguous(), group=self.pg)
+            qid_all = None
+            if qid is not None:
+                qid_all = torch.empty(W * B, dtype=torch.int64, device=self.device)
+                dist.all_gather_into_tensor(qid_all, qid, group=self.pg)
+            pos = (torch.arange(B, device=self.device, dtype=torch.int32) + r * B).contiguous()
+            z = float(W * B * (W * B - 1))
+            loss, _, dd_all = ops.inbatch_triplet_fwd_bwd(emb[0], d_all, self.margin, pos, qid, qid_all, 1.0 / (z * k), z,
+                                                          dq_out=dout[0])
+            dist.all_reduce(dd_all, op=dist.ReduceOp.SUM, group=self.pg)
+            dout[1].copy_(dd_all[r * B: (r + 1) * B])
+        eng.add_loss(loss)
+        eng.backward(slot, B, 2)
+
     # -- hipGraph replay ---------------------------------------------------------------
     def _graphable(self, entry, nxt: Optional[TripletBatch]) -> bool:
         if not self.use_graphs:
             return False
         if self.eager_every and self._steps_done % self.eager_every == self.eager_every - 1:
             return False
-        _, _, B, neg_index = entry
-        if neg_index is not None or B != self.engine.max_B:
+        _, _, B, neg_index, _ = entry
+        if neg_index is not None or B != self.engine.max_B or self.loss_kind != "triplet":
             return False
         if nxt is None:
             return True
@@ -423,7 +461,7 @@ class TripletTrainer:
         if not self._graphable(entry, nxt):
             self.apply(global_B, issue_next=(lambda: self.gather(nxt)) if nxt is not None else None)
             return
-        slot_fb, ev, B, _ = self._pending.popleft()
+        slot_fb, ev, B, _, _ = self._pending.popleft()
         slot_k1 = None
         if nxt is not None:
             slot_k1 = self._next_slot
@@ -438,7 +476,7 @@ class TripletTrainer:
         self._micro += 1
         self.step_count += 1
         if slot_k1 is not None:
-            self._pending.append((slot_k1, None, B, None))
+            self._pending.append((slot_k1, None, B, None, None))
 
     # -- public ------------------------------------------------------------------
     def train_step(self, batch: Batch, global_batch: Optional[int] = None) -> None:

@@ -106,6 +106,9 @@ def main():
                          "index: negatives as in-batch indices of the positives (2 gathers). cache: rows of a "
                          "frozen-feature cache + negative indices (epochs >= 2 of real training).  The last two are "
                          "reported with their own metric name; they are not the BASELINE metric.")
+    ap.add_argument("--loss", default="triplet", choices=["triplet", "inbatch"],
+                    help="inbatch: all in-batch negatives (BASELINE.json configs[4]; B x B cosine matrix on MFMA), "
+                         "2 gathers per batch; reported under its own metric name")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the multi-process "
                          "path with several ranks sharing one GPU)")
@@ -151,14 +154,19 @@ def main():
         params[name] = ((torch.rand(*shape, generator=gp) * 2 - 1) * bound).to(device)
     trainer = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
                              overlap_streams=(False if (args.no_overlap or args.k1_only) else None),
-                             k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs))
+                             k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss)
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1
     n_distinct = 8
     id_batches = make_ids(V, B, S, n_distinct, seed=1234 + rank, device=device, zipf=args.zipf)
     batches = [(ids, None, None) for ids in id_batches]  # full-length: no mask, no lens
-    if args.inputs != "ids3":
+    if args.loss == "inbatch":
+        from two_towers_overlords_amd.training import TripletBatch
+
+        args.inputs = "ids2"
+        batches = [TripletBatch(ids=ids[:2].contiguous()) for ids in id_batches]
+    elif args.inputs != "ids3":
         from two_towers_overlords_amd.training import TripletBatch
 
         gneg = torch.Generator().manual_seed(99 + rank)
@@ -240,7 +248,7 @@ def main():
     result = {
         "metric": ("triplets/sec (q,pos,neg @ seq128/d384), full training step" if args.config == "c2"
                    else "triplets/sec, full training step") if args.inputs == "ids3"
-                  else f"triplets/sec, full training step, inputs={args.inputs} (NOT the BASELINE metric)",
+                  else f"triplets/sec, full training step, inputs={args.inputs}, loss={args.loss} (NOT the BASELINE metric)",
         "value": args.steps * B * world / elapsed,
         "unit": "triplets/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -15,6 +15,7 @@
 //
 // Row ids are wave-uniform (v_readlane from the lane that loaded them), so the
 // row base address is scalar and each load is `global_load_dwordx4 v, v_off, s[base]`.
+#include <cstdlib>
 #include "tt_common.h"
 
 namespace {
@@ -67,14 +68,55 @@ __device__ __forceinline__ void pool_group(unsigned long long& mine, const float
   }
 }
 
+// A/B variant (north_star wording: "rows into LDS tiles"): the K rows go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: per-lane source address, wave-uniform LDS base + lane*16), are waited
+// for once, then read back and accumulated.  `tile` is this wave's [U][C*256]-float slab.
+typedef __attribute__((address_space(1))) const void* tt_gptr_t;
+typedef __attribute__((address_space(3))) void* tt_lptr_t;
+
+template <int K, int C>
+__device__ __forceinline__ void pool_group_lds(unsigned long long& mine, const float* __restrict__ src, int id_lane,
+                                               float w_lane, int D, int lane, bool last_ok, float4 (&acc)[C],
+                                               float* __restrict__ tile) {
+  float wk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int pos = __builtin_ctzll(mine);
+    mine &= mine - 1;
+    wk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_lane), pos));
+    const long long row = (long long)__builtin_amdgcn_readlane(id_lane, pos);
+    const float* __restrict__ rp = src + row * (long long)D;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (c < C - 1 || last_ok)
+        __builtin_amdgcn_global_load_lds((tt_gptr_t)(rp + (c * TT_WAVE + lane) * 4),
+                                         (tt_lptr_t)(tile + (k * C + c) * 256), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (c < C - 1 || last_ok) {
+        const float4 r = *reinterpret_cast<const float4*>(tile + (k * C + c) * 256 + lane * 4);
+        f4_fma(acc[c], wk[k], r);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is overwritten by the next group's DMA
+}
+
 // C = float4 chunks per lane = ceil(D/4/64); U = rows in flight per wave.
-template <typename IdT, typename MaskT, int C, int U, bool DENSE>
+// LDS_STAGE: the A/B variant above (token-id gathers only).
+template <typename IdT, typename MaskT, int C, int U, bool DENSE, bool LDS_STAGE = false>
 __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, int S, int D, long long V,
     int* __restrict__ oob_flag) {
   __shared__ float4 part[kWavesPerText][C * TT_WAVE];
   __shared__ float red[kWavesPerText];
+  __shared__ __attribute__((aligned(16))) float stage[LDS_STAGE ? kWavesPerText * U * C * 256 : 4];
 
   const long long text = blockIdx.x;
   const int lane = threadIdx.x & (TT_WAVE - 1);
@@ -113,6 +155,13 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
     unsigned long long mine = live & (0x1111111111111111ULL << wave);
     int cnt = __popcll(mine);
     const long long drow0 = tbase + seg;
+    if (LDS_STAGE) {
+      float* __restrict__ tile = stage + wave * (U * C * 256);
+      while (cnt >= U) {
+        pool_group_lds<U, C>(mine, src, id, w, D, lane, last_ok, acc, tile);
+        cnt -= U;
+      }
+    }
     while (cnt >= U) {
       pool_group<U, C, DENSE>(mine, src, id, w, drow0, D, lane, last_ok, acc);
       cnt -= U;
@@ -266,6 +315,12 @@ int launch_pool(const float* src, const void* ids, const void* mask, const int32
     return TT_OK;
   }
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
+  if (!DENSE && (D / 4 + TT_WAVE - 1) / TT_WAVE == 2 && getenv("TT_K1_LDS")) {  // A/B experiment, D in (256, 512]
+    hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, 2, 8, false, true>), grid, block, 0, st, src, ids_t, mask_t, lens,
+                       out, S, D, (long long)V, oob);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+  }
 #define TT_POOL_CASE(CC, UU)                                                                      \
   hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, CC, UU, DENSE>), grid, block,                    \
                      k1_dynamic_lds(blocks_per_cu, CC * 4096u + 16u), st, src, ids_t, mask_t, lens, out, S, D, \

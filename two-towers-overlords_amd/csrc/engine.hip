@@ -21,7 +21,9 @@ int tt_launch_loss_mean(const float* hinge_rows, long long B, float denom, float
                         long long* acc_count, hipStream_t st);
 int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float margin, float grad_scale,
                            long long B, int P, float* pos_dist, float* neg_dist, float* hinge_rows,
-                           float* dq, float* dp, float* dn, const int* neg_index, hipStream_t st);
+                           float* dq, float* dp, float* dn, const int* neg_index, hipStream_t st,
+                           float* mean_partials = nullptr, unsigned* mean_ticket = nullptr, float mean_denom = 1.f,
+                           float* mean_loss = nullptr, double* acc_sum = nullptr, long long* acc_count = nullptr);
 
 struct tt_engine {
   uint32_t magic;
@@ -50,11 +52,10 @@ struct tt_engine {
   double* loss_sum;
   long long* loss_cnt;
   int32_t* oob;
+  float* mean_partials;  // per-workgroup hinge sums of the triplet kernel (in-launch loss mean)
+  unsigned* mean_ticket;
   long long* dev_step;  // optimizer steps taken, device copy (tt_engine_adam_auto)
   float* dev_scal;      // {step_size, bc2_sqrt} of the current device step
-  // second stream for the work that is off the critical path of a step (loss mean, dW2/db2)
-  hipStream_t aux;
-  hipEvent_t ev_fork, ev_join;
 };
 
 namespace {
@@ -89,6 +90,8 @@ void carve(tt_engine* e, char* base, size_t* total) {
   e->loss_sum = c.take<double>(2);
   e->loss_cnt = c.take<long long>(2);
   e->oob = c.take<int32_t>(4);
+  e->mean_partials = c.take<float>((size_t)e->cfg.max_B / 4 + 4);
+  e->mean_ticket = c.take<unsigned>(4);
   e->dev_step = c.take<long long>(2);
   e->dev_scal = c.take<float>(4);
   *total = c.off;
@@ -139,13 +142,6 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
   }
   e->arena = static_cast<char*>(workspace);
   carve(e, e->arena, &total);
-  // the fork/join stream is optional: without it everything runs on the caller's stream
-  if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) e->aux = nullptr;
-  if (e->aux && (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                 hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)) {
-    (void)hipStreamDestroy(e->aux);
-    e->aux = nullptr;
-  }
   e->magic = kMagic;
   *out = e;
   return TT_OK;
@@ -153,12 +149,6 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
 
 extern "C" int tt_engine_destroy(tt_engine* e) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
-  if (e->aux) {
-    (void)hipStreamSynchronize(e->aux);
-    (void)hipEventDestroy(e->ev_fork);
-    (void)hipEventDestroy(e->ev_join);
-    (void)hipStreamDestroy(e->aux);
-  }
   e->magic = 0;
   delete e;
   return TT_OK;
@@ -232,35 +222,21 @@ static void fill_towers(tt_engine* e, int slot, int32_t B, int32_t doc_rows, ttp
   }
 }
 
-// dW2/db2 (+ optionally the loss mean) on the engine's second stream, under the dH -> dW1/db1
-// chain; joined before the caller's next stream-ordered call (reduce_grads / adam / next step).
-static int backward_forked(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_rows, float loss_denominator,
-                           hipStream_t st) {
+// Backward chain of phase B: [loss mean] -> one launch for the two independent GEMMs (split-K
+// dW2/db2 and dH) -> dW1/db1.  (An earlier version forked dW2 + the loss mean onto a second
+// stream; the fused launch measured the same step time with 5 fewer host API calls per step.)
+static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_rows, float loss_denominator,
+                          hipStream_t st) {
   const int D = e->cfg.D, P = e->cfg.P;
   const bool shared = e->cfg.k1_blocks_per_cu > 0;  // gathers run beside these kernels on another stream
   int rc;
-  if (!e->aux) {
-    if (loss_rows > 0) {
-      rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
-      if (rc != TT_OK) return rc;
-    }
-    return ttp::backward(t, 2, D, P, e->nslabs, e->slab_stride, st);
-  }
-  TT_HIP(hipEventRecord(e->ev_fork, st));
-  TT_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
   if (loss_rows > 0) {
-    rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, e->aux);
+    rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
     if (rc != TT_OK) return rc;
   }
-  rc = ttp::backward_dw2(t, 2, D, P, e->nslabs, e->slab_stride, e->aux);
+  rc = ttp::backward_dw2_dh(t, 2, D, P, e->nslabs, e->slab_stride, st, shared);
   if (rc != TT_OK) return rc;
-  TT_HIP(hipEventRecord(e->ev_join, e->aux));
-  rc = ttp::backward_dh(t, 2, D, P, st, shared);
-  if (rc != TT_OK) return rc;
-  rc = ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
-  if (rc != TT_OK) return rc;
-  TT_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
-  return TT_OK;
+  return ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
 }
 
 extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_t* neg_index, float margin,
@@ -279,10 +255,12 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
   const float* p = e->emb + (int64_t)B * P;
   // with neg_index the negatives ARE rows of the positives' embeddings (no third encode)
   const float* n = neg_index ? p : e->emb + 2 * (int64_t)B * P;
+  // the batch loss is reduced inside the triplet launch (last workgroup), not by a launch of its own
   rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
-                              e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st);
+                              e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st,
+                              e->mean_partials, e->mean_ticket, loss_denominator, e->loss, e->loss_sum, e->loss_cnt);
   if (rc != TT_OK) return rc;
-  return backward_forked(e, t, B, loss_denominator, st);
+  return backward_chain(e, t, 0, 1.f, st);
 }
 
 extern "C" int tt_engine_forward(tt_engine* e, int slot, int32_t B, int32_t roles, tt_stream_t stream) {
@@ -302,7 +280,7 @@ extern "C" int tt_engine_backward(tt_engine* e, int slot, int32_t B, int32_t rol
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B, TT_ERR_BAD_SHAPE);
   ttp::Tower t[2];
   fill_towers(e, slot, B, (roles - 1) * B, t);
-  return backward_forked(e, t, 0, 1.f, static_cast<hipStream_t>(stream));
+  return backward_chain(e, t, 0, 1.f, static_cast<hipStream_t>(stream));
 }
 
 extern "C" float* tt_engine_dout(const tt_engine* e) { return ok(e) ? e->dOut : nullptr; }

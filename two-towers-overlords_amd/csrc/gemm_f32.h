@@ -42,4 +42,8 @@ struct Batch {
 // Launches one grouped GEMM.  wm/wn pick the block tile: (64*wm) x (64*wn).
 int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st);
 
+// One launch for an independent (kTN split-K, kStore) + (kNN, kReluMask) pair; falls back to two
+// launches for shapes the vector path does not cover.
+int launch_tn_nn_pair(const Batch& tn, const Batch& nn, int wm, int wn, hipStream_t st);
+
 }  // namespace ttg

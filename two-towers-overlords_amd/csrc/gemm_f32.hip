@@ -128,8 +128,20 @@ __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, 
   return make_float4(p[0], p[R], p[2 * R], p[3 * R]);
 }
 
+template <int LAYOUT, int WM, int WN>
+struct TileCfg {
+  static constexpr int BM = 64 * WM, BN = 64 * WN;
+  static constexpr bool A_KC = (LAYOUT != kTN);
+  static constexpr bool B_KC = (LAYOUT == kNT);
+  static constexpr int A_TILE = A_KC ? BM * BKP : BK * BM;
+  static constexpr int B_TILE = B_KC ? BN * BKP : BK * BN;
+  static constexpr int CP = BN + 4;  // padded row of the epilogue's C tile
+  static constexpr int LDS_FLOATS = (2 * (A_TILE + B_TILE) > BM * CP) ? 2 * (A_TILE + B_TILE) : BM * CP;
+};
+
+// One workgroup's tile: (bx, by) tile coordinates, bz = group * nsplit + split.
 template <int LAYOUT, int EPI, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
+__device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ lds, int bx, int by, int bz) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr bool A_KC = (LAYOUT != kTN);
   constexpr bool B_KC = (LAYOUT == kNT);
@@ -138,11 +150,9 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   constexpr int NVA = BM * BK / 4 / kThreads, NVB = BN * BK / 4 / kThreads;
 
   constexpr int CP = BN + 4;  // padded row of the epilogue's C tile
-  constexpr int LDS_FLOATS = (2 * (A_TILE + B_TILE) > BM * CP) ? 2 * (A_TILE + B_TILE) : BM * CP;
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
-  const int grp = blockIdx.z / b.nsplit;
-  const int split = blockIdx.z - grp * b.nsplit;
+  const int grp = bz / b.nsplit;
+  const int split = bz - grp * b.nsplit;
   // Copy the problem descriptor out of the kernarg segment once: stores to C could
   // alias it as far as the compiler knows, which would force a reload + vmcnt(0)
   // after every store.
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   const int lda = b.p[grp].lda, ldb = b.p[grp].ldb, ldc = b.p[grp].ldc, ldaux = b.p[grp].ldaux;
   const int kps = b.p[grp].k_per_split;
 
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   if (m0 >= M || n0 >= N) return;  // grouped launch: grid is sized for the largest problem
 
   const int kbeg = (LAYOUT == kTN) ? min(K, split * kps) : 0;
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   // K-steps to land (the K loop is unrolled by two so that both sets are static).
   float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
   float csum = 0.f;  // kTN column sums of A (bias gradient), threads tid < BM of n-tile 0
-  const bool do_colsum = (LAYOUT == kTN) && gcolsum != nullptr && blockIdx.x == 0;
+  const bool do_colsum = (LAYOUT == kTN) && gcolsum != nullptr && bx == 0;
 
   // FULL: this block's tiles lie wholly inside A, B (rows and k) — true for every block of
   // the batch shapes the trainer uses; edge blocks take the guarded loads.
@@ -359,6 +369,38 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   if (do_colsum && tid < BM && m0 + tid < M) gcolsum[slab + m0 + tid] = csum;
 }
 
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN>::LDS_FLOATS];
+  gemm_body<LAYOUT, EPI, WM, WN, VEC>(b, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Two independent GEMMs of the projection backward in ONE launch: the split-K dW2/db2 (kTN,
+// 64x64 tiles) and dH = (dOut W2) * [H > 0] (kNN).  Workgroups [0, n_tn) take the TN tiles, the
+// rest the NN tiles (1-D grid, so no empty workgroups); saves a launch, and the two kinds of
+// tile fill each other's ramp-up / ramp-down.
+struct PairGeom {
+  int tn_gx, tn_gy, tn_blocks;  // TN tile grid (x, y) and total TN workgroups (gx*gy*gz)
+  int nn_gx, nn_gy;
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(kThreads) void gemm_tn_nn_kernel(const Batch bt, const Batch bn, const PairGeom g) {
+  constexpr int LT = TileCfg<kTN, 1, 1>::LDS_FLOATS, LN = TileCfg<kNN, WM, WN>::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LT > LN ? LT : LN];
+  int id = blockIdx.x;
+  if (id < g.tn_blocks) {
+    const int per_z = g.tn_gx * g.tn_gy;
+    const int z = id / per_z, rem = id - z * per_z;
+    gemm_body<kTN, kStore, 1, 1, true>(bt, lds, rem % g.tn_gx, rem / g.tn_gx, z);
+  } else {
+    id -= g.tn_blocks;
+    const int per_z = g.nn_gx * g.nn_gy;
+    const int z = id / per_z, rem = id - z * per_z;
+    gemm_body<kNN, kReluMask, WM, WN, true>(bn, lds, rem % g.nn_gx, rem / g.nn_gx, z);
+  }
+}
+
 // VEC requirements of one problem (see gload_kc / gload_ks)
 template <int LAYOUT>
 bool problem_vec_ok(const Problem& p) {
@@ -391,6 +433,34 @@ int launch_le(const Batch& b, int wm, int wn, hipStream_t st) {
 }
 
 }  // namespace
+
+int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStream_t st) {
+  bool vec = true;
+  for (int i = 0; i < bt.count; ++i) vec = vec && (bt.p[i].M == 0 || problem_vec_ok<kTN>(bt.p[i]));
+  for (int i = 0; i < bn.count; ++i) vec = vec && (bn.p[i].M == 0 || problem_vec_ok<kNN>(bn.p[i]));
+  if (!vec || !((wm == 1 && wn == 1) || (wm == 2 && wn == 1))) {  // odd shapes: two ordinary launches
+    int rc = launch(kTN, kStore, bt, 1, 1, st);
+    if (rc != TT_OK) return rc;
+    return launch(kNN, kReluMask, bn, wm, wn, st);
+  }
+  int tM = 0, tN = 0, nM = 0, nN = 0;
+  for (int i = 0; i < bt.count; ++i) { tM = bt.p[i].M > tM ? bt.p[i].M : tM; tN = bt.p[i].N > tN ? bt.p[i].N : tN; }
+  for (int i = 0; i < bn.count; ++i) { nM = bn.p[i].M > nM ? bn.p[i].M : nM; nN = bn.p[i].N > nN ? bn.p[i].N : nN; }
+  if (tM == 0 || tN == 0 || nM == 0 || nN == 0) return TT_ERR_BAD_SHAPE;
+  PairGeom g{};
+  g.tn_gx = (tN + 63) / 64;
+  g.tn_gy = (tM + 63) / 64;
+  g.tn_blocks = g.tn_gx * g.tn_gy * bt.count * bt.nsplit;
+  g.nn_gx = (nN + 64 * wn - 1) / (64 * wn);
+  g.nn_gy = (nM + 64 * wm - 1) / (64 * wm);
+  const long long total = (long long)g.tn_blocks + (long long)g.nn_gx * g.nn_gy * bn.count;
+  if (total > 0x7fffffffLL) return TT_ERR_BAD_SHAPE;
+  const dim3 grid((unsigned)total), block(kThreads);
+  if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1>), grid, block, 0, st, bt, bn, g);
+  else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1>), grid, block, 0, st, bt, bn, g);
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
 
 int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st) {
   if (b.count < 1 || b.count > kMaxGroup || b.nsplit < 1) return TT_ERR_BAD_SHAPE;

@@ -36,6 +36,9 @@ int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab
 // chain, so a caller may run it on another stream):
 int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
 int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, bool low_traffic = false);
+// dW2/db2 and dH as ONE launch (they are independent of each other)
+int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
+                    bool low_traffic = false);
 int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
 
 }  // namespace ttp

@@ -79,6 +79,33 @@ int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, bool lo
   return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st);
 }
 
+int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
+                    bool low_traffic) {
+  ttg::Batch g2{}, gh{};
+  g2.count = gh.count = count;
+  g2.nsplit = nsplit;
+  g2.slab_stride = slab_stride;
+  gh.nsplit = 1;
+  long long rows = 0;
+  for (int i = 0; i < count; ++i) {
+    rows += t[i].M;
+    ttg::Problem& a = g2.p[i];
+    a.A = t[i].dOut; a.B = t[i].H; a.C = t[i].gW2; a.colsum = t[i].gb2;
+    a.M = P; a.N = P; a.K = t[i].M; a.lda = P; a.ldb = P; a.ldc = P; a.k_per_split = k_per_split(t[i].M, nsplit);
+    ttg::Problem& h = gh.p[i];
+    h.A = t[i].dOut; h.B = t[i].W2; h.C = t[i].dH; h.aux = t[i].H;
+    h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
+  }
+  int wm, wn;
+  pick_tile(rows, P, wm, wn, low_traffic);
+  if (wm == 2 && wn == 2) {  // the fused kernel carries 64x64 and 128x64 NN tiles only
+    int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, 1, 1, st);
+    if (rc != TT_OK) return rc;
+    return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st);
+  }
+  return ttg::launch_tn_nn_pair(g2, gh, wm, wn, st);
+}
+
 int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
   ttg::Batch g1{};
   g1.count = count;

@@ -11,16 +11,39 @@ constexpr int kThreads = kWavesPerBlock * TT_WAVE;
 // (normalise each operand by max(|x|, 1e-8), then dot) so that values agree with
 // the reference to rounding; gradient is the closed form checked against
 // autograd in oracle/two_towers_oracle.py::triplet_loss_closed_form.
+// Optional in-launch loss mean ("last workgroup reduces"): every workgroup publishes the sum of its
+// rows' hinges, takes a ticket, and the workgroup that draws the last ticket adds the partials up in
+// a fixed order.  Hand-off in the fence-free form of cdna_hip_programming.md Guideline 16 /
+// MI355X_MICROARCH.md "Valid forms": ONE lane per workgroup stores its 4-byte partial write-through
+// (relaxed agent-scope atomic store = `global_store ... sc1`), drains it (vmcnt(0)), then takes the
+// ticket with a relaxed agent-scope fetch_add; the workgroup whose add returned the last ticket
+// reads every partial with sc1 loads (relaxed agent-scope atomic loads) after a workgroup barrier.
+// No release/acquire fence: a release here would write back the L2 lines of the 9 MB of gradients
+// this same kernel is storing (measured +15 us).  The last workgroup re-zeroes the ticket.
+struct TripletMean {
+  float* partials;       // [gridDim.x]; nullptr = no in-launch mean
+  unsigned* ticket;      // zero before the first launch
+  float denom;
+  float* loss;           // last batch loss
+  double* acc_sum;       // running sum of batch losses (may be null)
+  long long* acc_count;
+};
+
 // NC = ceil(P / 64) columns held per lane (register-resident rows).
 template <int NC>
 __global__ __launch_bounds__(kThreads) void triplet_kernel(
     const float* __restrict__ q, const float* __restrict__ p, const float* __restrict__ n, float margin,
     float grad_scale, long long B, int P, float* __restrict__ pos_dist, float* __restrict__ neg_dist,
     float* __restrict__ hinge_rows, float* __restrict__ dq, float* __restrict__ dp, float* __restrict__ dn,
-    const int* __restrict__ neg_index) {
+    const int* __restrict__ neg_index, const TripletMean mean) {
+  __shared__ float bh[kWavesPerBlock];
+  __shared__ int is_last;
   const int lane = threadIdx.x & (TT_WAVE - 1);
-  const long long row = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (row >= B) return;
+  const int wave = threadIdx.x >> 6;
+  const long long row_raw = (long long)blockIdx.x * kWavesPerBlock + wave;
+  const bool active = row_raw < B;
+  if (!active && !mean.partials) return;
+  const long long row = active ? row_raw : B - 1;  // idle waves of the last workgroup recompute row B-1, store nothing
   const float eps = 1e-8f;
   const long long o = row * (long long)P;
   // in-batch negatives (backend/data.py:113-137): negative i is positive neg_index[i]; `n` then
@@ -55,12 +78,41 @@ __global__ __launch_bounds__(kThreads) void triplet_kernel(
   const float cos_p = tt_wave_sum(dqp), cos_n = tt_wave_sum(dqn);
   const float pd = 1.f - cos_p, nd = 1.f - cos_n;  // model.py:135
   const float hinge = pd - nd + margin;            // model.py:143
-  if (lane == 0) {
+  if (lane == 0 && active) {
     if (pos_dist) pos_dist[row] = pd;
     if (neg_dist) neg_dist[row] = nd;
     hinge_rows[row] = fmaxf(hinge, 0.f);
   }
-  if (!dq) return;
+  if (mean.partials) {
+    if (lane == 0) bh[wave] = active ? fmaxf(hinge, 0.f) : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(mean.partials + blockIdx.x, ((bh[0] + bh[1]) + bh[2]) + bh[3], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(mean.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (is_last) {  // workgroup-uniform; the barrier above orders every wave's loads after the last ticket
+      float s = 0.f;
+      for (unsigned i = threadIdx.x; i < gridDim.x; i += kThreads)
+        s += __hip_atomic_load(mean.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s = tt_wave_sum(s);
+      if (lane == 0) bh[wave] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float l = (((bh[0] + bh[1]) + bh[2]) + bh[3]) / mean.denom;
+        *mean.loss = l;
+        if (mean.acc_sum) {
+          *mean.acc_sum += static_cast<double>(l);
+          *mean.acc_count += 1;
+        }
+        __hip_atomic_store(mean.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  if (!dq || !active) return;
 
   // d cos(a,b)/da = (v - u cos r)/c, r = c/|a| (|a|>0) else 0  (r == 1 unless |a| < eps)
   const float g = hinge > 0.f ? grad_scale : 0.f;
@@ -219,12 +271,15 @@ int tt_launch_loss_mean(const float* hinge_rows, long long B, float denom, float
 // internal: triplet rows only (no mean)
 int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float margin, float grad_scale,
                            long long B, int P, float* pos_dist, float* neg_dist, float* hinge_rows,
-                           float* dq, float* dp, float* dn, const int* neg_index, hipStream_t st) {
+                           float* dq, float* dp, float* dn, const int* neg_index, hipStream_t st,
+                           float* mean_partials = nullptr, unsigned* mean_ticket = nullptr, float mean_denom = 1.f,
+                           float* mean_loss = nullptr, double* acc_sum = nullptr, long long* acc_count = nullptr) {
+  const TripletMean mean{mean_partials, mean_ticket, mean_denom, mean_loss, acc_sum, acc_count};
   const dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
   const int nc = (P + TT_WAVE - 1) / TT_WAVE;
 #define TT_TRIP(NC)                                                                                     \
   hipLaunchKernelGGL(triplet_kernel<NC>, grid, block, 0, st, q, p, n, margin, grad_scale, B, P, pos_dist, \
-                     neg_dist, hinge_rows, dq, dp, dn, neg_index)
+                     neg_dist, hinge_rows, dq, dp, dn, neg_index, mean)
   if (nc <= 1) TT_TRIP(1);
   else if (nc <= 2) TT_TRIP(2);
   else if (nc <= 4) TT_TRIP(4);

@@ -267,6 +267,15 @@ int64_t tt_engine_param_count(const tt_engine* e);
 /* number of split-K gradient slabs the backward writes (>= 1) */
 int tt_engine_grad_slabs(const tt_engine* e);
 
+/*
+ * Host-side hint (no device work): with k1_blocks_per_cu > 0, say whether token-id gathers
+ * (tt_engine_pool on another stream) are actually running beside phase B right now.  Phase B then
+ * picks its backward schedule: second-stream fork (shortest critical path under sharing) or the
+ * fused single-stream form (fewer launches; faster when the chip is otherwise idle, e.g. batches
+ * fed from the frozen-feature cache).  Default: sharing.
+ */
+int tt_engine_set_sharing(tt_engine* e, int gathers_share_chip);
+
 /* Borrow caller-owned device buffers (valid until rebound or destroy). */
 int tt_engine_bind(tt_engine* e, const float* table, float* params, float* exp_avg,
                    float* exp_avg_sq);

@@ -358,7 +358,9 @@ def test_feature_cache_is_bitwise_the_gather(tt):
                        for i in range(4)]
         avg = tr.train_epoch(batches)
         out[mode] = (avg, tr.flat.clone())
-    assert out["ids"][0] == out["cache"][0]
+    # identical pooled inputs -> bit-identical parameters; the logged loss is summed in a different
+    # (fixed) order by the two backward schedules (second-stream fork vs fused, see engine.hip)
+    assert abs(out["ids"][0] - out["cache"][0]) <= 1e-6
     assert torch.equal(out["ids"][1], out["cache"][1])
 
 

@@ -11,7 +11,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtt_hotpath.so")
+# TT_HOTPATH_LIB selects another build of the same ABI (A/B runs of two library versions on one box)
+LIB_PATH = os.environ.get("TT_HOTPATH_LIB") or os.path.join(_HERE, "libtt_hotpath.so")
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "tt_engine_workspace_bytes": (_sz, [C.POINTER(TTEngineConfig)]),
     "tt_engine_create": (_i, [C.POINTER(TTEngineConfig), _vp, _sz, _vp, C.POINTER(_vp)]),
     "tt_engine_destroy": (_i, [_vp]),
+    "tt_engine_set_sharing": (_i, [_vp, _i]),
     "tt_engine_param_count": (_i64, [_vp]),
     "tt_engine_grad_slabs": (_i, [_vp]),
     "tt_engine_bind": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -7,6 +7,7 @@
 //              the positive and negative calls of training.py:41-42 share one GEMM
 //              and their gradients accumulate inside it), K3, K2 bwd     -> grad slabs
 //   adam     : K4, folding the slab sum into the update
+#include <cstdlib>
 #include <new>
 #include "proj.h"
 
@@ -56,6 +57,10 @@ struct tt_engine {
   unsigned* mean_ticket;
   long long* dev_step;  // optimizer steps taken, device copy (tt_engine_adam_auto)
   float* dev_scal;      // {step_size, bc2_sqrt} of the current device step
+  // second stream: dW2/db2 run there, under the dH -> dW1/db1 chain (see backward_chain)
+  hipStream_t aux;
+  hipEvent_t ev_fork, ev_join;
+  bool gathers_share_chip;  // tt_engine_set_sharing: token-id gathers are running beside phase B
 };
 
 namespace {
@@ -142,6 +147,14 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
   }
   e->arena = static_cast<char*>(workspace);
   carve(e, e->arena, &total);
+  // the fork/join stream is optional: without it the backward is one chain on the caller's stream
+  if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) e->aux = nullptr;
+  if (e->aux && (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                 hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)) {
+    (void)hipStreamDestroy(e->aux);
+    e->aux = nullptr;
+  }
+  e->gathers_share_chip = true;
   e->magic = kMagic;
   *out = e;
   return TT_OK;
@@ -149,8 +162,20 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
 
 extern "C" int tt_engine_destroy(tt_engine* e) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  if (e->aux) {
+    (void)hipStreamSynchronize(e->aux);
+    (void)hipEventDestroy(e->ev_fork);
+    (void)hipEventDestroy(e->ev_join);
+    (void)hipStreamDestroy(e->aux);
+  }
   e->magic = 0;
   delete e;
+  return TT_OK;
+}
+
+extern "C" int tt_engine_set_sharing(tt_engine* e, int gathers_share_chip) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  e->gathers_share_chip = gathers_share_chip != 0;
   return TT_OK;
 }
 
@@ -222,21 +247,50 @@ static void fill_towers(tt_engine* e, int slot, int32_t B, int32_t doc_rows, ttp
   }
 }
 
-// Backward chain of phase B: [loss mean] -> one launch for the two independent GEMMs (split-K
-// dW2/db2 and dH) -> dW1/db1.  (An earlier version forked dW2 + the loss mean onto a second
-// stream; the fused launch measured the same step time with 5 fewer host API calls per step.)
+// Backward of phase B.  dW2/db2 and dH are independent; dW1/db1 needs dH.  Two forms, A/B-measured on
+// one box with interleaved runs (TT_BWD=fork|fused overrides the choice):
+//   fork : dW2/db2 and the loss mean on the engine's second stream under the dH -> dW1 chain, joined
+//          before the caller's next stream-ordered call.  Shortest critical path; the default when
+//          the gathers share the chip (k1_blocks_per_cu > 0): 232 vs 248 us per step.  There the
+//          in-launch loss mean also loses (its ticket round trip queues behind the gather's loads).
+//   fused: loss mean inside the triplet launch, ONE launch for dW2/db2 + dH, then dW1: 6 fewer host
+//          API calls per step, 3 % faster when nothing else is on the chip (frozen-feature cache:
+//          125 vs 129 us); the default there.
+static bool use_fork(const tt_engine* e) {
+  bool fork = e->cfg.k1_blocks_per_cu > 0 && e->aux != nullptr && e->gathers_share_chip;
+  if (const char* v = getenv("TT_BWD")) fork = e->aux != nullptr && v[0] == 'f' && v[1] == 'o';
+  return fork;
+}
+
 static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_rows, float loss_denominator,
                           hipStream_t st) {
   const int D = e->cfg.D, P = e->cfg.P;
   const bool shared = e->cfg.k1_blocks_per_cu > 0;  // gathers run beside these kernels on another stream
   int rc;
+  if (!use_fork(e)) {
+    if (loss_rows > 0) {
+      rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
+      if (rc != TT_OK) return rc;
+    }
+    rc = ttp::backward_dw2_dh(t, 2, D, P, e->nslabs, e->slab_stride, st, shared);
+    if (rc != TT_OK) return rc;
+    return ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
+  }
+  TT_HIP(hipEventRecord(e->ev_fork, st));
+  TT_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
   if (loss_rows > 0) {
-    rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
+    rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, e->aux);
     if (rc != TT_OK) return rc;
   }
-  rc = ttp::backward_dw2_dh(t, 2, D, P, e->nslabs, e->slab_stride, st, shared);
+  rc = ttp::backward_dw2(t, 2, D, P, e->nslabs, e->slab_stride, e->aux);
   if (rc != TT_OK) return rc;
-  return ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
+  TT_HIP(hipEventRecord(e->ev_join, e->aux));
+  rc = ttp::backward_dh(t, 2, D, P, st, shared);
+  if (rc != TT_OK) return rc;
+  rc = ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
+  if (rc != TT_OK) return rc;
+  TT_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
+  return TT_OK;
 }
 
 extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_t* neg_index, float margin,
@@ -255,6 +309,12 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
   const float* p = e->emb + (int64_t)B * P;
   // with neg_index the negatives ARE rows of the positives' embeddings (no third encode)
   const float* n = neg_index ? p : e->emb + 2 * (int64_t)B * P;
+  if (use_fork(e)) {  // loss mean as its own launch on the second stream
+    rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
+                                e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st);
+    if (rc != TT_OK) return rc;
+    return backward_chain(e, t, B, loss_denominator, st);
+  }
   // the batch loss is reduced inside the triplet launch (last workgroup), not by a launch of its own
   rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
                               e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st,

@@ -29,8 +29,8 @@ struct TripletMean {
   long long* acc_count;
 };
 
-// NC = ceil(P / 64) columns held per lane (register-resident rows).
-template <int NC>
+// NC = ceil(P / 64) columns held per lane (register-resident rows).  MEAN: in-launch loss mean.
+template <int NC, bool MEAN>
 __global__ __launch_bounds__(kThreads) void triplet_kernel(
     const float* __restrict__ q, const float* __restrict__ p, const float* __restrict__ n, float margin,
     float grad_scale, long long B, int P, float* __restrict__ pos_dist, float* __restrict__ neg_dist,
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kThreads) void triplet_kernel(
   const int wave = threadIdx.x >> 6;
   const long long row_raw = (long long)blockIdx.x * kWavesPerBlock + wave;
   const bool active = row_raw < B;
-  if (!active && !mean.partials) return;
+  if (!MEAN && !active) return;
   const long long row = active ? row_raw : B - 1;  // idle waves of the last workgroup recompute row B-1, store nothing
   const float eps = 1e-8f;
   const long long o = row * (long long)P;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void triplet_kernel(
     if (neg_dist) neg_dist[row] = nd;
     hinge_rows[row] = fmaxf(hinge, 0.f);
   }
-  if (mean.partials) {
+  if (MEAN) {
     if (lane == 0) bh[wave] = active ? fmaxf(hinge, 0.f) : 0.f;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -277,9 +277,15 @@ int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float
   const TripletMean mean{mean_partials, mean_ticket, mean_denom, mean_loss, acc_sum, acc_count};
   const dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
   const int nc = (P + TT_WAVE - 1) / TT_WAVE;
-#define TT_TRIP(NC)                                                                                     \
-  hipLaunchKernelGGL(triplet_kernel<NC>, grid, block, 0, st, q, p, n, margin, grad_scale, B, P, pos_dist, \
-                     neg_dist, hinge_rows, dq, dp, dn, neg_index, mean)
+#define TT_TRIP(NC)                                                                                           \
+  do {                                                                                                        \
+    if (mean_partials)                                                                                        \
+      hipLaunchKernelGGL((triplet_kernel<NC, true>), grid, block, 0, st, q, p, n, margin, grad_scale, B, P,   \
+                         pos_dist, neg_dist, hinge_rows, dq, dp, dn, neg_index, mean);                        \
+    else                                                                                                      \
+      hipLaunchKernelGGL((triplet_kernel<NC, false>), grid, block, 0, st, q, p, n, margin, grad_scale, B, P,  \
+                         pos_dist, neg_dist, hinge_rows, dq, dp, dn, neg_index, mean);                        \
+  } while (0)
   if (nc <= 1) TT_TRIP(1);
   else if (nc <= 2) TT_TRIP(2);
   else if (nc <= 4) TT_TRIP(4);

@@ -127,6 +127,12 @@ class HotPathEngine:
         call("tt_engine_fwd_bwd", self._h, slot, B, ni, margin, (1.0 / B) if grad_scale is None else grad_scale,
              float(B) if loss_denominator is None else loss_denominator, self._stream())
 
+    def set_sharing(self, gathers_share_chip: bool) -> None:
+        """Tell phase B whether token-id gathers are running beside it (picks the backward schedule)."""
+        if getattr(self, "_sharing", None) != bool(gathers_share_chip):
+            call("tt_engine_set_sharing", self._h, int(bool(gathers_share_chip)))
+            self._sharing = bool(gathers_share_chip)
+
     def forward(self, slot: int, B: int, roles: int = 2) -> None:
         """Projection forward only; the embeddings are then in `embeddings(B, roles)`."""
         call("tt_engine_forward", self._h, slot, B, roles, self._stream())

@@ -296,6 +296,8 @@ class TripletTrainer:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
+        if hasattr(self.engine, "set_sharing"):  # a row copy from the cache does not compete with phase B
+            self.engine.set_sharing(batch.cache_rows is None and self.side is not None)
         if batch.cache_rows is not None:
             if self.feature_cache is None:
                 raise RuntimeError("batch carries cache_rows but build_feature_cache() has not been called")

@@ -258,7 +258,8 @@ static void fill_towers(tt_engine* e, int slot, int32_t B, int32_t doc_rows, ttp
 //          125 vs 129 us); the default there.
 static bool use_fork(const tt_engine* e) {
   bool fork = e->cfg.k1_blocks_per_cu > 0 && e->aux != nullptr && e->gathers_share_chip;
-  if (const char* v = getenv("TT_BWD")) fork = e->aux != nullptr && v[0] == 'f' && v[1] == 'o';
+  if (const char* v = getenv("TT_BWD"))  // "fork" / "fused" force a schedule (A/B runs); anything else: automatic
+    if (v[0] == 'f') fork = e->aux != nullptr && v[1] == 'o';
   return fork;
 }
 

@@ -68,13 +68,14 @@ def cpu_baseline(cfg, budget_s=20.0):
     V, D, P, S = cfg["V"], cfg["D"], cfg["P"], cfg["S"]
     B = min(cfg["B"], 2048)
     table = orc.synthetic_table(V, D, seed=1)
+    doc_table = table.clone()  # the reference holds one frozen model per tower (backend/model.py:84-85)
     params = orc.init_params(D, P, seed=2)
     st = orc.AdamState(lr=1e-3)
     batch = orc.synthetic_batch(B, S, V, seed=1234)
-    orc.train_epoch(table, [batch], params, st, 0.3)  # warm-up
+    orc.train_epoch(table, [batch], params, st, 0.3, doc_table=doc_table)  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        orc.train_epoch(table, [batch], params, st, 0.3)
+        orc.train_epoch(table, [batch], params, st, 0.3, doc_table=doc_table)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 64:

@@ -240,29 +240,34 @@ def adam_step(params: dict, grads: dict, st: AdamState) -> None:
         p.addcdiv_(st.m[k], denom, value=-step_size)
 
 
-def loss_and_grads(table, batch, params: dict, margin: float, loss_scale: float = 1.0):
+def loss_and_grads(table, batch, params: dict, margin: float, loss_scale: float = 1.0, doc_table=None):
     """backend/training.py:36-50 without the optimizer: three encodes in the
     reference's order (q, pos, neg), criterion, backward.  `batch` =
     ((ids_q, mask_q), (ids_p, mask_p), (ids_n, mask_n)).
+    `doc_table`: the document tower's own copy of the (identical) frozen table — the reference
+    loads one pretrained model PER tower (backend/model.py:84-85); values are the same, but two
+    46.9 MB tables is what its CPU loop walks, so the timing leg passes a copy here.
     Returns (loss, grads dict, (q_emb, p_emb, n_emb))."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
     (iq, mq), (ip, mp), (i_n, mn) = batch
+    dt = table if doc_table is None else doc_table
     q = encode(table, iq, mq, leaves, "query_tower")
-    p = encode(table, ip, mp, leaves, "document_tower")
-    n = encode(table, i_n, mn, leaves, "document_tower")
+    p = encode(dt, ip, mp, leaves, "document_tower")
+    n = encode(dt, i_n, mn, leaves, "document_tower")
     loss = triplet_loss(q, p, n, margin)
     (loss * loss_scale).backward()
     grads = {k: v.grad.detach() for k, v in leaves.items()}
     return loss.detach(), grads, (q.detach(), p.detach(), n.detach())
 
 
-def train_epoch(table, batches: Iterable, params: dict, st: AdamState, margin: float) -> Tuple[float, List[float]]:
+def train_epoch(table, batches: Iterable, params: dict, st: AdamState, margin: float,
+                doc_table=None) -> Tuple[float, List[float]]:
     """backend/training.py:26-63 (`train_epoch`): per batch zero_grad -> 3 encodes
     -> loss -> backward -> Adam step; returns mean of per-batch losses (and the trace).
     `params` is updated in place."""
     total, trace = 0.0, []
     for batch in batches:
-        loss, grads, _ = loss_and_grads(table, batch, params, margin)
+        loss, grads, _ = loss_and_grads(table, batch, params, margin, doc_table=doc_table)
         adam_step(params, grads, st)
         total += loss.item()
         trace.append(loss.item())

@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default: the config's)")
     ap.add_argument("--zipf", action="store_true", help="Zipf(1) token ids instead of uniform")
+    ap.add_argument("--ragged", action="store_true",
+                    help="ragged prefix lengths (queries U{8..S}, documents U{32..S}; SURVEY.md §8d) instead of full length")
     ap.add_argument("--k1-only", action="store_true", help="time only the gather+pool kernel (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
@@ -162,6 +164,13 @@ def main():
     n_distinct = 8
     id_batches = make_ids(V, B, S, n_distinct, seed=1234 + rank, device=device, zipf=args.zipf)
     batches = [(ids, None, None) for ids in id_batches]  # full-length: no mask, no lens
+    valid_tokens = 3 * B * S
+    if args.ragged:
+        gl = torch.Generator().manual_seed(4321 + rank)
+        lens_list = [torch.stack([torch.randint(8, S + 1, (B,), generator=gl), torch.randint(min(32, S), S + 1, (B,), generator=gl),
+                                  torch.randint(min(32, S), S + 1, (B,), generator=gl)]).int() for _ in range(n_distinct)]
+        valid_tokens = sum(int(l.sum()) for l in lens_list) / n_distinct
+        batches = [(ids, None, l.to(device)) for ids, l in zip(id_batches, lens_list)]
     if args.loss == "inbatch":
         from two_towers_overlords_amd.training import TripletBatch
 
@@ -232,13 +241,16 @@ def main():
     iso_ev = []
     for i in range(20):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); trainer.engine.pool(i & 1, id_batches[i % n_distinct], None, None); e1.record()
+        bb = batches[i % n_distinct] if (args.ragged and args.inputs == "ids3") else (id_batches[i % n_distinct], None, None)
+        e0.record(); trainer.engine.pool(i & 1, bb[0], None, bb[2]); e1.record()
         iso_ev.append((e0, e1))
     torch.cuda.synchronize(device)
     iso_ms = sum(a.elapsed_time(b) for a, b in iso_ev[4:]) / len(iso_ev[4:])
     k1_ms = sum(a.elapsed_time(b) for a, b in k1_ev) / max(len(k1_ev), 1)
     roles = 3 if args.inputs == "ids3" else 2
     alg = k1_algorithmic_bytes(roles * B, S, D)
+    if args.ragged and args.inputs == "ids3":  # n_valid*D*4 + S*4 + D*4 per text with the actual lengths
+        alg = int(valid_tokens * D * 4 + roles * B * (S * 4 + D * 4))
     traffic = None  # HBM-side bytes per K1 launch from the committed PMC passes of this same workload, if any
     tpath = os.path.join(ROOT, "profiles", f"r01_k1_traffic_{args.config}.json")
     if os.path.exists(tpath) and not args.zipf:
@@ -259,7 +271,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["label"], "encoder_mode": "embed", "vocab": V, "embed_dim": D, "proj_dim": P,
                    "seq_len": S, "batch_per_gpu": B, "global_batch": B * world, "ids": "int32 [3,B,S], "
-                   + ("zipf" if args.zipf else "uniform") + ", full length", "parallelism": f"dp{world}", "inputs": args.inputs,
+                   + ("zipf" if args.zipf else "uniform") + (", ragged lengths" if args.ragged else ", full length"), "parallelism": f"dp{world}", "inputs": args.inputs,
                    "k1_only": bool(args.k1_only),
                    "gather_overlap": "side stream, K1 capped at %d workgroups/CU" % (trainer.engine_k1_cap)
                    if trainer.side is not None else "none (same stream)",

@@ -253,3 +253,25 @@ def test_run_training_end_to_end_with_cache_and_eval():
                          pretrained_model=EmbeddingOnlyEncoder(table), seed=5, feature_cache=cache)
         out[cache] = torch.cat([p.detach().reshape(-1).cpu() for p in m.trainable_parameters()])
     assert (out[True] - out[False]).abs().max() <= 2e-5  # 3 epochs x 4 steps of Adam at lr 1e-2
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_training_is_bitwise_reproducible(overlap):
+    """No float atomics anywhere on the path (split-K slabs, fixed-order reductions): two runs of the
+    same epochs give bit-identical parameters and losses, with or without the gather side stream."""
+    from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
+
+    V, D, P, B, S = 5000, 384, 128, 256, 64
+    table = orc.synthetic_table(V, D, seed=1) * 30
+    params = orc.init_params(D, P, seed=2)
+    batches = [orc.synthetic_batch(B, S, V, seed=500 + i, ragged=True) for i in range(6)]
+    dev = [TripletBatch(ids=torch.stack([r[0] for r in b]).int().cuda(),
+                        lens=torch.stack([r[1].sum(1) for r in b]).int().cuda()) for b in batches]
+    runs = []
+    for _ in range(2):
+        tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B,
+                            max_seq_len=S, margin=0.3, lr=1e-3, overlap_streams=overlap)
+        losses = [tr.train_epoch(dev) for _ in range(3)]
+        runs.append((losses, tr.flat.clone()))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])

@@ -86,6 +86,24 @@ int tt_gather_pool_norm_f32(const float* table, const void* ids, int ids_dtype,
                             int32_t* oob_flag, tt_stream_t stream);
 
 /*
+ * XCD-sliced form of tt_gather_pool_norm_f32 (same arguments, same result to fp32 summation order):
+ * workgroups that share an XCD gather only token ids of one residue class mod 8, so each XCD's L2
+ * serves one eighth of the table; per-slice partial sums meet in `workspace`
+ * (tt_gather_pool_sliced_workspace_bytes(N, D) bytes, 16-byte aligned) and a second launch adds them
+ * in slice order, divides and normalises.  Requires D % 4 == 0, D <= 1024, S <= 512.  Faster than
+ * the per-text form when the table is far larger than one L2 (4 MiB) — BERT-sized vocabularies.
+ */
+size_t tt_gather_pool_sliced_workspace_bytes(int64_t N, int D);
+/* 1 if the sliced form is the faster one for this shape on MI355X (host-side rule from measurements;
+ * tt_engine_pool applies it by itself). */
+int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S);
+int tt_gather_pool_norm_sliced_f32(const float* table, const void* ids, int ids_dtype,
+                                   const void* mask, int mask_dtype, const int32_t* lens,
+                                   float* out, int64_t N, int S, int D, int64_t V,
+                                   int32_t* oob_flag, void* workspace, size_t workspace_bytes,
+                                   tt_stream_t stream);
+
+/*
  * Same pooling + normalisation over dense hidden states [N,S,D] (the `bert`
  * encoder mode: the frozen encoder of backend/model.py:51-52 is run by stock
  * PyTorch-ROCm, its last_hidden_state is pooled here).  Replaces

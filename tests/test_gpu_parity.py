@@ -112,6 +112,61 @@ def test_pool_vs_oracle_shapes(tt, D, S, V, N):
     close(ops.pool_norm_dense(hidden.cuda(), mask.cuda()), ref)
 
 
+@pytest.mark.parametrize("D,S,V,N", [(384, 128, 30522, 301), (768, 256, 5000, 67), (64, 7, 100, 5), (1024, 33, 777, 9),
+                                     (384, 512, 30522, 13), (8, 300, 40, 3), (128, 64, 5, 6), (384, 128, 30522, 5000)])
+def test_pool_sliced_vs_oracle_shapes(tt, D, S, V, N):
+    """XCD-sliced K1 (tt_gather_pool_norm_sliced_f32): same contract as the per-text form — masks with holes,
+    prefix lengths (incl. 0), both index widths, all-ones, vocabularies smaller than the slice count."""
+    ops, _ = tt
+    gen = torch.Generator().manual_seed(D + S + 1)
+    table = torch.randn(V, D, generator=gen)
+    ids = torch.randint(0, V, (N, S), generator=gen)
+    lens = torch.randint(0, S + 1, (N,), generator=gen)
+    lens[0] = S
+    lens[-1] = 0
+    mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+    ref = orc.gather_pool_normalize(table, ids, mask)
+    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), mask.cuda(), check_ids=True, sliced=True), ref)
+    close(ops.gather_pool_norm(table.cuda(), ids.int().cuda(), lens=lens.int().cuda(), sliced=True), ref)
+    close(ops.gather_pool_norm(table.cuda(), ids.int().cuda(), mask.int().cuda(), sliced=True), ref)
+    holey = (torch.rand(N, S, generator=gen) < 0.6).long()
+    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), holey.cuda(), sliced=True),
+          orc.gather_pool_normalize(table, ids, holey))
+    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), sliced=True), orc.gather_pool_normalize(table, ids, torch.ones_like(ids)))
+    # the two forms differ only in fp32 summation order
+    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), holey.cuda(), sliced=True),
+          ops.gather_pool_norm(table.cuda(), ids.cuda(), holey.cuda()), atol=1e-6)
+
+
+def test_pool_sliced_golden_and_flags(tt):
+    ops, _ = tt
+    g = load_golden("pool_edges.npz")
+    table, ids, mask = dev(g["table"]), dev(g["ids"]), dev(g["mask"])
+    out = ops.gather_pool_norm(table, ids, mask, check_ids=True, sliced=True)
+    close(out, g["out"])
+    assert torch.all(out[2] == 0)  # all-padding row
+    for name in ("kat0.npz", "step_d384.npz"):
+        g = load_golden(name)
+        for r in "qpn":
+            close(ops.gather_pool_norm(dev(g["table"]), dev(g[f"batch0/ids_{r}"]), dev(g[f"batch0/mask_{r}"]), sliced=True),
+                  g[f"fwd/pooled_{r}"])
+    t = torch.randn(10, 8).cuda()
+    bad = torch.tensor([[1, 2, 99], [3, -4, 5]]).cuda()
+    with pytest.raises(IndexError):
+        ops.gather_pool_norm(t, bad, check_ids=True, sliced=True)
+    m = torch.tensor([[1, 1, 0], [1, 0, 1]]).cuda()  # the out-of-range ids are masked out: no flag, no read
+    close(ops.gather_pool_norm(t, bad, m, check_ids=True, sliced=True),
+          orc.gather_pool_normalize(t.cpu(), bad.cpu().clamp(0, 9), m.cpu()))
+    # one-hot table: the pooled sum is the histogram of the unmasked ids
+    V = 256
+    gen = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, V, (37, 50), generator=gen)
+    lens = torch.randint(1, 51, (37,), generator=gen)
+    out = ops.gather_pool_norm(torch.eye(V).cuda(), ids.int().cuda(), lens=lens.int().cuda(), sliced=True).cpu()
+    hist = torch.stack([torch.bincount(ids[b, : lens[b]], minlength=V).float() for b in range(37)])
+    assert torch.equal(out != 0, hist != 0)
+
+
 def test_pool_out_of_range_id_is_flagged_not_read(tt):
     ops, _ = tt
     table = torch.randn(10, 8).cuda()
@@ -266,22 +321,48 @@ def test_engine_matches_reference_golden(tt, name):
     eng.close()
 
 
+def _relu_kink_mask(table, batch, params, D, P, near=2e-7):
+    """Elements of the flat gradient that depend on a hidden unit whose pre-activation is within `near` of
+    the ReLU kink for some row of this batch: there d relu/dx flips on a 1e-8 reassociation difference, so
+    row j of dW1 and db1[j] of that tower are not comparable (a measure-zero discontinuity, not an error)."""
+    from two_towers_overlords_amd.engine import flat_param_slices
+
+    mask = torch.zeros(sum(int(np.prod(sh)) for _, _, sh in flat_param_slices(D, P)), dtype=torch.bool)
+    offs = {name: (off, shape) for name, off, shape in flat_param_slices(D, P)}
+    for tower, roles in (("query_tower", [0]), ("document_tower", [1, 2])):
+        W1, b1 = params[f"{tower}.projection.0.weight"].double(), params[f"{tower}.projection.0.bias"].double()
+        units = torch.zeros(P, dtype=torch.bool)
+        for r in roles:
+            x = orc.gather_pool_normalize(table, batch[r][0], batch[r][1]).double()
+            units |= ((x @ W1.T + b1).abs() < near).any(0)
+        ow, _ = offs[f"{tower}.projection.0.weight"]
+        ob, _ = offs[f"{tower}.projection.0.bias"]
+        for u in units.nonzero().flatten().tolist():
+            mask[ow + u * D: ow + (u + 1) * D] = True
+            mask[ob + u] = True
+    return mask
+
+
 def test_engine_vs_oracle_metric_shape(tt):
-    """BASELINE metric shape (S=128, D=384, P=384) at a batch the oracle finishes in seconds,
-    int32 ids + prefix lengths, three optimizer steps."""
+    """BASELINE metric shape (V=30522, S=128, D=384, P=384) at a batch the oracle finishes in seconds, int32
+    ids + prefix lengths, three optimizer steps.  Every step is checked from the engine's own state (the
+    oracle is given the engine's parameters and Adam moments), so one step's rounding cannot leak into the
+    next step's comparison."""
     _, engine = tt
     V, D, P, B, S = 30522, 384, 384, 256, 128
     table = orc.synthetic_table(V, D, seed=1)
-    params = orc.init_params(D, P, seed=2)
     batches = [orc.synthetic_batch(B, S, V, seed=50 + i, ragged=True) for i in range(3)]
     eng = engine.HotPathEngine(table.cuda(), P, B, S)
-    flat = _flat(params).cuda()
+    flat = _flat(orc.init_params(D, P, seed=2)).cuda()
     m, v = torch.zeros_like(flat), torch.zeros_like(flat)
     eng.bind(flat, m, v)
-    st = orc.AdamState(lr=1e-3)
+    n_kink = 0
     for i, batch in enumerate(batches):
         ids = torch.stack([b[0] for b in batch]).int().cuda()
         lens = torch.stack([b[1].sum(1) for b in batch]).int().cuda()
+        params = {k: t.clone() for k, t in _unflat(flat.cpu(), D, P).items()}
+        st = orc.AdamState(lr=1e-3, step=i, m={k: t.clone() for k, t in _unflat(m.cpu(), D, P).items()},
+                           v={k: t.clone() for k, t in _unflat(v.cpu(), D, P).items()})
         loss, grads, embs = orc.loss_and_grads(table, batch, params, 0.3)
         eng.pool(0, ids, lens=lens)
         eng.fwd_bwd(0, B, 0.3)
@@ -289,13 +370,16 @@ def test_engine_vs_oracle_metric_shape(tt):
             close(eng.embeddings(B)[j], embs[j])
         gflat = torch.empty_like(flat)
         eng.reduce_grads(gflat)
-        close(gflat, _flat(grads), rel_to_max=True)
+        kink = _relu_kink_mask(table, batch, params, D, P)
+        n_kink += int(kink.sum())
+        close(torch.where(kink, 0.0, gflat.cpu()), torch.where(kink, 0.0, _flat(grads)), atol=1e-6)
         eng.adam(i + 1, 1e-3)
         orc.adam_step(params, grads, st)
         _, _, last = eng.read_stats()
         assert abs(last - loss.item()) <= TOL
-    for k, pt in _unflat(flat, D, P).items():
-        assert_params_close(pt.cpu().numpy(), params[k].numpy(), 1e-3, 3)
+        keep = ~kink.numpy()
+        assert_params_close(flat.cpu().numpy()[keep], _flat(params).numpy()[keep], 1e-3, 1)
+    assert n_kink <= 12 * (D + 1)  # the exclusion stays a handful of units out of 3 steps x 2 towers x 384
     eng.close()
 
 

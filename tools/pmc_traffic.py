@@ -13,12 +13,19 @@ import sys
 
 
 def per_launch(dirname, counter, kernel_substr):
-    vals = []
+    """Counter values of the launches whose kernel name contains `kernel_substr`; with several
+    comma-separated substrings (a K1 made of two launches) the i-th launches of each are added."""
+    names = kernel_substr.split(",")
+    vals = {n: [] for n in names}
     for f in glob.glob(f"{dirname}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and kernel_substr in r["Kernel_Name"]:
-                vals.append(float(r["Counter_Value"]))
-    return vals
+            if r["Counter_Name"] != counter:
+                continue
+            for n in names:
+                if n in r["Kernel_Name"]:
+                    vals[n].append(float(r["Counter_Value"]))
+    k = min(len(v) for v in vals.values())
+    return [sum(vals[n][i] for n in names) for i in range(k)]
 
 
 def main():

@@ -50,6 +50,9 @@ SIGNATURES = {
     "tt_abi_version": (_i, []),
     "tt_status_string": (C.c_char_p, [_i]),
     "tt_gather_pool_norm_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp]),
+    "tt_gather_pool_sliced_workspace_bytes": (_sz, [_i64, _i]),
+    "tt_k1_prefers_sliced": (_i, [_i64, _i, _i64, _i]),
+    "tt_gather_pool_norm_sliced_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "tt_pool_norm_dense_f32": (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _i, _vp]),
     "tt_embed_gather_f32": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _vp]),
     "tt_proj_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),

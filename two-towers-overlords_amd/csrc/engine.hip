@@ -14,6 +14,10 @@
 int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                  const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
                  int blocks_per_cu, hipStream_t st);
+int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                        const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                        void* workspace, size_t workspace_bytes, int blocks_per_cu, hipStream_t st);
+int tt_k1_sliced_supported(int S, int D, const float* table, const float* out);
 int tt_launch_adam_auto(float* params, const float* grads, int nslabs, long long slab_stride, float* exp_avg,
                         float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
                         long long* dev_step, float* dev_scal, hipStream_t st);
@@ -41,6 +45,8 @@ struct tt_engine {
   // carved out of the caller's workspace
   char* arena;
   float* pooled[TT_ENGINE_SLOTS];
+  float* k1_partial[TT_ENGINE_SLOTS];  // XCD-sliced K1: per-slice partial sums + mask sums of one batch
+  size_t k1_partial_bytes;
   float* H;
   float* emb;
   float* dOut;
@@ -83,6 +89,8 @@ void carve(tt_engine* e, char* base, size_t* total) {
   Carver c{base};
   const size_t rows = 3 * (size_t)e->cfg.max_B;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->pooled[i] = c.take<float>(rows * e->cfg.D);
+  e->k1_partial_bytes = tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D);
+  for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->k1_partial[i] = c.take<float>(e->k1_partial_bytes / sizeof(float));
   e->H = c.take<float>(rows * e->cfg.P);
   e->emb = c.take<float>(rows * e->cfg.P);
   e->dOut = c.take<float>(rows * e->cfg.P);
@@ -207,6 +215,12 @@ extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_d
   TT_REQUIRE(e->table, TT_ERR_NULL_POINTER);
   TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (roles == 2 || roles == 3), TT_ERR_BAD_SHAPE);
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && S >= 1 && S <= e->cfg.max_S, TT_ERR_BAD_SHAPE);
+  // XCD-sliced form where it is the faster one (table several times an XCD's L2, see tt_k1_prefers_sliced)
+  if (tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, roles * (int64_t)B, S) &&
+      tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]))
+    return tt_k1_sliced_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B,
+                               S, e->cfg.D, e->cfg.V, e->oob, e->k1_partial[slot], e->k1_partial_bytes,
+                               e->cfg.k1_blocks_per_cu, static_cast<hipStream_t>(stream));
   return tt_k1_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B, S,
                       e->cfg.D, e->cfg.V, e->oob, e->cfg.k1_blocks_per_cu, static_cast<hipStream_t>(stream));
 }

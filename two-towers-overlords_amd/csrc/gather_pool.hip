@@ -214,6 +214,193 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// XCD-sliced K1.  A 30522 x 384 fp32 table is 47 MB: 12x an XCD's 4 MiB L2, so the per-text kernel
+// above is served by the Infinity Cache (~8.6 TB/s, MI355X_MICROARCH.md "Indexed rows").  Workgroups
+// with equal blockIdx % 8 share an XCD (placement label: speed only, never correctness), so here
+// workgroup b gathers only the tokens whose id % NS == b % NS: every XCD then re-reads one 1/NS
+// slice of the table (5.9 MB at NS = 8) and most row reads hit its own L2.
+//
+// Persistent: the grid is NS x G workgroups (G chosen from the CU count and the residency wanted),
+// wave w of workgroup (slice, g) walks texts g*4+w, +4G, +8G, ...  One (text, slice) step: the ids /
+// mask of the NEXT text are loaded into registers first (their latency hides under this text's
+// rows), this text's selected (id, weight) list — compacted into LDS one step earlier — is gathered
+// U rows at a time, the slice's partial sum [D] goes to a workspace, then the next text's list is
+// compacted.  A second launch adds a text's NS partials in slice order (fixed order: bitwise
+// reproducible), divides by the mask sum and L2-normalises.  Costs N*NS*D*4 bytes written + read.
+template <typename IdT, typename MaskT, int C, int U, int NPH, int MAXSEG>
+__global__ __launch_bounds__(kThreads) void pool_sliced_kernel(
+    const float* __restrict__ table, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
+    const int* __restrict__ lens, float* __restrict__ partial, float* __restrict__ wsum_out, long long N,
+    int S, int D, long long V, int* __restrict__ oob_flag) {
+  extern __shared__ int sliced_lds[];  // per wave: 2 x ([S] ids + [S] weights)
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  // NS = 8 * NPH residue classes; the grid is NPH phases of (8 x G) workgroups, dispatched in order, so at any
+  // time an XCD works on ONE class (phase * 8 + its blockIdx % 8 label): 1/NS of the table in its L2
+  constexpr int NS = 8 * NPH;
+  const unsigned per_phase = gridDim.x / NPH;
+  const int slice = (int)(blockIdx.x / per_phase) * 8 + (int)(blockIdx.x % 8);
+  const unsigned within = blockIdx.x % per_phase;
+  const long long tstride = (long long)(per_phase / 8) * kWavesPerText;
+  long long text = (long long)(within / 8) * kWavesPerText + wave;
+  if (text >= N) return;  // wave-uniform; no workgroup barrier anywhere below
+  int* const lbase = sliced_lds + wave * (4 * S);
+  const int nchunk = D >> 2;
+  const bool last_ok = (C - 1) * TT_WAVE + lane < nchunk;
+
+  IdT idr[MAXSEG];
+  MaskT mr[MAXSEG];
+  int len_r = S;
+
+  // registers <- ids / mask of text t (loads only; nothing waits on them here)
+  auto fetch = [&](long long t) {
+    len_r = lens ? lens[t] : S;
+    const long long tb = t * (long long)S;
+#pragma unroll
+    for (int k = 0; k < MAXSEG; ++k) {
+      const int tok = k * TT_WAVE + lane;
+      idr[k] = 0;
+      mr[k] = 0;
+      if (tok < S) {
+        idr[k] = ids[tb + tok];
+        if (mask) mr[k] = mask[tb + tok];
+      }
+    }
+  };
+  // registers -> compacted (id, weight) list of this slice in LDS buffer `buf`; returns the count
+  auto compact = [&](int buf, float& wtot) -> int {
+    int* __restrict__ lid = lbase + buf * (2 * S);
+    float* __restrict__ lw = reinterpret_cast<float*>(lid + S);
+    int n = 0;
+    wtot = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXSEG; ++k) {
+      const int tok = k * TT_WAVE + lane;
+      float w = 0.f;
+      int id = 0;
+      if (tok < S) {
+        w = mask ? static_cast<float>(mr[k]) : (tok < len_r ? 1.f : 0.f);
+        const long long raw = static_cast<long long>(idr[k]);
+        if (raw < 0 || raw >= V) {
+          if (w != 0.f && oob_flag) atomicOr(oob_flag, 1);
+          id = raw < 0 ? 0 : static_cast<int>(V - 1);
+        } else {
+          id = static_cast<int>(raw);
+        }
+      }
+      wtot += w;
+      const bool sel = (w != 0.f) && (id % NS == slice);
+      const unsigned long long m = __ballot(sel);
+      if (sel) {
+        const int at = n + __popcll(m & ((1ULL << lane) - 1ULL));
+        lid[at] = id;
+        lw[at] = w;
+      }
+      n += __popcll(m);
+    }
+    return n;  // the list is written and read by this wave only: LDS ops of one wave complete in order
+  };
+
+  float wtot = 0.f;
+  fetch(text);
+  int n = compact(0, wtot);
+  int buf = 0;
+  while (true) {
+    const long long tnext = text + tstride;
+    if (tnext < N) fetch(tnext);
+
+    const int* __restrict__ lid = lbase + buf * (2 * S);
+    const float* __restrict__ lw = reinterpret_cast<const float*>(lid + S);
+    float4 acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = f4_zero();
+    for (int base = 0; base < n; base += TT_WAVE) {
+      const int have = min(n - base, TT_WAVE);
+      int id = 0;
+      float w = 0.f;
+      if (lane < have) {
+        id = lid[base + lane];
+        w = lw[base + lane];
+      }
+      unsigned long long mine = have == TT_WAVE ? ~0ULL : ((1ULL << have) - 1ULL);
+      int cnt = have;
+      while (cnt >= U) {
+        pool_group<U, C, false>(mine, table, id, w, 0, D, lane, last_ok, acc);
+        cnt -= U;
+      }
+      if (U > 8 && cnt >= 8) {
+        pool_group<8, C, false>(mine, table, id, w, 0, D, lane, last_ok, acc);
+        cnt -= 8;
+      }
+      if (U > 4 && cnt >= 4) {
+        pool_group<4, C, false>(mine, table, id, w, 0, D, lane, last_ok, acc);
+        cnt -= 4;
+      }
+      if (U > 2 && cnt >= 2) {
+        pool_group<2, C, false>(mine, table, id, w, 0, D, lane, last_ok, acc);
+        cnt -= 2;
+      }
+      if (cnt >= 1) pool_group<1, C, false>(mine, table, id, w, 0, D, lane, last_ok, acc);
+    }
+
+    // (storing the partials `sc1`, so that they leave this XCD's L2 to the table slice, measured 3 % alone and
+    // 1 % in the step: not worth hand-written store instructions)
+    float4* __restrict__ pp = reinterpret_cast<float4*>(partial + (text * NS + slice) * (long long)D);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      if (c < C - 1 || last_ok) pp[c * TT_WAVE + lane] = acc[c];
+    if (slice == 0) {
+      const float ws = tt_wave_sum(wtot);
+      if (lane == 0) wsum_out[text] = ws;
+    }
+    if (tnext >= N) break;
+    buf ^= 1;
+    n = compact(buf, wtot);
+    text = tnext;
+  }
+}
+
+// One wave per text: partials summed in slice order, mean (clamp 1e-9), L2 normalise (clamp 1e-12).
+template <int C, int NS>
+__global__ __launch_bounds__(kThreads) void pool_combine_kernel(const float* __restrict__ partial,
+                                                                const float* __restrict__ wsum,
+                                                                float* __restrict__ out, long long N, int D) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const long long text = (long long)blockIdx.x * kWavesPerText + (threadIdx.x >> 6);
+  if (text >= N) return;
+  const int nchunk = D >> 2;
+  const bool last_ok = (C - 1) * TT_WAVE + lane < nchunk;
+  const float den = fmaxf(wsum[text], 1e-9f);
+  const float4* __restrict__ pp = reinterpret_cast<const float4*>(partial + text * NS * (long long)D);
+  float4 m[C];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    m[c] = f4_zero();
+    if (c < C - 1 || last_ok) {
+      float4 r[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) r[s] = pp[s * nchunk + c * TT_WAVE + lane];
+      float4 a = r[0];
+#pragma unroll
+      for (int s = 1; s < NS; ++s) {
+        a.x += r[s].x;
+        a.y += r[s].y;
+        a.z += r[s].z;
+        a.w += r[s].w;
+      }
+      m[c] = make_float4(a.x / den, a.y / den, a.z / den, a.w / den);
+      ss = fmaf(m[c].x, m[c].x, fmaf(m[c].y, m[c].y, fmaf(m[c].z, m[c].z, fmaf(m[c].w, m[c].w, ss))));
+    }
+  }
+  const float dn = fmaxf(sqrtf(tt_wave_sum(ss)), 1e-12f);
+  float4* __restrict__ op = reinterpret_cast<float4*>(out + text * (long long)D);
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+    if (c < C - 1 || last_ok) op[c * TT_WAVE + lane] = make_float4(m[c].x / dn, m[c].y / dn, m[c].z / dn, m[c].w / dn);
+}
+
 // Any D (not a multiple of 4, or > 1024, or unaligned): correct, not fast.
 template <typename IdT, typename MaskT, bool DENSE>
 __global__ __launch_bounds__(kThreads) void pool_norm_generic_kernel(
@@ -349,6 +536,72 @@ int dispatch_pool(const float* src, const void* ids, int ids_dtype, const void* 
   return TT_ERR_BAD_DTYPE;
 }
 
+constexpr int kPhases = 1;
+constexpr int kSlices = 8 * kPhases;
+constexpr int kSlicedMaxS = 512;
+
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
+}
+
+template <typename IdT, typename MaskT>
+int launch_sliced(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
+                  int S, int D, int64_t V, int32_t* oob, float* ws, int blocks_per_cu, hipStream_t st) {
+  const IdT* ids_t = static_cast<const IdT*>(ids);
+  const MaskT* mask_t = static_cast<const MaskT*>(mask);
+  float* partial = ws;
+  float* wsum = ws + (size_t)N * kSlices * D;
+  const long long groups_all = (N + kWavesPerText - 1) / kWavesPerText;
+  // Default: one workgroup per (4 texts, slice), residency capped through dynamic LDS like the per-text
+  // form.  TT_K1_SLICED_BPC=n (A/B) makes the grid persistent instead: n workgroups per CU walking the
+  // texts — within 5 % alone, 4 % slower beside the projection kernels (213-216 vs 205 us per step).
+  static const int persist_bpc = getenv("TT_K1_SLICED_BPC") ? atoi(getenv("TT_K1_SLICED_BPC")) : 0;
+  long long G = groups_all;
+  unsigned lds = (unsigned)(4 * kWavesPerText * S * sizeof(int));
+  if (persist_bpc > 0) {
+    G = (long long)cu_count() * persist_bpc / 8;
+    if (G > groups_all) G = groups_all;
+    if (G < 1) G = 1;
+  } else {
+    const unsigned cap = k1_dynamic_lds(blocks_per_cu, 0);
+    if (cap > lds) lds = cap;
+  }
+  const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
+  const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
+#define TT_SLICED_LAUNCH(CC, UU, MS)                                                                          \
+  hipLaunchKernelGGL((pool_sliced_kernel<IdT, MaskT, CC, UU, kPhases, MS>), dim3((unsigned)(G * kSlices)),     \
+                     dim3(kThreads), lds, st, table, ids_t, mask_t, lens, partial, wsum, (long long)N, S, D,   \
+                     (long long)V, oob)
+#define TT_SLICED_CASE(CC, UU)                  \
+  do {                                          \
+    if (nseg <= 2) TT_SLICED_LAUNCH(CC, UU, 2); \
+    else if (nseg <= 4) TT_SLICED_LAUNCH(CC, UU, 4); \
+    else TT_SLICED_LAUNCH(CC, UU, 8);           \
+    TT_CHECK_LAUNCH();                          \
+    hipLaunchKernelGGL((pool_combine_kernel<CC, kSlices>), dim3((unsigned)groups_all), dim3(kThreads), 0, st, \
+                       partial, wsum, out, (long long)N, D); \
+  } while (0)
+  switch (C) {
+    case 1: TT_SLICED_CASE(1, 8); break;
+    case 2: TT_SLICED_CASE(2, 8); break;
+    case 3: TT_SLICED_CASE(3, 4); break;
+    default: TT_SLICED_CASE(4, 4); break;
+  }
+#undef TT_SLICED_CASE
+#undef TT_SLICED_LAUNCH
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
 }  // namespace
 
 // internal (engine.hip): K1 with a residency cap (0 = none)
@@ -404,4 +657,54 @@ extern "C" int tt_embed_gather_f32(const float* table, const void* ids, int ids_
   }
   TT_CHECK_LAUNCH();
   return TT_OK;
+}
+
+extern "C" size_t tt_gather_pool_sliced_workspace_bytes(int64_t N, int D) {
+  if (N <= 0 || D <= 0) return 0;
+  return ((size_t)N * kSlices * (size_t)D + (size_t)N) * sizeof(float);
+}
+
+// internal (engine.hip) + public: the XCD-sliced form.  Same contract as tt_gather_pool_norm_f32.
+int tt_k1_sliced_supported(int S, int D, const float* table, const float* out) {
+  return (D % 4 == 0) && D <= 1024 && S <= kSlicedMaxS && tt_aligned16(table) && tt_aligned16(out);
+}
+
+// Measured on MI355X (tools/k1_sliced_ab.py, D = 384, N = 6144 texts): the sliced form wins when the
+// table is well beyond one XCD's 4 MiB L2 but a slice still mostly fits (15 MB table: 121 -> 77 us,
+// 47 MB: 153 -> 96 us; 7.7 MB and 184 MB: equal; 3 MB: 55 vs 83 us), the texts are long enough to
+// leave each slice a few rows (S = 32: 41 vs 55 us) and there are enough of them to amortise the
+// second launch (512 texts: equal).  TT_K1_SLICED=0/1 overrides (A/B runs).
+extern "C" int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S) {
+  if (D < 4 || (D % 4) != 0 || D > 1024 || S > kSlicedMaxS || S < 1 || V < 1 || N < 1) return 0;
+  if (const char* v = getenv("TT_K1_SLICED"))
+    if (*v) return *v != '0';
+  const double table_bytes = (double)V * D * 4.0;
+  return table_bytes >= 10e6 && table_bytes <= 128e6 && S >= 48 && (double)N * S >= 131072.0;
+}
+
+// internal (engine.hip): sliced K1 with a residency cap (0 = none)
+int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                        const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                        void* workspace, size_t workspace_bytes, int blocks_per_cu, hipStream_t st) {
+  TT_REQUIRE(table && ids && out && workspace, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x0fffffffLL, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  TT_REQUIRE(tt_k1_sliced_supported(S, D, table, out) && tt_aligned16(workspace), TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(workspace_bytes >= tt_gather_pool_sliced_workspace_bytes(N, D), TT_ERR_WORKSPACE);
+  if (N == 0) return TT_OK;
+  float* ws = static_cast<float*>(workspace);
+  const int md = mask ? mask_dtype : TT_I32;
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_sliced<int32_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, blocks_per_cu, st);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_sliced<int32_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, blocks_per_cu, st);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_sliced<int64_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, blocks_per_cu, st);
+  return launch_sliced<int64_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, blocks_per_cu, st);
+}
+
+extern "C" int tt_gather_pool_norm_sliced_f32(const float* table, const void* ids, int ids_dtype, const void* mask,
+                                              int mask_dtype, const int32_t* lens, float* out, int64_t N, int S, int D,
+                                              int64_t V, int32_t* oob_flag, void* workspace, size_t workspace_bytes,
+                                              tt_stream_t stream) {
+  return tt_k1_sliced_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, workspace,
+                             workspace_bytes, 0, static_cast<hipStream_t>(stream));
 }

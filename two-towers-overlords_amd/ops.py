@@ -63,6 +63,20 @@ def _mask_or_lens(mask, lens, N: int, S: int, dev) -> Tuple[Optional[torch.Tenso
     return mask, mw, lens
 
 
+_SCRATCH: dict = {}
+
+
+def _scratch(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Grow-only per-device scratch for kernels whose workspace lives only inside one call
+    (stream-ordered reuse: every user launches on the current stream)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
 def gather_pool_norm(
     table: torch.Tensor,
     input_ids: torch.Tensor,
@@ -70,10 +84,13 @@ def gather_pool_norm(
     lens: Optional[torch.Tensor] = None,
     out: Optional[torch.Tensor] = None,
     check_ids: bool = False,
+    sliced: Optional[bool] = None,
 ) -> torch.Tensor:
     """K1: normalize(mean_pool(table[input_ids], attention_mask)) -> [N, D].
     Replaces backend/model.py:51-56 (`embed` mode).  check_ids=True synchronises
-    and raises if any unmasked id was outside [0, V)."""
+    and raises if any unmasked id was outside [0, V).  sliced: force the per-text (False) or the
+    XCD-sliced (True, tt_gather_pool_norm_sliced_f32) form; None picks the faster one for the
+    shape (tt_k1_prefers_sliced).  Same result to fp32 summation order."""
     _req(table, "table", torch.float32, 2)
     _req(input_ids, "input_ids", ndim=2)
     iw = _int_tensor(input_ids, "input_ids")
@@ -90,8 +107,16 @@ def gather_pool_norm(
             raise ValueError(f"out: expected {(N, D)}, got {tuple(out.shape)}")
     flag = torch.zeros(1, dtype=torch.int32, device=table.device) if check_ids else None
     with torch.cuda.device(table.device):
-        call("tt_gather_pool_norm_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw, _ptr(lens),
-             out.data_ptr(), N, S, D, V, _ptr(flag), _stream())
+        if sliced is None:
+            sliced = bool(_lib.load().tt_k1_prefers_sliced(V, D, N, S)) and table.data_ptr() % 16 == 0
+        if sliced:
+            nbytes = int(_lib.load().tt_gather_pool_sliced_workspace_bytes(N, D))
+            ws = _scratch(table.device, nbytes)
+            call("tt_gather_pool_norm_sliced_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw,
+                 _ptr(lens), out.data_ptr(), N, S, D, V, _ptr(flag), ws.data_ptr(), nbytes, _stream())
+        else:
+            call("tt_gather_pool_norm_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw, _ptr(lens),
+                 out.data_ptr(), N, S, D, V, _ptr(flag), _stream())
     if check_ids and int(flag.item()) != 0:
         raise IndexError(f"input_ids contains a token id outside [0, {V})")
     return out

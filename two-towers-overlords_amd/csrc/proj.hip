@@ -1,3 +1,4 @@
+#include <cstdlib>
 // K2 — per-tower projection Linear(D,P) -> ReLU -> Linear(P,P) and its parameter
 // gradients, as grouped exact-fp32 MFMA GEMMs (both towers in one launch).
 // Replaces backend/model.py:33-38,59 and the part of loss.backward()
@@ -21,6 +22,9 @@ int choose_nsplit(long long M) {
 
 // block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
 static void pick_tile(long long total_rows, int N, int& wm, int& wn, bool low_traffic = false) {
+  if (const char* v = getenv("TT_TILE")) {  // A/B: "11", "21", "22"
+    if (v[0] == '1' || v[0] == '2') { wm = v[0] - '0'; wn = (v[1] == '2') ? 2 : 1; if (wm == 1) wn = 1; return; }
+  }
   const long long tiles64 = ((total_rows + 63) / 64) * ((N + 63) / 64);
   if (tiles64 >= 2048 && N >= 128) { wm = 2; wn = 2; }
   else if (tiles64 >= 1024 || (low_traffic && tiles64 >= 512)) { wm = 2; wn = 1; }

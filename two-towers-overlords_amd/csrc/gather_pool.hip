@@ -221,14 +221,16 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
 // workgroup b gathers only the tokens whose id % NS == b % NS: every XCD then re-reads one 1/NS
 // slice of the table (5.9 MB at NS = 8) and most row reads hit its own L2.
 //
-// Persistent: the grid is NS x G workgroups (G chosen from the CU count and the residency wanted),
-// wave w of workgroup (slice, g) walks texts g*4+w, +4G, +8G, ...  One (text, slice) step: the ids /
-// mask of the NEXT text are loaded into registers first (their latency hides under this text's
-// rows), this text's selected (id, weight) list — compacted into LDS one step earlier — is gathered
-// U rows at a time, the slice's partial sum [D] goes to a workspace, then the next text's list is
-// compacted.  A second launch adds a text's NS partials in slice order (fixed order: bitwise
-// reproducible), divides by the mask sum and L2-normalises.  Costs N*NS*D*4 bytes written + read.
-template <typename IdT, typename MaskT, int C, int U, int NPH, int MAXSEG>
+// The grid is NS x G workgroups; wave w of workgroup (slice, g) takes texts g*4+w, +4G, +8G, ...  By
+// default G covers all texts (one text per wave); with fewer workgroups (TT_K1_SLICED_BPC, an A/B
+// knob) the same loop makes the grid persistent.  One (text, slice) step: the ids / mask of the NEXT
+// text, if any, are loaded into registers first (their latency hides under this text's rows), this
+// text's selected (id, weight) list — compacted into LDS one step earlier — is gathered U rows at a
+// time, the slice's partial sum [D] goes to a workspace, then the next text's list is compacted.
+// A second launch adds a text's NS partials in slice order (fixed order: bitwise reproducible),
+// divides by the mask sum and L2-normalises.  Costs N*NS*D*4 bytes written + read.
+// (NS = 16 in two grid phases, so that a slice fits the L2 whole, doubles the partials: 114 vs 96 us.)
+template <typename IdT, typename MaskT, int C, int U, int NS, int MAXSEG>
 __global__ __launch_bounds__(kThreads) void pool_sliced_kernel(
     const float* __restrict__ table, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ partial, float* __restrict__ wsum_out, long long N,
@@ -236,14 +238,10 @@ __global__ __launch_bounds__(kThreads) void pool_sliced_kernel(
   extern __shared__ int sliced_lds[];  // per wave: 2 x ([S] ids + [S] weights)
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const int wave = threadIdx.x >> 6;
-  // NS = 8 * NPH residue classes; the grid is NPH phases of (8 x G) workgroups, dispatched in order, so at any
-  // time an XCD works on ONE class (phase * 8 + its blockIdx % 8 label): 1/NS of the table in its L2
-  constexpr int NS = 8 * NPH;
-  const unsigned per_phase = gridDim.x / NPH;
-  const int slice = (int)(blockIdx.x / per_phase) * 8 + (int)(blockIdx.x % 8);
-  const unsigned within = blockIdx.x % per_phase;
-  const long long tstride = (long long)(per_phase / 8) * kWavesPerText;
-  long long text = (long long)(within / 8) * kWavesPerText + wave;
+  static_assert(NS == 8, "one residue class per XCD");
+  const int slice = (int)(blockIdx.x % NS);
+  const long long tstride = (long long)(gridDim.x / NS) * kWavesPerText;
+  long long text = (long long)(blockIdx.x / NS) * kWavesPerText + wave;
   if (text >= N) return;  // wave-uniform; no workgroup barrier anywhere below
   int* const lbase = sliced_lds + wave * (4 * S);
   const int nchunk = D >> 2;
@@ -536,8 +534,7 @@ int dispatch_pool(const float* src, const void* ids, int ids_dtype, const void* 
   return TT_ERR_BAD_DTYPE;
 }
 
-constexpr int kPhases = 1;
-constexpr int kSlices = 8 * kPhases;
+constexpr int kSlices = 8;  // = XCDs per MI355X
 constexpr int kSlicedMaxS = 512;
 
 static int cu_count() {
@@ -578,7 +575,7 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
   const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
 #define TT_SLICED_LAUNCH(CC, UU, MS)                                                                          \
-  hipLaunchKernelGGL((pool_sliced_kernel<IdT, MaskT, CC, UU, kPhases, MS>), dim3((unsigned)(G * kSlices)),     \
+  hipLaunchKernelGGL((pool_sliced_kernel<IdT, MaskT, CC, UU, kSlices, MS>), dim3((unsigned)(G * kSlices)),     \
                      dim3(kThreads), lds, st, table, ids_t, mask_t, lens, partial, wsum, (long long)N, S, D,   \
                      (long long)V, oob)
 #define TT_SLICED_CASE(CC, UU)                  \

@@ -554,3 +554,121 @@ def test_inbatch_triplet_vs_oracle(tt, Bq, Bd, P, ids):
     assert abs(loss.item() - ref.item()) <= TOL
     close(dq, qq.grad, rel_to_max=True, atol=2e-5)
     close(dd, dd_.grad, rel_to_max=True, atol=2e-5)
+
+
+# --------------------------------------------------------------------------- BASELINE size: properties
+def test_metric_size_properties(tt):
+    """BASELINE.json configs[1] at its full size (V=30522, D=P=384, S=128, B=2048 triplets), where the
+    oracle would take minutes: size-independent properties + the oracle on a row subsample (the forward is
+    row-independent, so any subset of rows must agree with the oracle run on just those rows)."""
+    ops, engine = tt
+    V, D, P, B, S = 30522, 384, 384, 2048, 128
+    gen = torch.Generator().manual_seed(77)
+    table = orc.synthetic_table(V, D, seed=1)
+    params = orc.init_params(D, P, seed=2)
+    ids = torch.randint(0, V, (3, B, S), generator=gen, dtype=torch.int32)
+    lens = torch.randint(1, S + 1, (3, B), generator=gen, dtype=torch.int32)
+    lens[:, 0] = S
+    tab_d, ids_d, lens_d = table.cuda(), ids.cuda(), lens.cuda()
+    flat_ids, flat_lens = ids_d.reshape(3 * B, S), lens_d.reshape(3 * B)
+    mask = (torch.arange(S, device="cuda").unsqueeze(0) < flat_lens.unsqueeze(1)).int()
+
+    # K1: both forms, mask == prefix lengths, unit norm, scale invariance, token-order invariance
+    per_text = ops.gather_pool_norm(tab_d, flat_ids, lens=flat_lens, sliced=False)
+    sliced = ops.gather_pool_norm(tab_d, flat_ids, lens=flat_lens, sliced=True)
+    assert (per_text - sliced).abs().max().item() <= 1e-6
+    assert torch.equal(sliced, ops.gather_pool_norm(tab_d, flat_ids, mask, sliced=True))       # same weights, same order
+    assert torch.equal(per_text, ops.gather_pool_norm(tab_d, flat_ids, mask, sliced=False))
+    assert (sliced.norm(dim=1) - 1).abs().max().item() <= 1e-6
+    assert (ops.gather_pool_norm(tab_d * 4.0, flat_ids, lens=flat_lens) - sliced).abs().max().item() <= 1e-6  # exact x4
+    perm = torch.stack([torch.randperm(S, generator=gen) for _ in range(64)]).cuda()
+    rows = torch.arange(64, device="cuda")
+    full = flat_lens[:64] * 0 + S  # order invariance needs every position valid
+    a = ops.gather_pool_norm(tab_d, flat_ids[:64], lens=full.int())
+    b = ops.gather_pool_norm(tab_d, torch.gather(flat_ids[:64], 1, perm), lens=full.int())
+    assert (a - b).abs().max().item() <= 1e-6
+    assert rows.numel() == 64
+
+    # one full engine step; identical runs are bitwise identical
+    def run():
+        eng = engine.HotPathEngine(tab_d, P, B, S)
+        flat = _flat(params).cuda()
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        eng.bind(flat, m, v)
+        eng.pool(0, ids_d, lens=lens_d)
+        eng.fwd_bwd(0, B, 0.3)
+        g = torch.empty_like(flat)
+        eng.reduce_grads(g)
+        emb = eng.embeddings(B).clone()
+        pooled = eng.pooled(0, B).clone()
+        _, _, loss = eng.read_stats()
+        eng.adam(1, 1e-3)
+        out = (emb, pooled, g.clone(), loss, flat.clone())
+        eng.close()
+        return out
+
+    emb, pooled, g, loss, flat1 = run()
+    emb2, pooled2, g2, loss2, flat2 = run()
+    assert torch.equal(emb, emb2) and torch.equal(g, g2) and loss == loss2 and torch.equal(flat1, flat2)
+    assert torch.equal(pooled.reshape(3 * B, D), sliced)  # the engine's gather is the public entry point's
+
+    # oracle on a subsample of rows: pooled vectors and projected embeddings
+    pick = torch.randperm(B, generator=gen)[:48]
+    for r, tower in enumerate(("query_tower", "document_tower", "document_tower")):
+        sub_ids, sub_lens = ids[r, pick].long(), lens[r, pick]
+        sub_mask = (torch.arange(S).unsqueeze(0) < sub_lens.unsqueeze(1)).long()
+        close(pooled[r, pick.cuda()], orc.gather_pool_normalize(table, sub_ids, sub_mask), atol=1e-6)
+        close(emb[r, pick.cuda()], orc.encode(table, sub_ids, sub_mask, params, tower))
+
+    # loss and gradients against fp64 torch autograd ON THE DEVICE from the engine's own pooled inputs
+    p64 = {k: t.double().cuda().requires_grad_(True) for k, t in params.items()}
+    x = pooled.double()
+
+    def tower(xr, name):
+        h = torch.relu(xr @ p64[f"{name}.projection.0.weight"].T + p64[f"{name}.projection.0.bias"])
+        return h @ p64[f"{name}.projection.2.weight"].T + p64[f"{name}.projection.2.bias"]
+
+    q, pos, neg = tower(x[0], "query_tower"), tower(x[1], "document_tower"), tower(x[2], "document_tower")
+    cos = torch.nn.functional.cosine_similarity
+    ref_loss = torch.relu((1 - cos(q, pos)) - (1 - cos(q, neg)) + 0.3).mean()
+    ref_loss.backward()
+    assert abs(loss - ref_loss.item()) <= 1e-6
+    ref_g = torch.cat([p64[k].grad.reshape(-1) for k in orc.PARAM_KEYS]).float()
+    close(g, ref_g, atol=1e-6)
+    # Adam's first step moves every parameter by at most lr (and by ~lr where the gradient is not noise)
+    step = (flat1 - _flat(params).cuda()).abs()
+    assert step.max().item() <= 1e-3 * (1 + 1e-5)
+    assert (step[g.abs() > 1e-6] - 1e-3).abs().max().item() <= 1e-5
+
+
+def test_inbatch_metric_size_properties(tt):
+    """BASELINE.json configs[4] at its full size (B=4096, P=384; 16.8 M query-document pairs): the oracle's
+    definition evaluated in fp64 ON THE DEVICE as one matrix expression, its autograd gradient, and the
+    symmetry of the loss under a joint permutation of the batch."""
+    ops, _ = tt
+    B, P = 4096, 384
+    gen = torch.Generator().manual_seed(5)
+    q = torch.randn(B, P, generator=gen)
+    d = torch.randn(B, P, generator=gen) * 0.5 + q * 0.5
+    qid = torch.randint(0, B // 2, (B,), generator=gen)  # repeated queries: their documents are not negatives
+    qd, dd_ = q.cuda(), d.cuda()
+    loss, dq, dd = ops.inbatch_triplet_fwd_bwd(qd, dd_, 0.2, None, qid.cuda(), qid.cuda())
+
+    q64, d64 = qd.double().requires_grad_(True), dd_.double().requires_grad_(True)
+    qn = q64 / q64.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    dn = d64 / d64.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    S = qn @ dn.T
+    valid = qid.cuda().unsqueeze(0) != qid.cuda().unsqueeze(1)
+    valid.fill_diagonal_(False)
+    ref = (torch.relu(S - S.diagonal().unsqueeze(1) + 0.2) * valid).sum() / float(B * (B - 1))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-6
+    close(dq, q64.grad.float(), rel_to_max=True, atol=1e-6)
+    close(dd, d64.grad.float(), rel_to_max=True, atol=1e-6)
+
+    perm = torch.randperm(B, generator=gen).cuda()
+    loss_p, dq_p, dd_p = ops.inbatch_triplet_fwd_bwd(qd[perm].contiguous(), dd_[perm].contiguous(), 0.2, None,
+                                                     qid.cuda()[perm].contiguous(), qid.cuda()[perm].contiguous())
+    assert abs(loss_p.item() - loss.item()) <= 1e-6
+    close(dq_p, dq[perm], rel_to_max=True, atol=1e-6)
+    close(dd_p, dd[perm], rel_to_max=True, atol=1e-6)

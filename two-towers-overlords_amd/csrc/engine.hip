@@ -89,8 +89,11 @@ void carve(tt_engine* e, char* base, size_t* total) {
   Carver c{base};
   const size_t rows = 3 * (size_t)e->cfg.max_B;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->pooled[i] = c.take<float>(rows * e->cfg.D);
-  e->k1_partial_bytes = tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D);
-  for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->k1_partial[i] = c.take<float>(e->k1_partial_bytes / sizeof(float));
+  // partial sums of the XCD-sliced K1: only for tables the sliced form can win on (any N, S)
+  e->k1_partial_bytes = tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, (int64_t)1 << 40, 128)
+                            ? tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D) : 0;
+  for (int i = 0; i < TT_ENGINE_SLOTS; ++i)
+    e->k1_partial[i] = e->k1_partial_bytes ? c.take<float>(e->k1_partial_bytes / sizeof(float)) : nullptr;
   e->H = c.take<float>(rows * e->cfg.P);
   e->emb = c.take<float>(rows * e->cfg.P);
   e->dOut = c.take<float>(rows * e->cfg.P);
@@ -216,7 +219,7 @@ extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_d
   TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (roles == 2 || roles == 3), TT_ERR_BAD_SHAPE);
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && S >= 1 && S <= e->cfg.max_S, TT_ERR_BAD_SHAPE);
   // XCD-sliced form where it is the faster one (table several times an XCD's L2, see tt_k1_prefers_sliced)
-  if (tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, roles * (int64_t)B, S) &&
+  if (e->k1_partial_bytes && tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, roles * (int64_t)B, S) &&
       tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]))
     return tt_k1_sliced_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B,
                                S, e->cfg.D, e->cfg.V, e->oob, e->k1_partial[slot], e->k1_partial_bytes,

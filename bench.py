@@ -278,7 +278,9 @@ def main():
                    "seq_len": S, "batch_per_gpu": B, "global_batch": B * world, "ids": "int32 [3,B,S], "
                    + ("zipf" if args.zipf else "uniform") + (", ragged lengths" if args.ragged else ", full length"), "parallelism": f"dp{world}", "inputs": args.inputs,
                    "k1_only": bool(args.k1_only),
-                   "gather_overlap": "side stream, K1 capped at %d workgroups/CU" % (trainer.engine_k1_cap)
+                   "gather_overlap": ("side stream, " + ("K1's LDS reservation paired with the projection tile (auto)"
+                                                       if trainer.engine_k1_cap < 0 else
+                                                       "K1 capped at %d workgroups/CU" % trainer.engine_k1_cap))
                    if trainer.side is not None else "none (same stream)",
                    "launch": "hipGraph replay (1 step per graph; every 8th step eager for K1 event timing)"
                    if trainer.use_graphs else "eager (kernel by kernel)"},

@@ -267,11 +267,16 @@ typedef struct {
   int32_t max_B;    /* max triplets per step on this replica */
   int32_t max_S;    /* max padded sequence length */
   int32_t device;   /* HIP device ordinal */
-  int32_t k1_blocks_per_cu; /* 0 = no cap; >0 caps the K1 workgroups resident per CU (via dynamic
-                               LDS) so that tt_engine_pool can share the chip with the MFMA
-                               kernels of tt_engine_fwd_bwd running on another stream (2 is
-                               enough for ~97 % of K1's stand-alone bandwidth) */
+  int32_t k1_blocks_per_cu; /* How tt_engine_pool shares the chip with the MFMA kernels of
+                               tt_engine_fwd_bwd running on another stream (both sides are steered
+                               through the LDS a gather workgroup occupies):
+                                 0                 not shared: no reservation, stand-alone tile choice
+                                 TT_K1_SHARE_AUTO  the measured-best pairing for the table: XCD-sliced K1
+                                                   sized just above a 64x64 projection tile's LDS, or the
+                                                   per-text K1 at 2 workgroups per CU beside 128x64 tiles
+                                 n >= 2            at most n gather workgroups per CU, 128x64 tiles (A/B) */
 } tt_engine_config;
+#define TT_K1_SHARE_AUTO (-1)
 
 /* Device bytes of activation + split-K workspace an engine of this config needs. */
 size_t tt_engine_workspace_bytes(const tt_engine_config* cfg);

@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 TT_I32, TT_I64 = 4, 8
+TT_K1_SHARE_AUTO = -1  # tt_engine_config.k1_blocks_per_cu: pair the K1 form with the projection tile
 ABI_VERSION = 1
 
 _lib = None

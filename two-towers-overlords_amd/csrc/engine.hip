@@ -13,10 +13,10 @@
 
 int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                  const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                 int blocks_per_cu, hipStream_t st);
+                 unsigned lds_total, hipStream_t st);
 int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                        void* workspace, size_t workspace_bytes, int blocks_per_cu, hipStream_t st);
+                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st);
 int tt_k1_sliced_supported(int S, int D, const float* table, const float* out);
 int tt_launch_adam_auto(float* params, const float* grads, int nslabs, long long slab_stride, float* exp_avg,
                         float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
@@ -47,6 +47,10 @@ struct tt_engine {
   float* pooled[TT_ENGINE_SLOTS];
   float* k1_partial[TT_ENGINE_SLOTS];  // XCD-sliced K1: per-slice partial sums + mask sums of one batch
   size_t k1_partial_bytes;
+  // sharing with the gathers (cfg.k1_blocks_per_cu != 0), see gather_pool.hip "Sharing the chip"
+  bool shared;           // gathers run beside phase B on another stream
+  bool tile_above;       // sliced K1 reserved just above the 64x64 projection tile's LDS (else: capped K1, 128x64 tiles)
+  int cap;               // capped mode: gather workgroups per CU
   float* H;
   float* emb;
   float* dOut;
@@ -117,7 +121,7 @@ void carve(tt_engine* e, char* base, size_t* total) {
 static int fill_dims(tt_engine* e, const tt_engine_config* cfg) {
   TT_REQUIRE(cfg->V >= 1 && cfg->V <= 0x7fffffffLL && cfg->D >= 1 && cfg->P >= 1 && cfg->P <= 1024 &&
                  cfg->max_B >= 1 && cfg->max_S >= 1 && (int64_t)cfg->max_B * 3 <= 0x7fffffffLL &&
-                 cfg->k1_blocks_per_cu >= 0,
+                 cfg->k1_blocks_per_cu >= TT_K1_SHARE_AUTO,
              TT_ERR_BAD_SHAPE);
   e->cfg = *cfg;
   e->tower_n = (int64_t)cfg->P * cfg->D + cfg->P + (int64_t)cfg->P * cfg->P + cfg->P;
@@ -166,6 +170,10 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
     e->aux = nullptr;
   }
   e->gathers_share_chip = true;
+  e->shared = cfg->k1_blocks_per_cu != 0;
+  e->tile_above = cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO && e->k1_partial_bytes != 0 &&
+                  tt_k1_prefers_sliced(cfg->V, cfg->D, 3 * (int64_t)cfg->max_B, cfg->max_S);
+  e->cap = cfg->k1_blocks_per_cu > 0 ? cfg->k1_blocks_per_cu : (cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO ? 2 : 0);
   e->magic = kMagic;
   *out = e;
   return TT_OK;
@@ -218,14 +226,21 @@ extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_d
   TT_REQUIRE(e->table, TT_ERR_NULL_POINTER);
   TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (roles == 2 || roles == 3), TT_ERR_BAD_SHAPE);
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && S >= 1 && S <= e->cfg.max_S, TT_ERR_BAD_SHAPE);
+  // LDS a gather workgroup occupies while it shares the chip (0 = no reservation)
+  unsigned lds_total = 0;
+  if (e->shared)
+    lds_total = e->tile_above ? (unsigned)ttp::chain_lds_bytes(3 * (long long)e->cfg.max_B, e->cfg.P, ttp::kTileSmall) + 3072u
+                              : tt_k1_lds_for_cap(e->cap);
   // XCD-sliced form where it is the faster one (table several times an XCD's L2, see tt_k1_prefers_sliced)
   if (e->k1_partial_bytes && tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, roles * (int64_t)B, S) &&
-      tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]))
+      tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot])) {
+    if (e->shared && !e->tile_above && e->cfg.k1_blocks_per_cu == TT_K1_SHARE_AUTO) lds_total = tt_k1_lds_for_cap(3);
     return tt_k1_sliced_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B,
-                               S, e->cfg.D, e->cfg.V, e->oob, e->k1_partial[slot], e->k1_partial_bytes,
-                               e->cfg.k1_blocks_per_cu, static_cast<hipStream_t>(stream));
+                               S, e->cfg.D, e->cfg.V, e->oob, e->k1_partial[slot], e->k1_partial_bytes, lds_total,
+                               static_cast<hipStream_t>(stream));
+  }
   return tt_k1_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B, S,
-                      e->cfg.D, e->cfg.V, e->oob, e->cfg.k1_blocks_per_cu, static_cast<hipStream_t>(stream));
+                      e->cfg.D, e->cfg.V, e->oob, lds_total, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tt_engine_pool_cached(tt_engine* e, int slot, const float* cache, int64_t cache_rows,
@@ -273,8 +288,13 @@ static void fill_towers(tt_engine* e, int slot, int32_t B, int32_t doc_rows, ttp
 //   fused: loss mean inside the triplet launch, ONE launch for dW2/db2 + dH, then dW1: 6 fewer host
 //          API calls per step, 3 % faster when nothing else is on the chip (frozen-feature cache:
 //          125 vs 129 us); the default there.
+// projection tiles that pair with how the gathers are reserved (gather_pool.hip "Sharing the chip")
+static int tile_policy(const tt_engine* e) {
+  return !e->shared ? ttp::kTileAuto : (e->tile_above ? ttp::kTileSmall : ttp::kTileLowTraffic);
+}
+
 static bool use_fork(const tt_engine* e) {
-  bool fork = e->cfg.k1_blocks_per_cu > 0 && e->aux != nullptr && e->gathers_share_chip;
+  bool fork = e->shared && e->aux != nullptr && e->gathers_share_chip;
   if (const char* v = getenv("TT_BWD"))  // "fork" / "fused" force a schedule (A/B runs); anything else: automatic
     if (v[0] == 'f') fork = e->aux != nullptr && v[1] == 'o';
   return fork;
@@ -283,7 +303,7 @@ static bool use_fork(const tt_engine* e) {
 static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_rows, float loss_denominator,
                           hipStream_t st) {
   const int D = e->cfg.D, P = e->cfg.P;
-  const bool shared = e->cfg.k1_blocks_per_cu > 0;  // gathers run beside these kernels on another stream
+  const int shared = tile_policy(e);
   int rc;
   if (!use_fork(e)) {
     if (loss_rows > 0) {
@@ -321,7 +341,7 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
   const int D = e->cfg.D, P = e->cfg.P;
   ttp::Tower t[2];
   fill_towers(e, slot, B, neg_index ? B : 2 * B, t);
-  int rc = ttp::forward(t, 2, D, P, st, e->cfg.k1_blocks_per_cu > 0);
+  int rc = ttp::forward(t, 2, D, P, st, tile_policy(e));
   if (rc != TT_OK) return rc;
   const float* q = e->emb;
   const float* p = e->emb + (int64_t)B * P;
@@ -348,7 +368,7 @@ extern "C" int tt_engine_forward(tt_engine* e, int slot, int32_t B, int32_t role
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B, TT_ERR_BAD_SHAPE);
   ttp::Tower t[2];
   fill_towers(e, slot, B, (roles - 1) * B, t);
-  return ttp::forward(t, 2, e->cfg.D, e->cfg.P, static_cast<hipStream_t>(stream), e->cfg.k1_blocks_per_cu > 0);
+  return ttp::forward(t, 2, e->cfg.D, e->cfg.P, static_cast<hipStream_t>(stream), tile_policy(e));
 }
 
 extern "C" int tt_engine_backward(tt_engine* e, int slot, int32_t B, int32_t roles, tt_stream_t stream) {

@@ -474,21 +474,23 @@ __global__ __launch_bounds__(kThreads) void embed_gather_kernel(const float* __r
   }
 }
 
-// Residency cap.  K1 keeps ~97 % of its bandwidth with only 2 workgroups (8 waves) per
-// CU — each wave has 8 rows (12 KB) in flight — so when it shares the chip with the MFMA
-// kernels on another stream it is launched with enough *dynamic* LDS that at most
-// `blocks_per_cu` of its workgroups fit on a CU, leaving wave slots / registers for them.
-static unsigned k1_dynamic_lds(int blocks_per_cu, unsigned static_lds) {
-  if (blocks_per_cu <= 0 || blocks_per_cu >= 16) return 0;
-  const unsigned per_block = (160u * 1024u) / (unsigned)blocks_per_cu;
-  // one granule (1 KB) of slack so that blocks_per_cu still fit, blocks_per_cu + 1 do not
-  const unsigned want = per_block - 1024u;
-  return want > static_lds ? want - static_lds : 0;
+// Sharing the chip with the projection kernels of another stream.  K1 is launched with enough *dynamic*
+// LDS that a workgroup occupies `lds_total` bytes of the CU's 160 KB; what the CU then holds is decided
+// by which workgroup fits the hole a finished one leaves (measured):
+//  * tt_k1_lds_for_cap(n): 160 KB / n minus one granule — at most n gather workgroups per CU.  The
+//    per-text form runs best at n = 2 beside 128x64 projection tiles.
+//  * projection tile's LDS + 3 KB (engine.hip, sliced form beside 64x64 tiles: 37 KB): a hole left by a
+//    gather workgroup takes either kind, a hole left by a projection workgroup is too small for a gather
+//    workgroup — the projection chain, which is the critical path, never waits for LDS, and the gathers
+//    fill what it leaves (up to four workgroups per CU).  One KB less and it stops working (216 vs 198 us).
+// (tt_k1_lds_for_cap lives in tt_common.h)
+static unsigned k1_dynamic_lds(unsigned lds_total, unsigned static_lds) {
+  return lds_total > static_lds ? lds_total - static_lds : 0;
 }
 
 template <typename IdT, typename MaskT, bool DENSE>
 int launch_pool(const float* src, const void* ids, const void* mask, const int32_t* lens, float* out,
-                int64_t N, int S, int D, int64_t V, int32_t* oob, int blocks_per_cu, hipStream_t st) {
+                int64_t N, int S, int D, int64_t V, int32_t* oob, unsigned lds_total, hipStream_t st) {
   const IdT* ids_t = static_cast<const IdT*>(ids);
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
   const dim3 grid(static_cast<unsigned>(N)), block(kThreads);
@@ -508,7 +510,7 @@ int launch_pool(const float* src, const void* ids, const void* mask, const int32
   }
 #define TT_POOL_CASE(CC, UU)                                                                      \
   hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, CC, UU, DENSE>), grid, block,                    \
-                     k1_dynamic_lds(blocks_per_cu, CC * 4096u + 16u), st, src, ids_t, mask_t, lens, out, S, D, \
+                     k1_dynamic_lds(lds_total, CC * 4096u + 16u), st, src, ids_t, mask_t, lens, out, S, D, \
                      (long long)V, oob)
   switch (C) {
     case 1: TT_POOL_CASE(1, 8); break;
@@ -524,13 +526,13 @@ int launch_pool(const float* src, const void* ids, const void* mask, const int32
 template <bool DENSE>
 int dispatch_pool(const float* src, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                   const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob,
-                  int blocks_per_cu, hipStream_t st) {
+                  unsigned lds_total, hipStream_t st) {
   // without a mask the MaskT instantiation is irrelevant: use int32
   const int md = mask ? mask_dtype : TT_I32;
-  if (ids_dtype == TT_I32 && md == TT_I32) return launch_pool<int32_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, blocks_per_cu, st);
-  if (ids_dtype == TT_I32 && md == TT_I64) return launch_pool<int32_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, blocks_per_cu, st);
-  if (ids_dtype == TT_I64 && md == TT_I32) return launch_pool<int64_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, blocks_per_cu, st);
-  if (ids_dtype == TT_I64 && md == TT_I64) return launch_pool<int64_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, blocks_per_cu, st);
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_pool<int32_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_pool<int32_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_pool<int64_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st);
+  if (ids_dtype == TT_I64 && md == TT_I64) return launch_pool<int64_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st);
   return TT_ERR_BAD_DTYPE;
 }
 
@@ -552,13 +554,13 @@ static int cu_count() {
 
 template <typename IdT, typename MaskT>
 int launch_sliced(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
-                  int S, int D, int64_t V, int32_t* oob, float* ws, int blocks_per_cu, hipStream_t st) {
+                  int S, int D, int64_t V, int32_t* oob, float* ws, unsigned lds_total, hipStream_t st) {
   const IdT* ids_t = static_cast<const IdT*>(ids);
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
   float* partial = ws;
   float* wsum = ws + (size_t)N * kSlices * D;
   const long long groups_all = (N + kWavesPerText - 1) / kWavesPerText;
-  // Default: one workgroup per (4 texts, slice), residency capped through dynamic LDS like the per-text
+  // Default: one workgroup per (4 texts, slice), residency steered through dynamic LDS like the per-text
   // form.  TT_K1_SLICED_BPC=n (A/B) makes the grid persistent instead: n workgroups per CU walking the
   // texts — within 5 % alone, 4 % slower beside the projection kernels (213-216 vs 205 us per step).
   static const int persist_bpc = getenv("TT_K1_SLICED_BPC") ? atoi(getenv("TT_K1_SLICED_BPC")) : 0;
@@ -569,8 +571,7 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
     if (G > groups_all) G = groups_all;
     if (G < 1) G = 1;
   } else {
-    const unsigned cap = k1_dynamic_lds(blocks_per_cu, 0);
-    if (cap > lds) lds = cap;
+    if (lds_total > lds) lds = lds_total;
   }
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
   const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
@@ -601,17 +602,17 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
 
 }  // namespace
 
-// internal (engine.hip): K1 with a residency cap (0 = none)
+// internal (engine.hip): K1 with an LDS reservation (0 = none)
 int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                  const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                 int blocks_per_cu, hipStream_t st) {
+                 unsigned lds_total, hipStream_t st) {
   TT_REQUIRE(table && ids && out, TT_ERR_NULL_POINTER);
   TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x7fffffffLL, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   if (N == 0) return TT_OK;
   return dispatch_pool<false>(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag,
-                              blocks_per_cu, st);
+                              lds_total, st);
 }
 
 extern "C" int tt_gather_pool_norm_f32(const float* table, const void* ids, int ids_dtype,
@@ -679,10 +680,10 @@ extern "C" int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S) {
   return table_bytes >= 10e6 && table_bytes <= 128e6 && S >= 48 && (double)N * S >= 131072.0;
 }
 
-// internal (engine.hip): sliced K1 with a residency cap (0 = none)
+// internal (engine.hip): sliced K1 with an LDS reservation (0 = none)
 int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                        void* workspace, size_t workspace_bytes, int blocks_per_cu, hipStream_t st) {
+                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st) {
   TT_REQUIRE(table && ids && out && workspace, TT_ERR_NULL_POINTER);
   TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x0fffffffLL, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
@@ -692,10 +693,10 @@ int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, cons
   if (N == 0) return TT_OK;
   float* ws = static_cast<float*>(workspace);
   const int md = mask ? mask_dtype : TT_I32;
-  if (ids_dtype == TT_I32 && md == TT_I32) return launch_sliced<int32_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, blocks_per_cu, st);
-  if (ids_dtype == TT_I32 && md == TT_I64) return launch_sliced<int32_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, blocks_per_cu, st);
-  if (ids_dtype == TT_I64 && md == TT_I32) return launch_sliced<int64_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, blocks_per_cu, st);
-  return launch_sliced<int64_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, blocks_per_cu, st);
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_sliced<int32_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_sliced<int32_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_sliced<int64_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st);
+  return launch_sliced<int64_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st);
 }
 
 extern "C" int tt_gather_pool_norm_sliced_f32(const float* table, const void* ids, int ids_dtype, const void* mask,

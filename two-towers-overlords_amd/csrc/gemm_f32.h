@@ -39,6 +39,9 @@ struct Batch {
   long long slab_stride;  // floats between consecutive split slabs of C / colsum
 };
 
+// Static LDS of one workgroup of the (layout, wm, wn) kernel, in bytes.
+size_t tile_lds_bytes(Layout layout, int wm, int wn);
+
 // Launches one grouped GEMM.  wm/wn pick the block tile: (64*wm) x (64*wn).
 int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st);
 

@@ -462,6 +462,19 @@ int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStrea
   return TT_OK;
 }
 
+template <int WM, int WN>
+static size_t lds_of(Layout layout) {
+  const int f = layout == kNT ? TileCfg<kNT, WM, WN>::LDS_FLOATS
+                              : layout == kNN ? TileCfg<kNN, WM, WN>::LDS_FLOATS : TileCfg<kTN, WM, WN>::LDS_FLOATS;
+  return (size_t)f * sizeof(float);
+}
+
+size_t tile_lds_bytes(Layout layout, int wm, int wn) {
+  if (wm == 2 && wn == 2) return lds_of<2, 2>(layout);
+  if (wm == 2 && wn == 1) return lds_of<2, 1>(layout);
+  return lds_of<1, 1>(layout);
+}
+
 int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st) {
   if (b.count < 1 || b.count > kMaxGroup || b.nsplit < 1) return TT_ERR_BAD_SHAPE;
   if (layout == kNT && epi == kBiasRelu) return launch_le<kNT, kBiasRelu>(b, wm, wn, st);

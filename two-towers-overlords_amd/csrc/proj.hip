@@ -21,17 +21,28 @@ int choose_nsplit(long long M) {
 }
 
 // block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
-static void pick_tile(long long total_rows, int N, int& wm, int& wn, bool low_traffic = false) {
+static void pick_tile(long long total_rows, int N, int& wm, int& wn, int policy = kTileAuto) {
+  const bool low_traffic = policy == kTileLowTraffic;
   if (const char* v = getenv("TT_TILE")) {  // A/B: "11", "21", "22"
     if (v[0] == '1' || v[0] == '2') { wm = v[0] - '0'; wn = (v[1] == '2') ? 2 : 1; if (wm == 1) wn = 1; return; }
   }
   const long long tiles64 = ((total_rows + 63) / 64) * ((N + 63) / 64);
   if (tiles64 >= 2048 && N >= 128) { wm = 2; wn = 2; }
+  else if (policy == kTileSmall) { wm = 1; wn = 1; }
   else if (tiles64 >= 1024 || (low_traffic && tiles64 >= 512)) { wm = 2; wn = 1; }
   else { wm = 1; wn = 1; }
 }
 
-int forward(const Tower* t, int count, int D, int P, hipStream_t st, bool low_traffic) {
+size_t chain_lds_bytes(long long rows, int P, int policy) {
+  int wm, wn;
+  pick_tile(rows, P, wm, wn, policy);
+  size_t m = ttg::tile_lds_bytes(ttg::kNT, wm, wn);
+  const size_t nn = ttg::tile_lds_bytes(ttg::kNN, wm, wn), tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1);
+  m = nn > m ? nn : m;
+  return tn > m ? tn : m;
+}
+
+int forward(const Tower* t, int count, int D, int P, hipStream_t st, int policy) {
   ttg::Batch b1{}, b2{};
   b1.count = b2.count = count;
   b1.nsplit = b2.nsplit = 1;
@@ -46,7 +57,7 @@ int forward(const Tower* t, int count, int D, int P, hipStream_t st, bool low_tr
     q.M = t[i].M; q.N = P; q.K = P; q.lda = P; q.ldb = P; q.ldc = P;
   }
   int wm, wn;
-  pick_tile(rows, P, wm, wn, low_traffic);
+  pick_tile(rows, P, wm, wn, policy);
   int rc = ttg::launch(ttg::kNT, ttg::kBiasRelu, b1, wm, wn, st);
   if (rc != TT_OK) return rc;
   return ttg::launch(ttg::kNT, ttg::kBias, b2, wm, wn, st);
@@ -66,7 +77,7 @@ int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long 
   return ttg::launch(ttg::kTN, ttg::kStore, g2, 1, 1, st);
 }
 
-int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, bool low_traffic) {
+int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, int policy) {
   ttg::Batch gh{};
   gh.count = count;
   gh.nsplit = 1;
@@ -79,12 +90,12 @@ int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, bool lo
     h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
   }
   int wm, wn;
-  pick_tile(rows, P, wm, wn, low_traffic);
+  pick_tile(rows, P, wm, wn, policy);
   return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st);
 }
 
 int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
-                    bool low_traffic) {
+                    int policy) {
   ttg::Batch g2{}, gh{};
   g2.count = gh.count = count;
   g2.nsplit = nsplit;
@@ -101,7 +112,7 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
     h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
   }
   int wm, wn;
-  pick_tile(rows, P, wm, wn, low_traffic);
+  pick_tile(rows, P, wm, wn, policy);
   if (wm == 2 && wn == 2) {  // the fused kernel carries 64x64 and 128x64 NN tiles only
     int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, 1, 1, st);
     if (rc != TT_OK) return rc;

@@ -25,6 +25,13 @@
     if (_e != hipSuccess) return (int)_e;    \
   } while (0)
 
+// LDS bytes a gather workgroup must occupy so that at most `blocks_per_cu` of them fit the CU's 160 KB
+// (gather_pool.hip, "Sharing the chip").
+static inline unsigned tt_k1_lds_for_cap(int blocks_per_cu) {
+  if (blocks_per_cu <= 0 || blocks_per_cu >= 16) return 0;
+  return (160u * 1024u) / (unsigned)blocks_per_cu - 1024u;  // one granule of slack: n fit, n + 1 do not
+}
+
 static inline bool tt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #ifdef __HIPCC__

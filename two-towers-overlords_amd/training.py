@@ -199,16 +199,13 @@ class TripletTrainer:
         self.margin, self.lr, self.betas, self.eps = float(margin), float(lr), betas, float(eps)
         self.accumulation_steps = int(accumulation_steps)
         # Default on a GPU: the gathers of the next batches run on a side stream under this batch's
-        # projection kernels, with K1's residency capped (2 workgroups per CU for the per-text form, 3 for
-        # the XCD-sliced form: the best of 2/3/4/6 measured for each) so that the projection kernels keep
-        # getting onto every CU: +20 % triplets/s over running them back to back.
+        # projection kernels; how the two share a CU is steered through the LDS a gather workgroup occupies
+        # (TT_K1_SHARE_AUTO: the engine pairs the K1 form with the projection tile): +20 %
+        # triplets/s over running them back to back.
         if overlap_streams is None:
             overlap_streams = self.device.type == "cuda" and engine is None
         if k1_blocks_per_cu is None:
-            k1_blocks_per_cu = 0
-            if overlap_streams:
-                sliced = _lib.load().tt_k1_prefers_sliced(table.shape[0], self.D, 3 * int(max_batch), int(max_seq_len))
-                k1_blocks_per_cu = 3 if sliced else 2
+            k1_blocks_per_cu = _lib.TT_K1_SHARE_AUTO if overlap_streams else 0
         self.engine = engine if engine is not None else HotPathEngine(table.contiguous(), self.P, max_batch, max_seq_len,
                                                                       k1_blocks_per_cu=k1_blocks_per_cu)
         self.engine_k1_cap = int(k1_blocks_per_cu or 0)

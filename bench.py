@@ -216,14 +216,29 @@ def main():
                     trainer.gather(batches[issued % n_distinct])
                     issued += 1
         else:
+            k = 0
             while trainer._pending:
                 nxt = None
                 if issued < n_steps:
                     nxt = batches[issued % n_distinct]
                     issued += 1
                 trainer.advance(nxt, B * world)
+                k += 1
+                if timed and trace_ev and k % 10 == 0 and k // 10 <= len(trace_ev):
+                    trace_ev[k // 10 - 1].record()
+                    trace_host.append(time.perf_counter())
         trainer.k1_events = None
 
+    trace_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // 10)] if os.environ.get("TT_TRACE") else []
+    trace_host = []
+
+    if os.environ.get("TT_GC_FREEZE", "1") == "1":  # (0: A/B of this very effect)
+        # A full (generation-2) pass of Python's cyclic GC over the ~10^6 objects that importing torch leaves
+        # behind takes 60-90 ms of host time; it used to land inside about one timed region in fifteen and
+        # starve the GPU (step 200 -> 500 us).  Freeze what exists now: later passes only look at new objects.
+        import gc
+        gc.collect()
+        gc.freeze()
     run(args.warmup, timed=False)
     barrier()
     t0 = time.perf_counter()
@@ -301,6 +316,11 @@ def main():
         result["roofline"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg)
+    if trace_ev and result["ms_per_step"] > 0.3:
+        gaps = [round(trace_ev[i].elapsed_time(trace_ev[i + 1]), 2) for i in range(len(trace_host) - 1)]
+        hgaps = [round((trace_host[i + 1] - trace_host[i]) * 1e3, 2) for i in range(len(trace_host) - 1)]
+        print("TRACE gpu ms per 10 steps:", gaps, file=sys.stderr)
+        print("TRACE host ms per 10 steps:", hgaps, file=sys.stderr)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -15,6 +15,7 @@ Two ways to run the batch body of backend/training.py:36-53:
 from __future__ import annotations
 
 import collections
+import gc
 import dataclasses
 import math
 from typing import Iterable, Optional, Sequence, Tuple
@@ -174,13 +175,15 @@ class TripletTrainer:
     an oracle-backed stand-in); the product default is the HIP engine.
     """
 
+    _gc_frozen = False  # gc.freeze() is process-wide: done once
     SLOTS = 3  # == TT_ENGINE_SLOTS (include/tt_hotpath.h)
 
     def __init__(self, model: Optional[TwoTowersModel] = None, *, table: Optional[torch.Tensor] = None,
                  params: Optional[dict] = None, max_batch: int, max_seq_len: int, margin: float = 0.3,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
                  process_group=None, engine=None, overlap_streams: Optional[bool] = None,
-                 k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet"):
+                 k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
+                 freeze_gc: bool = True):
         if model is not None:
             if model.query_tower.encoder_mode != "embed":
                 raise ValueError("the fused engine implements the `embed` encoder mode; use train_epoch for `bert`")
@@ -193,6 +196,7 @@ class TripletTrainer:
         if loss not in ("triplet", "inbatch"):
             raise ValueError("loss must be 'triplet' (the reference's sampled-negative triplet loss) or 'inbatch'")
         self.loss_kind = loss
+        self.freeze_gc = bool(freeze_gc)  # gc.freeze() once before the first epoch (see train_epoch)
         self.device = table.device
         self.D = table.shape[1]
         self.P = tensors[1].shape[0]
@@ -490,6 +494,13 @@ class TripletTrainer:
     def train_epoch(self, batches: Iterable[Batch], global_batch_sizes: Optional[Sequence[int]] = None) -> float:
         """All batches of an epoch; returns the mean of the per-batch (global) losses
         like backend/training.py:63.  One host sync at the end."""
+        if self.freeze_gc and not TripletTrainer._gc_frozen:
+            # The loop keeps the host ~2x ahead of the GPU; a full pass of Python's cyclic GC over the ~10^6
+            # objects torch's import leaves behind (60-90 ms) used to land in an epoch now and then and drain
+            # that lead.  Freezing the existing objects once makes later passes look at new objects only.
+            gc.collect()
+            gc.freeze()
+            TripletTrainer._gc_frozen = True
         it = iter(batches)
         depth = self.SLOTS - 1 if self.side is not None else 1
         while len(self._pending) < depth:  # prime the pipeline

@@ -65,3 +65,40 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_k1_form_selection_and_workspace_rules(monkeypatch):
+    """Host-only logic: which K1 form a shape gets (tt_k1_prefers_sliced, measured rule in gather_pool.hip) and
+    what that means for the engine's workspace; the sliced entry point's argument checks."""
+    lib = pkg.load()
+    monkeypatch.delenv("TT_K1_SLICED", raising=False)
+    pref = lib.tt_k1_prefers_sliced
+    assert pref(30522, 384, 6144, 128) == 1        # the metric shape: 46.9 MB table
+    assert pref(30522, 384, 6144, 32) == 0         # too few rows per slice
+    assert pref(30522, 384, 256, 128) == 0         # too few texts to pay for the second launch
+    assert pref(2000, 384, 6144, 128) == 0         # 3 MB table: already L2-resident
+    assert pref(250000, 768, 49152, 256) == 0      # 768 MB table: a slice no longer fits an L2
+    assert pref(30522, 386, 6144, 128) == 0        # D % 4 != 0: generic path only
+    assert pref(30522, 384, 6144, 1024) == 0       # S beyond the sliced kernel's list buffers
+    monkeypatch.setenv("TT_K1_SLICED", "0")
+    assert pref(30522, 384, 6144, 128) == 0
+    monkeypatch.setenv("TT_K1_SLICED", "1")
+    assert pref(2000, 384, 64, 128) == 1 and pref(30522, 386, 6144, 128) == 0
+    monkeypatch.delenv("TT_K1_SLICED")
+
+    ws = lib.tt_gather_pool_sliced_workspace_bytes
+    assert ws(6144, 384) == (6144 * 8 * 384 + 6144) * 4 and ws(0, 384) == 0
+    # null workspace / short workspace / unsupported S are refused before any launch
+    f = lib.tt_gather_pool_norm_sliced_f32
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, None, 0, None) == -1
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, 64, None) == -5
+    assert f(16, 16, 4, None, 4, None, 16, 8, 4096, 384, 1000, None, 16, 1 << 30, None) == -2
+
+    def engine_bytes(V, D, share):
+        cfg = _lib.TTEngineConfig(V, D, 384, 2048, 128, 0, share)
+        return lib.tt_engine_workspace_bytes(ctypes.byref(cfg))
+
+    small, metric = engine_bytes(2000, 384, 0), engine_bytes(30522, 384, 0)
+    assert metric - small >= 3 * ws(3 * 2048, 384)            # three slots of partial sums, only where sliced applies
+    assert engine_bytes(30522, 384, _lib.TT_K1_SHARE_AUTO) == metric  # sharing mode does not change the layout
+    assert engine_bytes(30522, 384, -2) == 0                          # invalid sharing mode

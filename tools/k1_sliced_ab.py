@@ -6,8 +6,9 @@ import two_towers_overlords_amd as pkg
 from two_towers_overlords_amd import ops
 pkg.load()
 dev = torch.device("cuda")
-D = 384
-for (V, N, S) in [(30522, 6144, 128), (30522, 6144, 64), (30522, 1536, 512), (2000, 6144, 128), (5000, 6144, 128),
+D = int(os.environ.get("D", "384"))
+CASES = [tuple(int(x) for x in c.split(",")) for c in os.environ["CASES"].split(";")] if os.environ.get("CASES") else None
+for (V, N, S) in CASES or [(30522, 6144, 128), (30522, 6144, 64), (30522, 1536, 512), (2000, 6144, 128), (5000, 6144, 128),
                   (10000, 6144, 128), (20000, 6144, 128), (120000, 6144, 128), (30522, 6144, 32), (30522, 512, 128),
                   (30522, 64, 128)]:
     table = (torch.randn(V, D) * 0.02).to(dev)

@@ -281,20 +281,22 @@ static void fill_towers(tt_engine* e, int slot, int32_t B, int32_t doc_rows, ttp
 
 // Backward of phase B.  dW2/db2 and dH are independent; dW1/db1 needs dH.  Two forms, A/B-measured on
 // one box with interleaved runs (TT_BWD=fork|fused overrides the choice):
+//   fused: loss mean inside the triplet launch, ONE launch for dW2/db2 + dH, then dW1: 8 launches and no
+//          event traffic per step.  The default: alone on the chip (frozen-feature cache: 125 vs 129 us),
+//          and beside gathers reserved just above the projection tile's LDS, where it ties with the fork
+//          at B = 2048 (199 vs 200 us) and wins below (B = 512: 100 vs 113 us) because it costs the host
+//          a third less (52-69 vs 85-100 us of API time per step).
 //   fork : dW2/db2 and the loss mean on the engine's second stream under the dH -> dW1 chain, joined
-//          before the caller's next stream-ordered call.  Shortest critical path; the default when
-//          the gathers share the chip (k1_blocks_per_cu > 0): 232 vs 248 us per step.  There the
-//          in-launch loss mean also loses (its ticket round trip queues behind the gather's loads).
-//   fused: loss mean inside the triplet launch, ONE launch for dW2/db2 + dH, then dW1: 6 fewer host
-//          API calls per step, 3 % faster when nothing else is on the chip (frozen-feature cache:
-//          125 vs 129 us); the default there.
+//          before the caller's next stream-ordered call.  Shortest critical path beside a CAPPED K1
+//          (explicit k1_blocks_per_cu, per-text form): 232 vs 248 us per step; there the in-launch loss
+//          mean also loses (its ticket round trip queues behind the gather's loads).
 // projection tiles that pair with how the gathers are reserved (gather_pool.hip "Sharing the chip")
 static int tile_policy(const tt_engine* e) {
   return !e->shared ? ttp::kTileAuto : (e->tile_above ? ttp::kTileSmall : ttp::kTileLowTraffic);
 }
 
 static bool use_fork(const tt_engine* e) {
-  bool fork = e->shared && e->aux != nullptr && e->gathers_share_chip;
+  bool fork = e->shared && !e->tile_above && e->aux != nullptr && e->gathers_share_chip;
   if (const char* v = getenv("TT_BWD"))  // "fork" / "fused" force a schedule (A/B runs); anything else: automatic
     if (v[0] == 'f') fork = e->aux != nullptr && v[1] == 'o';
   return fork;

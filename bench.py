@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 CONFIGS = {
     # name: V, D, P, B per GPU, S
     "c2": dict(V=30522, D=384, P=384, B=2048, S=128, label="configs[1]: MiniLM-L6 table V=30522 d=384, proj 384, batch 2048/GPU, seq 128"),
+    "c3": dict(V=30522, D=384, P=512, B=1024, S=128, label="configs[2]: one GPU's share of batch 8192 over 8 GPUs (1024/GPU), proj 512, seq 128"),
     "c4": dict(V=250000, D=768, P=768, B=16384, S=256, label="configs[3]: synthetic V=250k d=768 proj 768 batch 16384/GPU seq 256 (HBM stress)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)

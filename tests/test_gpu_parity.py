@@ -672,3 +672,42 @@ def test_inbatch_metric_size_properties(tt):
     assert abs(loss_p.item() - loss.item()) <= 1e-6
     close(dq_p, dq[perm], rel_to_max=True, atol=1e-6)
     close(dd_p, dd[perm], rel_to_max=True, atol=1e-6)
+
+
+def test_pool_forms_fuzz(tt):
+    """Seeded fuzz over shapes, index / mask widths, mask kinds and out-of-range ids: both K1 forms against the
+    oracle (ids clamped the way the kernels clamp them) and against each other."""
+    ops, _ = tt
+    gen = torch.Generator().manual_seed(20240607)
+    for case in range(48):
+        D = int(torch.randint(1, 65, (1,), generator=gen)) * 4
+        S = int(torch.randint(1, 200, (1,), generator=gen))
+        V = int(torch.randint(1, 3000, (1,), generator=gen))
+        N = int(torch.randint(1, 40, (1,), generator=gen))
+        table = torch.randn(V, D, generator=gen)
+        ids = torch.randint(0, V, (N, S), generator=gen)
+        kind = case % 4
+        mask = lens = None
+        if kind == 0:
+            lens = torch.randint(0, S + 1, (N,), generator=gen)
+            eff = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+        elif kind == 1:
+            mask = (torch.rand(N, S, generator=gen) < 0.7).long()
+            eff = mask
+        elif kind == 2:
+            mask = torch.randint(0, 4, (N, S), generator=gen)  # weights other than 0/1 are honoured
+            eff = mask
+        else:
+            eff = torch.ones(N, S, dtype=torch.long)
+        if case % 5 == 0:  # ids outside the table are clamped into it (and flagged), never read out of range
+            ids[0, 0] = V + 7
+            ids[-1, -1] = -3
+        ref = orc.gather_pool_normalize(table, ids.clamp(0, V - 1), eff)
+        idt = torch.int32 if case % 2 else torch.int64
+        mt = torch.int32 if case % 3 else torch.int64
+        kw = dict(attention_mask=None if mask is None else mask.to(mt).cuda(), lens=None if lens is None else lens.int().cuda())
+        a = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=False, **kw)
+        b = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=True, **kw)
+        close(a, ref, atol=2e-6)
+        close(b, ref, atol=2e-6)
+        assert (a - b).abs().max().item() <= 1e-6, (case, D, S, V, N, kind)

@@ -63,6 +63,14 @@ int forward(const Tower* t, int count, int D, int P, hipStream_t st, int policy)
   return ttg::launch(ttg::kNT, ttg::kBias, b2, wm, wn, st);
 }
 
+// Weight-gradient launches put the towers with more rows (longer K loops) first: workgroups are placed in
+// index order, so the short ones then fill in behind the long ones instead of the other way round.
+static int tn_slot(const Tower* t, int count, int i) {
+  static const bool lpt = !(getenv("TT_TN_LPT") && getenv("TT_TN_LPT")[0] == '0');
+  if (!lpt || count != 2) return i;
+  return (t[1].M > t[0].M) ? 1 - i : i;
+}
+
 int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
   ttg::Batch g2{};
   g2.count = count;
@@ -70,7 +78,7 @@ int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long 
   g2.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW2[i,j] = sum_m dOut[m,i] H[m,j];  db2[i] = sum_m dOut[m,i]
-    ttg::Problem& a = g2.p[i];
+    ttg::Problem& a = g2.p[tn_slot(t, count, i)];
     a.A = t[i].dOut; a.B = t[i].H; a.C = t[i].gW2; a.colsum = t[i].gb2;
     a.M = P; a.N = P; a.K = t[i].M; a.lda = P; a.ldb = P; a.ldc = P; a.k_per_split = k_per_split(t[i].M, nsplit);
   }
@@ -104,7 +112,7 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
-    ttg::Problem& a = g2.p[i];
+    ttg::Problem& a = g2.p[tn_slot(t, count, i)];
     a.A = t[i].dOut; a.B = t[i].H; a.C = t[i].gW2; a.colsum = t[i].gb2;
     a.M = P; a.N = P; a.K = t[i].M; a.lda = P; a.ldb = P; a.ldc = P; a.k_per_split = k_per_split(t[i].M, nsplit);
     ttg::Problem& h = gh.p[i];
@@ -128,7 +136,7 @@ int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long 
   g1.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW1[i,j] = sum_m dH[m,i] X[m,j];  db1[i] = sum_m dH[m,i]
-    ttg::Problem& c = g1.p[i];
+    ttg::Problem& c = g1.p[tn_slot(t, count, i)];
     c.A = t[i].dH; c.B = t[i].X; c.C = t[i].gW1; c.colsum = t[i].gb1;
     c.M = P; c.N = D; c.K = t[i].M; c.lda = P; c.ldb = D; c.ldc = D; c.k_per_split = k_per_split(t[i].M, nsplit);
   }

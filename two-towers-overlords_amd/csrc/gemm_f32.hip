@@ -20,6 +20,7 @@
 // computes, bitwise), K-steps in ascending order; split-K (kTN) partials go to
 // separate slabs that are summed in fixed order later => run-to-run bitwise
 // reproducible, no float atomics.
+#include <cstdlib>
 #include <type_traits>
 #include "gemm_f32.h"
 
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
 struct PairGeom {
   int tn_gx, tn_gy, tn_blocks;  // TN tile grid (x, y) and total TN workgroups (gx*gy*gz)
   int nn_gx, nn_gy;
+  int tn_head, nn_blocks;       // workgroup order: TN [0, tn_head), all NN, the remaining TN (longest K loops first)
 };
 
 template <int WM, int WN>
@@ -389,12 +391,14 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_nn_kernel(const Batch bt, co
   constexpr int LT = TileCfg<kTN, 1, 1>::LDS_FLOATS, LN = TileCfg<kNN, WM, WN>::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LT > LN ? LT : LN];
   int id = blockIdx.x;
-  if (id < g.tn_blocks) {
+  const bool is_tn = id < g.tn_head || id >= g.tn_head + g.nn_blocks;
+  if (is_tn) {
+    if (id >= g.tn_head) id -= g.nn_blocks;
     const int per_z = g.tn_gx * g.tn_gy;
     const int z = id / per_z, rem = id - z * per_z;
     gemm_body<kTN, kStore, 1, 1, true>(bt, lds, rem % g.tn_gx, rem / g.tn_gx, z);
   } else {
-    id -= g.tn_blocks;
+    id -= g.tn_head;
     const int per_z = g.nn_gx * g.nn_gy;
     const int z = id / per_z, rem = id - z * per_z;
     gemm_body<kNN, kReluMask, WM, WN, true>(bn, lds, rem % g.nn_gx, rem / g.nn_gx, z);
@@ -453,8 +457,14 @@ int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStrea
   g.tn_blocks = g.tn_gx * g.tn_gy * bt.count * bt.nsplit;
   g.nn_gx = (nN + 64 * wn - 1) / (64 * wn);
   g.nn_gy = (nM + 64 * wm - 1) / (64 * wm);
-  const long long total = (long long)g.tn_blocks + (long long)g.nn_gx * g.nn_gy * bn.count;
+  const long long nn_total = (long long)g.nn_gx * g.nn_gy * bn.count;
+  const long long total = (long long)g.tn_blocks + nn_total;
   if (total > 0x7fffffffLL) return TT_ERR_BAD_SHAPE;
+  g.nn_blocks = (int)nn_total;
+  // TN problems arrive longest-K first (proj.hip): the first problem's workgroups lead, the NN tiles (K = P) follow,
+  // shorter TN problems close the grid.  TT_PAIR_ORDER=0: all TN first (A/B).
+  static const bool mid = !(getenv("TT_PAIR_ORDER") && getenv("TT_PAIR_ORDER")[0] == '0');
+  g.tn_head = (mid && bt.count > 1 && bt.p[0].K > bt.p[1].K) ? g.tn_gx * g.tn_gy * bt.nsplit : g.tn_blocks;
   const dim3 grid((unsigned)total), block(kThreads);
   if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1>), grid, block, 0, st, bt, bn, g);
   else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1>), grid, block, 0, st, bt, bn, g);

@@ -140,3 +140,38 @@ def test_packed_token_files_round_trip(tmp_path):
     for tb in c:
         qid = torch.tensor(c.query_ids)
         assert tb.neg_index.dtype == torch.int32 and tb.ids.shape[0] == 2
+
+
+def test_device_sampler_loader_needs_no_per_batch_shapes_and_keeps_triplet_structure():
+    """sampler="device" (default pad="max"): every batch is padded to the collection's longest row (so nothing
+    about a batch has to be read back to size it), negatives are in-batch positives of a different query,
+    the three emit modes describe the same triplets, and a batch without two distinct queries raises on the
+    host (the reference would spin forever in create_triplets, backend/data.py:124-128)."""
+    import pytest
+
+    ds = _DS(23, 6)
+    mk = lambda emit: TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit=emit, sampler="device")
+    a, b = list(mk("ids3")), list(mk("index"))
+    ld = mk("cache")
+    c = list(ld)
+    assert ld.pad == "max"
+    Smax = max(ld.q_ids.shape[1], ld.p_ids.shape[1])
+    qid = torch.tensor(ld.query_ids)
+    total = 0
+    for (ids3, lens3), bi, bc in zip(a, b, c):
+        B = ids3.shape[1]
+        total += B
+        assert ids3.shape == (3, B, Smax) and bi.ids.shape == (2, B, Smax)
+        e = bi.expand_negatives()
+        assert torch.equal(e.ids, ids3) and torch.equal(e.lens, lens3) and torch.equal(bc.neg_index, bi.neg_index)
+        items = bc.cache_rows[0].long()                       # dataset indices of the batch
+        assert bool((qid[items][bi.neg_index.long()] != qid[items]).all())
+        assert int((ids3 * (torch.arange(Smax).view(1, 1, -1) >= lens3.unsqueeze(-1))).abs().sum()) == 0
+    assert total == 23
+
+    class _One(_DS):
+        def __init__(self):
+            super().__init__(6, 1)
+
+    with pytest.raises(RuntimeError):
+        list(TokenTripletLoader(_One(), _tok, batch_size=4, device="cpu", seed=1, sampler="device"))

@@ -90,38 +90,42 @@ def _inbatch_setup():
     return table, params, batches, qids, (Vv, Dd, Pp, Bb, Ss, nb)
 
 
-def _inbatch_reference():
+def _inbatch_reference(Bg):
     table, params, batches, qids, (_, _, _, Bb, _, nb) = _inbatch_setup()
     st = orc.AdamState(lr=1e-3)
     losses = []
     for (qb, pb), qid in zip(batches, qids):
         leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-        q = orc.encode(table, qb[0], qb[1], leaves, "query_tower")
-        d = orc.encode(table, pb[0], pb[1], leaves, "document_tower")
-        loss = orc.inbatch_triplet_loss(q, d, 0.2, None, qid, qid)
+        q = orc.encode(table, qb[0][:Bg], qb[1][:Bg], leaves, "query_tower")
+        d = orc.encode(table, pb[0][:Bg], pb[1][:Bg], leaves, "document_tower")
+        loss = orc.inbatch_triplet_loss(q, d, 0.2, None, qid[:Bg], qid[:Bg])
         loss.backward()
         orc.adam_step(params, {k: v.grad for k, v in leaves.items()}, st)
         losses.append(loss.item())
     return sum(losses) / nb, params
 
 
-def _inbatch_worker(rank, world, port, q):
+def _inbatch_worker(rank, world, port, Bg, q):
     try:
-        from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
+        from two_towers_overlords_amd.training import TripletBatch, TripletTrainer, shard_batch
 
         if world > 1:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         torch.cuda.set_device(0)
         table, params, batches, qids, (_, _, _, Bb, Ss, _) = _inbatch_setup()
-        n = Bb // world
-        tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=n,
-                            max_seq_len=Ss, margin=0.2, lr=1e-3, loss="inbatch")
-        sl = slice(rank * n, (rank + 1) * n)
-        shards = [TripletBatch(ids=torch.stack([qb[0][sl], pb[0][sl]]).int().cuda(),
-                               lens=torch.stack([qb[1][sl].sum(1), pb[1][sl].sum(1)]).int().cuda(),
-                               query_ids=qid[sl].cuda()) for (qb, pb), qid in zip(batches, qids)]
-        avg = tr.train_epoch(shards)
+        tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()},
+                            max_batch=(Bg + world - 1) // world, max_seq_len=Ss, margin=0.2, lr=1e-3, loss="inbatch")
+        shards, sizes = [], []
+        for (qb, pb), qid in zip(batches, qids):  # the global batch (first Bg rows), then this rank's contiguous shard
+            gb = TripletBatch(ids=torch.stack([qb[0][:Bg], pb[0][:Bg]]).int().cuda(),
+                              lens=torch.stack([qb[1][:Bg].sum(1), pb[1][:Bg].sum(1)]).int().cuda(),
+                              query_ids=qid[:Bg].cuda())
+            sh, n = shard_batch(gb, rank, world)
+            assert sh.query_ids.shape[0] == sh.size
+            shards.append(sh)
+            sizes.append(n)
+        avg = tr.train_epoch(shards, global_batch_sizes=sizes)
         if rank == 0:
             q.put(("ok", avg, {k: v.cpu().numpy().copy() for k, v in tr.named_parameters().items()}))
         if world > 1:
@@ -134,14 +138,15 @@ def _inbatch_worker(rank, world, port, q):
         raise
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_inbatch_negatives_trainer_vs_oracle(world):
+@pytest.mark.parametrize("world,Bg", [(1, 64), (2, 64), (2, 63)])
+def test_inbatch_negatives_trainer_vs_oracle(world, Bg):
     """In-batch-negatives loss through the trainer: one rank, and two ranks exchanging document
-    embeddings (all-gather) and their gradient (all-reduce), against the oracle's autograd."""
+    embeddings + query ids (all-gather) and the documents' gradient (all-reduce) — equal shards
+    and uneven ones (63 = 32 + 31: zero-padded exchange blocks) — against the oracle's autograd."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    port = 29700 + os.getpid() % 1000 + world
-    procs = [ctx.Process(target=_inbatch_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29700 + os.getpid() % 1000 + world + Bg
+    procs = [ctx.Process(target=_inbatch_worker, args=(r, world, port, Bg, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get()
@@ -149,7 +154,7 @@ def test_inbatch_negatives_trainer_vs_oracle(world):
         p.join(180)
     assert out[0] == "ok", out[1]
     _, avg, params = out
-    ref_avg, ref_params = _inbatch_reference()
+    ref_avg, ref_params = _inbatch_reference(Bg)
     assert abs(avg - ref_avg) <= 1e-5
     from conftest import assert_params_close
 

@@ -275,3 +275,91 @@ def test_training_is_bitwise_reproducible(overlap):
         runs.append((losses, tr.flat.clone()))
     assert runs[0][0] == runs[1][0]
     assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_gather_is_ordered_behind_batches_produced_on_the_callers_stream():
+    """K1 runs on the trainer's side stream and reads ids / lens that the CALLER's stream produces:
+    here every batch arrives by a non_blocking host->device copy queued behind ~tens of ms of other
+    work on that stream, is dropped by the producer right after the yield, and its memory is
+    immediately asked for again and overwritten.  The trainer has to (a) make the side stream wait
+    for the producer, (b) keep the tensors alive until the main stream is ordered behind the
+    gather.  Result must be bitwise the run on pre-staged, synchronised batches."""
+    from two_towers_overlords_amd.training import TripletTrainer
+
+    V, D, P, B, S, NB = 5000, 384, 64, 256, 64, 6
+    table = orc.synthetic_table(V, D, seed=1) * 30
+    params = orc.init_params(D, P, seed=2)
+    host = []
+    for i in range(NB):
+        b = orc.synthetic_batch(B, S, V, seed=900 + i, ragged=True)
+        host.append((torch.stack([r[0] for r in b]).int().pin_memory(), torch.stack([r[1].sum(1) for r in b]).int().pin_memory()))
+
+    def trainer():
+        return TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B,
+                              max_seq_len=S, margin=0.3, lr=1e-3, overlap_streams=True)
+
+    staged = [(i.cuda(), None, l.cuda()) for i, l in host]
+    torch.cuda.synchronize()
+    ref = trainer()
+    ref_loss = ref.train_epoch(staged)
+
+    busy = torch.randn(4096, 4096, device="cuda")
+
+    def late_batches():
+        for ids_h, lens_h in host:
+            for _ in range(6):          # the producer's stream is busy: the copies below land late
+                busy @ busy
+            ids = ids_h.to("cuda", non_blocking=True)
+            lens = lens_h.to("cuda", non_blocking=True)
+            yield (ids, None, lens)
+            del ids, lens               # producer drops the batch; a same-sized request may get its memory
+            scratch = torch.full((3, B, S), V - 1, dtype=torch.int32, device="cuda")
+            scratch2 = torch.full((3, B), 1, dtype=torch.int32, device="cuda")
+            del scratch, scratch2
+
+    tr = trainer()
+    loss = tr.train_epoch(late_batches())
+    assert loss == ref_loss
+    assert torch.equal(tr.flat, ref.flat)
+
+
+def test_token_loader_device_sampler_trains_like_reference_sampler_statistically():
+    """TokenTripletLoader(sampler="device", pad="max"): no per-batch host read-back; batches are valid
+    triplets (negative = another in-batch item's positive, different query) and an epoch through the
+    trainer runs end to end."""
+    import random
+
+    from test_gpu_eval import IntTokenizer
+    from two_towers_overlords_amd.data import TokenTripletLoader
+    from two_towers_overlords_amd.training import TripletTrainer
+
+    rng = random.Random(4)
+    V, items = 500, []
+    for qid in range(200):
+        qt = [rng.randrange(1, V) for _ in range(rng.randint(3, 8))]
+        for _ in range(rng.randint(1, 4)):
+            doc = [rng.randrange(1, V) for _ in range(rng.randint(6, 40))]
+            items.append({"query_id": qid, "query": " ".join(map(str, qt)), "positive": " ".join(map(str, doc))})
+    ld = TokenTripletLoader(items, IntTokenizer(), batch_size=64, device="cuda", seed=7, sampler="device")
+    assert ld.pad == "max"
+    qid_t = torch.tensor([it["query_id"] for it in items], device="cuda")
+    seen = 0
+    for ids, lens in ld:
+        B, S = ids.shape[1], ids.shape[2]
+        assert S == max(ld.q_ids.shape[1], ld.p_ids.shape[1]) and ids.dtype == torch.int32
+        # every negative row is some in-batch positive row of a different query
+        same = (ids[2].unsqueeze(1) == ids[1].unsqueeze(0)).all(-1)          # [B neg, B pos]
+        assert bool(same.any(1).all())
+        qrow = ids[0]
+        j = same.float().argmax(1)
+        assert bool((qrow[j] != qrow).any(-1).all())
+        seen += B
+    assert seen == len(items)
+    table = orc.synthetic_table(V, 64, seed=9) * 30
+    params = orc.init_params(64, 32, seed=3)
+    tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=64,
+                        max_seq_len=max(ld.q_ids.shape[1], ld.p_ids.shape[1]), margin=0.3, lr=1e-2)
+    l0 = tr.train_epoch((ids, None, lens) for ids, lens in ld)
+    for _ in range(4):
+        l1 = tr.train_epoch((ids, None, lens) for ids, lens in ld)
+    assert l1 < l0

@@ -74,11 +74,12 @@ def _worker_body(rank, world, port, accum, q):
         dist.destroy_process_group()
 
 
-def _run(world, accum):
+def _run(world, accum, worker=None):
+    worker = worker or _worker
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    port = 29500 + (os.getpid() % 2000) + 7 * world + accum
-    procs = [ctx.Process(target=_worker, args=(r, world, port, accum, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world + accum + (0 if worker is _worker else 31)
+    procs = [ctx.Process(target=worker, args=(r, world, port, accum, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get()
@@ -97,6 +98,66 @@ def test_sharded_epoch_equals_single_replica(world, accum):
     assert abs(avg - ref_avg) < 1e-6
     for k in orc.PARAM_KEYS:
         np.testing.assert_allclose(params[k], ref_params[k].numpy(), atol=2e-6, rtol=0)
+
+
+def _worker_unsynced(rank, world, port, accum, q):
+    """Ranks build DIFFERENT initial projections (what nn.Linear's per-process default init gives,
+    backend/model.py:33-38): the trainer must start every replica from rank 0's, and a global batch
+    smaller than the world (an empty shard on rank 1) must not stall the step's all-reduce."""
+    try:
+        from oracle_engine import OracleEngine
+        from two_towers_overlords_amd.training import TripletTrainer, shard_batch
+
+        torch.set_num_threads(1)
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        table, params, batches = _setup()
+        mine = {k: v.clone() for k, v in params.items()} if rank == 0 else orc.init_params(D, P, seed=900 + rank)
+        tr = TripletTrainer(table=table, params=mine, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
+                            accumulation_steps=1, engine=OracleEngine(table, P, B, S))
+        div0 = tr.replica_divergence()
+        gbs = _global_batches(batches)
+        gbs.append(tuple(None if t is None else t[:, :1].contiguous() for t in gbs[0]))  # one triplet for two ranks
+        shards, sizes = [], []
+        for gb in gbs:
+            sh, n = shard_batch(gb, rank, world)
+            shards.append(sh)
+            sizes.append(n)
+        assert shards[-1][0].shape[1] == (1 if rank == 0 else 0)
+        avg = tr.train_epoch(shards, global_batch_sizes=sizes)
+        div1 = tr.replica_divergence()
+        if rank == 0:
+            q.put((avg, {k: v.detach().numpy().copy() for k, v in tr.named_parameters().items()}, (div0, div1)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+
+        q.put(("error", f"rank {rank}: {e}\n{traceback.format_exc()}", None))
+        raise
+
+
+def test_replicas_start_from_rank0_and_empty_shard_takes_part():
+    avg, params, (div0, div1) = _run(2, 1, worker=_worker_unsynced)
+    assert div0 == 0.0 and div1 == 0.0  # in step after construction and after the epoch
+    table, ref_params, batches = _setup()
+    one = tuple([r[0][:1], r[1][:1]] for r in batches[0])
+    st = orc.AdamState(lr=1e-3)
+    ref_avg, _ = orc.train_epoch(table, batches + [one], ref_params, st, 0.3)
+    assert abs(avg - ref_avg) < 1e-6
+    for k in orc.PARAM_KEYS:
+        np.testing.assert_allclose(params[k], ref_params[k].numpy(), atol=2e-6, rtol=0)
+
+
+def test_shard_batch_carries_query_ids():
+    from two_towers_overlords_amd.training import TripletBatch, shard_batch
+
+    tb = TripletBatch(ids=torch.arange(2 * 7 * 3).view(2, 7, 3), lens=torch.ones(2, 7).int(),
+                      query_ids=torch.arange(7) * 10)
+    parts = [shard_batch(tb, r, 3)[0] for r in range(3)]
+    assert [p.size for p in parts] == [3, 2, 2]
+    assert torch.equal(torch.cat([p.query_ids for p in parts]), tb.query_ids)
+    assert all(p.query_ids.shape[0] == p.size for p in parts)
 
 
 def test_shard_batch_partition():

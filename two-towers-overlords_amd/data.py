@@ -42,34 +42,33 @@ def sample_negative_indices(query_ids: Sequence[int], rng=random) -> List[int]:
 
 
 def sample_negative_indices_device(query_ids: torch.Tensor, generator: Optional[torch.Generator] = None,
-                                   max_rounds: int = 64) -> torch.Tensor:
-    """Same distribution as `sample_negative_indices` (uniform over the other in-batch items,
-    redrawn while the query_id is equal — backend/data.py:113-137), drawn for the whole batch at
-    once with tensor ops on `query_ids`' device: O(B) per round instead of the reference's O(B^2)
-    Python list building per batch.  Not the same *draws* as the reference under a shared seed.
-    Raises if some item has no admissible negative (the reference would loop forever)."""
+                                   check: bool = True) -> torch.Tensor:
+    """Same distribution as `sample_negative_indices` (uniform over the in-batch items of a
+    different query — what backend/data.py:113-137's rejection loop converges to), drawn for the
+    whole batch at once on `query_ids`' device, exactly and without rejection: sort the batch by
+    query id, so the items item i must NOT draw form one contiguous run [a_i, b_i) of the sorted
+    order; draw u uniformly from the B - (b_i - a_i) admissible positions and skip over the run.
+    O(B log B) tensor work against the reference's O(B^2) Python list building per batch, and no
+    host synchronisation when `check=False` (the caller has then verified on the host that the
+    batch holds at least two distinct query ids).  Not the same *draws* as the reference under a
+    shared seed.  With `check=True` raises like the reference fails: IndexError for a batch of
+    one (`random.choice([])`), RuntimeError when every item shares one query id (the reference
+    never returns)."""
     B = query_ids.numel()
     if B < 2:
         raise IndexError("cannot draw an in-batch negative from a batch of one")  # reference: random.choice([])
-    dev = query_ids.device
-    ar = torch.arange(B, device=dev)
-    neg = torch.empty(B, dtype=torch.long, device=dev)
-    todo = ar
-    for _ in range(max_rounds):
-        j = torch.randint(0, B - 1, (todo.numel(),), generator=generator, device=dev)
-        j = j + (j >= todo).long()          # uniform over the B-1 items other than i
-        ok = query_ids[j] != query_ids[todo]
-        neg[todo[ok]] = j[ok]
-        todo = todo[~ok]
-        if todo.numel() == 0:
-            return neg
-    # leftovers: items whose admissible set is tiny or empty — enumerate it exactly
-    for i in todo.tolist():
-        cand = ar[query_ids != query_ids[i]]
-        if cand.numel() == 0:
-            raise RuntimeError("every item of the batch shares one query_id: no admissible negative")
-        neg[i] = cand[torch.randint(0, cand.numel(), (1,), generator=generator, device=dev)]
-    return neg
+    q = query_ids.reshape(-1)
+    sorted_q, perm = torch.sort(q)
+    run_lo = torch.searchsorted(sorted_q, q, right=False)
+    run_hi = torch.searchsorted(sorted_q, q, right=True)
+    run = run_hi - run_lo
+    admissible = B - run
+    if check and int(admissible.min()) == 0:
+        raise RuntimeError("every item of the batch shares one query_id: no admissible negative")
+    u = torch.rand(B, generator=generator, device=q.device, dtype=torch.float64)
+    pick = torch.minimum((u * admissible).long(), (admissible - 1).clamp_(min=0))
+    pick = torch.where(pick < run_lo, pick, pick + run)
+    return perm[pick.clamp_(max=B - 1)]
 
 
 class PackedTokens:
@@ -157,6 +156,14 @@ class TripletDataLoader:
         return len(self.dataloader)
 
 
+class _Rows:
+    """Padded token rows handed to TokenTripletLoader.from_tensors."""
+
+    def __init__(self, q_ids, q_lens, p_ids, p_lens, query_ids):
+        self.q_ids, self.q_lens, self.p_ids, self.p_lens = q_ids, q_lens, p_ids, p_lens
+        self.query_ids = query_ids.tolist() if hasattr(query_ids, "tolist") else list(query_ids)
+
+
 class TokenTripletLoader:
     """Device-side triplet batches for the fused engine: yields
     (ids [3,B,S] int32, lens [3,B] int32) with rows ordered (query, positive,
@@ -172,29 +179,43 @@ class TokenTripletLoader:
 
     def __init__(self, dataset, tokenizer: Optional[Callable], batch_size: int, device, max_length: int = 512,
                  seed: Optional[int] = None, shuffle: bool = True, emit: str = "ids3", sampler: str = "reference",
-                 packed: Optional[Tuple["PackedTokens", "PackedTokens", Sequence[int]]] = None):
+                 packed: Optional[Tuple["PackedTokens", "PackedTokens", Sequence[int]]] = None,
+                 pad: Optional[str] = None):
         """sampler: "reference" — `sample_negative_indices`, the reference's draws under the same seed
                     (O(B^2) Python per batch, like backend/data.py:132-137); "device" — the same
-                    distribution drawn with tensor ops (`sample_negative_indices_device`).
+                    distribution drawn with tensor ops (`sample_negative_indices_device`), no host
+                    synchronisation per batch.
         packed: (queries, positives, query_ids) as PackedTokens instead of tokenising `dataset`.
         emit: "ids3"  -> (ids [3,B,S], lens [3,B])                      three gathers per batch
                  "index" -> TripletBatch(ids [2,B,S], lens, neg_index)     negatives by in-batch index
                  "cache" -> TripletBatch(cache_rows [2,B], neg_index)      rows of a frozen-feature cache
                             laid out [queries (N); positives (N)] — build it with
-                            `trainer.build_feature_cache(*loader.all_texts())`"""
+                            `trainer.build_feature_cache(*loader.all_texts())`
+        pad: "batch" — S = the longest row of the batch, what `padding=True` gives each call of
+                    backend/model.py:43-45 (costs one device->host read per batch); "max" — S = the
+                    longest row of the collection (no read-back; K1 never fetches past a row's length,
+                    so the extra padding is free).  Default: "batch" with the reference sampler,
+                    "max" with the device sampler."""
         if emit not in ("ids3", "index", "cache"):
             raise ValueError("emit must be 'ids3', 'index' or 'cache'")
         if sampler not in ("reference", "device"):
             raise ValueError("sampler must be 'reference' or 'device'")
+        if pad not in (None, "batch", "max"):
+            raise ValueError("pad must be 'batch' or 'max'")
         self.emit = emit
         self.sampler = sampler
+        self.pad = pad or ("max" if sampler == "device" else "batch")
         self.batch_size = batch_size
         self.device = torch.device(device)
         self.shuffle = shuffle
         self.rng = random.Random(seed) if seed is not None else random
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed if seed is not None else random.getrandbits(60))
-        if packed is not None:
+        if isinstance(packed, _Rows):
+            self.query_ids = [int(x) for x in packed.query_ids]
+            self.q_ids, self.q_lens = packed.q_ids.to(self.device, torch.int32), packed.q_lens.to(self.device, torch.int32)
+            self.p_ids, self.p_lens = packed.p_ids.to(self.device, torch.int32), packed.p_lens.to(self.device, torch.int32)
+        elif packed is not None:
             pq, pp, qids = packed
             self.query_ids = [int(x) for x in qids]
             self.q_ids, self.q_lens = pq.padded(self.device)
@@ -205,12 +226,18 @@ class TokenTripletLoader:
             self.query_ids = [int(it["query_id"]) for it in items]
             self.q_ids, self.q_lens = self._tokenize(tokenizer, [it["query"] for it in items], max_length)
             self.p_ids, self.p_lens = self._tokenize(tokenizer, [it["positive"] for it in items], max_length)
-        self._qid_t = torch.tensor(self.query_ids, device=self.device)
+        import numpy as np
+
+        self._qid_np = np.asarray(self.query_ids, dtype=np.int64)
+        self._qid_t = torch.from_numpy(self._qid_np).to(self.device)
+        self._padded = None  # (q_ids, p_ids) padded to one common S (pad="max")
 
     def _tokenize(self, tokenizer, texts, max_length):
         tok = tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=max_length)
         ids, mask = tok["input_ids"], tok["attention_mask"]
         lens = mask.sum(1)
+        if int(lens.max()) < ids.shape[1]:  # a tokenizer may pad beyond the longest row
+            ids, mask = ids[:, : max(int(lens.max()), 1)], mask[:, : max(int(lens.max()), 1)]
         if not torch.equal(mask, (torch.arange(mask.shape[1]).unsqueeze(0) < lens.unsqueeze(1)).to(mask.dtype)):
             raise ValueError("TokenTripletLoader expects prefix (right-padded) attention masks")
         return ids.to(torch.int32).to(self.device), lens.to(torch.int32).to(self.device)
@@ -234,49 +261,89 @@ class TokenTripletLoader:
         return cls(None, None, batch_size, device,
                    packed=(PackedTokens.load(prefix + ".q"), PackedTokens.load(prefix + ".p"), qids), **kw)
 
+    @classmethod
+    def from_tensors(cls, q_ids: torch.Tensor, q_lens: torch.Tensor, p_ids: torch.Tensor, p_lens: torch.Tensor,
+                     query_ids, batch_size: int, device, **kw) -> "TokenTripletLoader":
+        """Already tokenised, padded rows: q_ids [N,Sq] / p_ids [N,Sp] int32, lengths [N] int32,
+        query_ids [N] (one per item).  No copy is made of tensors already on `device`."""
+        self = cls.__new__(cls)
+        cls.__init__(self, None, None, batch_size, device, packed=_Rows(q_ids, q_lens, p_ids, p_lens, query_ids), **kw)
+        return self
+
     def all_texts(self):
         """(ids [2N, S], lens [2N]) of every query then every positive — the input of the feature cache."""
         S = max(self.q_ids.shape[1], self.p_ids.shape[1])
         pad = lambda t: torch.nn.functional.pad(t, (0, S - t.shape[1]))
         return torch.cat([pad(self.q_ids), pad(self.p_ids)]).contiguous(), torch.cat([self.q_lens, self.p_lens]).contiguous()
 
+    def _common(self):
+        """(q_ids, p_ids) zero-padded to one common S, built once (pad="max")."""
+        if self._padded is None:
+            S = max(self.q_ids.shape[1], self.p_ids.shape[1])
+            pad = lambda t: t if t.shape[1] == S else torch.nn.functional.pad(t, (0, S - t.shape[1])).contiguous()
+            self._padded = (pad(self.q_ids), pad(self.p_ids))
+        return self._padded
+
+    def _negatives(self, idx, it) -> torch.Tensor:
+        """In-batch negative indices (int64 [B] on the device) of the batch whose items are `idx`."""
+        if self.sampler == "device":
+            qb = self._qid_np[idx]
+            if len(idx) < 2:
+                raise IndexError("cannot draw an in-batch negative from a batch of one")
+            if qb.min() == qb.max():  # checked on the host, so that the device draw needs no read-back
+                raise RuntimeError("every item of the batch shares one query_id: no admissible negative")
+            return sample_negative_indices_device(self._qid_t[it], self.gen, check=False)
+        return torch.tensor(sample_negative_indices([self.query_ids[i] for i in idx], self.rng), device=self.device)
+
     def __iter__(self):
+        import numpy as np
+
         n = len(self.query_ids)
         order = list(range(n))
         if self.shuffle:
             self.rng.shuffle(order)
+        order_np = np.asarray(order, dtype=np.int64)
+        order_t = torch.from_numpy(order_np).to(self.device)  # one host->device copy per epoch
+        n_items = n
         for s in range(0, n, self.batch_size):
-            idx = order[s: s + self.batch_size]
-            it = torch.tensor(idx, device=self.device)
-            if self.sampler == "device":
-                neg_t = sample_negative_indices_device(self._qid_t[it], self.gen)
-            else:
-                neg_t = torch.tensor(sample_negative_indices([self.query_ids[i] for i in idx], self.rng), device=self.device)
-            if self.emit != "ids3":
+            idx = order_np[s: s + self.batch_size]
+            it = order_t[s: s + self.batch_size]
+            neg_t = self._negatives(idx, it)
+            B = len(idx)
+            if self.emit == "cache":
                 from .training import TripletBatch
 
-                ni = neg_t.to(torch.int32)
-                if self.emit == "cache":
-                    n_items = len(self.query_ids)
-                    rows = torch.stack([it, it + n_items]).to(torch.int32).contiguous()
-                    yield TripletBatch(cache_rows=rows, neg_index=ni)
+                rows = torch.stack([it, it + n_items]).to(torch.int32).contiguous()
+                yield TripletBatch(cache_rows=rows, neg_index=neg_t.to(torch.int32))
+                continue
+            roles = 3 if self.emit == "ids3" else 2
+            ql, pl = self.q_lens[it], self.p_lens[it]
+            if self.pad == "max":  # no read-back: every batch is padded to the collection's longest row
+                qsrc, psrc = self._common()
+                S = qsrc.shape[1]
+                ids = torch.empty((roles, B, S), dtype=torch.int32, device=self.device)
+                torch.index_select(qsrc, 0, it, out=ids[0])
+                torch.index_select(psrc, 0, it, out=ids[1])
+                if roles == 3:
+                    nt = it[neg_t]
+                    torch.index_select(psrc, 0, nt, out=ids[2])
+                    yield ids, torch.stack([ql, pl, self.p_lens[nt]])
                     continue
-                q, ql = self.q_ids[it], self.q_lens[it]
-                p, pl = self.p_ids[it], self.p_lens[it]
-                S = int(max(int(ql.max()), int(pl.max())))
-                ids = torch.zeros((2, len(idx), S), dtype=torch.int32, device=self.device)
+            else:  # pad to the longest row of this batch, like `padding=True` does per call
+                q, p = self.q_ids[it], self.p_ids[it]
+                if roles == 3:
+                    nt = it[neg_t]
+                    ng, nl = self.p_ids[nt], self.p_lens[nt]
+                    S = int(torch.stack([ql.max(), pl.max(), nl.max()]).max())
+                else:
+                    S = int(torch.stack([ql.max(), pl.max()]).max())
+                ids = torch.zeros((roles, B, S), dtype=torch.int32, device=self.device)
                 ids[0, :, : min(S, q.shape[1])] = q[:, :S]
                 ids[1, :, : min(S, p.shape[1])] = p[:, :S]
-                yield TripletBatch(ids=ids, lens=torch.stack([ql, pl]), neg_index=ni)
-                continue
-            nt = it[neg_t]
-            q, ql = self.q_ids[it], self.q_lens[it]
-            p, pl = self.p_ids[it], self.p_lens[it]
-            ng, nl = self.p_ids[nt], self.p_lens[nt]
-            # pad to the longest row of this batch, like `padding=True` does per call
-            S = int(max(int(ql.max()), int(pl.max()), int(nl.max())))
-            ids = torch.zeros((3, len(idx), S), dtype=torch.int32, device=self.device)
-            ids[0, :, : min(S, q.shape[1])] = q[:, :S]
-            ids[1, :, : min(S, p.shape[1])] = p[:, :S]
-            ids[2, :, : min(S, ng.shape[1])] = ng[:, :S]
-            yield ids, torch.stack([ql, pl, nl])
+                if roles == 3:
+                    ids[2, :, : min(S, ng.shape[1])] = ng[:, :S]
+                    yield ids, torch.stack([ql, pl, nl])
+                    continue
+            from .training import TripletBatch
+
+            yield TripletBatch(ids=ids, lens=torch.stack([ql, pl]), neg_index=neg_t.to(torch.int32))

@@ -12,10 +12,14 @@ Additive only: tensor-level entry points (`encode_ids`) that take the
 tokenizer's int64 `input_ids` / `attention_mask` directly, and
 `encoder_mode={"embed","bert"}`: "embed" pools the frozen
 word-embedding rows (the gather hot path), "bert" runs the frozen encoder with
-stock PyTorch-ROCm ops and pools its last_hidden_state (reference-exact).
+stock PyTorch-ROCm ops and pools its last_hidden_state (reference-exact).  Left
+unset, a `pretrained_model` that has transformer layers runs in "bert" mode — what
+backend/model.py:51-52 executes, so reference-trained projections give the
+reference's embeddings — and says so once; a bare embedding table runs "embed".
 """
 from __future__ import annotations
 
+import warnings
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -80,16 +84,18 @@ class AveragePoolingTower(nn.Module):
         *,
         tokenizer: Optional[Callable] = None,
         pretrained_model: Optional[nn.Module] = None,
-        encoder_mode: str = "embed",
+        encoder_mode: Optional[str] = None,
     ):
         super().__init__()
-        if encoder_mode not in ("embed", "bert"):
+        if encoder_mode not in (None, "embed", "bert"):
             raise ValueError("encoder_mode must be 'embed' or 'bert'")
         if tokenizer is None or pretrained_model is None:
             from transformers import AutoModel, AutoTokenizer  # same loaders as model.py:23-24
 
             tokenizer = tokenizer or AutoTokenizer.from_pretrained(model_name)
             pretrained_model = pretrained_model or AutoModel.from_pretrained(model_name)
+        if encoder_mode is None:
+            encoder_mode = _default_encoder_mode(pretrained_model)
         self.tokenizer = tokenizer
         self.pretrained_model = pretrained_model
         self.encoder_mode = encoder_mode
@@ -159,14 +165,14 @@ class TwoTowersModel(nn.Module):
         *,
         tokenizer: Optional[Callable] = None,
         pretrained_model: Optional[nn.Module] = None,
-        encoder_mode: str = "embed",
+        encoder_mode: Optional[str] = None,
     ):
         super().__init__()
         kw = dict(tokenizer=tokenizer, pretrained_model=pretrained_model, encoder_mode=encoder_mode)
         self.query_tower = AveragePoolingTower(model_name, projection_dim, **kw)
         if pretrained_model is None:  # loaded from disk: share the frozen weights and tokenizer
             kw = dict(tokenizer=self.query_tower.tokenizer, pretrained_model=self.query_tower.pretrained_model,
-                      encoder_mode=encoder_mode)
+                      encoder_mode=self.query_tower.encoder_mode)
         self.document_tower = AveragePoolingTower(model_name, projection_dim, **kw)
 
     def encode_queries(self, queries: list[str]) -> Tensor:
@@ -277,6 +283,26 @@ class EmbeddingOnlyEncoder(nn.Module):
 
     def forward(self, input_ids=None, **kw):
         return (self.word_embeddings(input_ids),)
+
+
+_warned_default_bert = False
+
+
+def _default_encoder_mode(pm: nn.Module) -> str:
+    """encoder_mode left unset: a model with transformer layers (HF `BertModel.encoder`) runs as the
+    reference's code does (backend/model.py:51-52, the full frozen encoder); a bare embedding table
+    has nothing but the `embed` path.  Never silently the faster of the two."""
+    global _warned_default_bert
+    if getattr(pm, "encoder", None) is None:
+        return "embed"
+    if not _warned_default_bert:
+        _warned_default_bert = True
+        warnings.warn("encoder_mode not given and the pretrained model has encoder layers: running the frozen "
+                      "encoder (encoder_mode='bert', what backend/model.py:51-52 executes, stock PyTorch ops).  "
+                      "Pass encoder_mode='embed' to pool the word-embedding rows directly (the HIP gather hot "
+                      "path, what the reference's docstrings describe); projections trained in one mode do not "
+                      "transfer to the other.", stacklevel=3)
+    return "bert"
 
 
 def _hidden_size(pm: nn.Module) -> int:

@@ -229,13 +229,20 @@ class TripletTrainer:
         self.bucket = torch.empty_like(self.flat) if (self.world > 1 or self.accumulation_steps > 1) else None
         self.step_count = 0        # optimizer steps taken
         self._micro = 0            # batches since the last optimizer step (carried across epochs, like the reference)
+        if self.world > 1:
+            self.sync_replicas()   # replicas start from rank 0's weights (what DDP's constructor broadcast does)
         self.side = torch.cuda.Stream(self.device) if (overlap_streams and self.device.type == "cuda") else None
-        self._pending = collections.deque()   # gathered, not yet applied: (slot, ready event, local B)
+        # gathered, not yet applied: (slot, ready event, local B, neg_index, query_ids, batch).  The batch is
+        # kept referenced until apply() has made the main stream wait for its gather: K1 reads ids / mask /
+        # lens on the side stream, and a tensor dropped earlier could be handed out again by the caching
+        # allocator (which orders reuse on the main stream only) while K1 still reads it.
+        self._pending = collections.deque()
         self._next_slot = 0
-        self._slot_free = [None] * self.SLOTS  # slot -> event after the fwd_bwd that last read it
-        if self.side is not None:             # events are reused: one "ready" and one "done" per slot
+        if self.side is not None:             # events are reused: one "fence" and one "ready" per slot
+            self._slot_fence = [torch.cuda.Event() for _ in range(self.SLOTS)]
             self._slot_ready = [torch.cuda.Event() for _ in range(self.SLOTS)]
-            self._slot_done = [torch.cuda.Event() for _ in range(self.SLOTS)]
+            # tt_engine_create cleared the workspace on the main stream: order the side stream behind it
+            self.side.wait_stream(torch.cuda.current_stream(self.device))
         self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
         self.k1_event_every = 4               # ... of every 4th launch
         self._k1_count = 0
@@ -251,7 +258,6 @@ class TripletTrainer:
         self._ring_ids = self._ring_lens = None
         self._ring_fill = [None] * self.SLOTS
         self._steps_done = 0
-        self._main_dirty = False              # a graph ran on the main stream since the last side-stream fence
         # device-side Adam step counter only where replay needs it: its one-thread prep kernel
         # (two double pow) sits on the critical chain and costs ~20 us per step
         self._auto_step = self.use_graphs and self.bucket is None and hasattr(self.engine, "adam_auto")
@@ -275,22 +281,25 @@ class TripletTrainer:
         batch = as_batch(batch)
         if batch.neg_index is not None and self.world > 1:
             batch = batch.expand_negatives()  # an in-batch index does not survive sharding across ranks
+        if batch.size == 0:  # an empty shard (global batch smaller than the world): nothing to pool
+            self._pending.append((slot, None, 0, None, batch.query_ids, None))
+            return
         if self.side is None:
             self._timed_pool(slot, batch, None)
-            self._pending.append((slot, None, batch.size, batch.neg_index, batch.query_ids))
+            self._pending.append((slot, None, batch.size, batch.neg_index, batch.query_ids, None))
             return
-        if self._main_dirty:  # graph replays are ordered by the main stream only: fence once
-            self.side.wait_stream(torch.cuda.current_stream(self.device))
-            self._main_dirty = False
-            self._slot_free = [None] * self.SLOTS
-        free = self._slot_free[slot]
-        if free is not None:
-            self.side.wait_event(free)  # the fwd_bwd that last read this slot (on the main stream)
+        # Order the side stream behind everything the caller's stream holds at this point: (a) the kernels or
+        # copies that PRODUCE this batch's ids / mask / lens / cache_rows (a loader's index ops, a
+        # non_blocking H2D copy), (b) the fwd_bwd that last read this pooled-input slot (enqueued earlier on
+        # the same stream), (c) graph replays.  K1 runs two batches ahead, so this wait is off the critical path.
+        fence = self._slot_fence[slot]
+        fence.record(torch.cuda.current_stream(self.device))
+        self.side.wait_event(fence)
         # launch on the side stream by handle (no stream context switch on the host)
         self._timed_pool(slot, batch, self.side)
         ev = self._slot_ready[slot]
         ev.record(self.side)
-        self._pending.append((slot, ev, batch.size, batch.neg_index, batch.query_ids))
+        self._pending.append((slot, ev, batch.size, batch.neg_index, batch.query_ids, batch))
 
     def _timed_pool(self, slot, batch: TripletBatch, stream) -> None:
         timed = False
@@ -333,8 +342,10 @@ class TripletTrainer:
         `issue_next()` (optional) is called where enqueueing further gathers overlaps best:
         before the projection kernels when gathers have their own stream, else right after
         the gradient all-reduce has been launched."""
-        slot, ev, local_B, neg_index, query_ids = self._pending.popleft()
+        slot, ev, local_B, neg_index, query_ids, held = self._pending.popleft()
         global_B = global_B or local_B * self.world
+        if global_B <= 0:
+            raise ValueError("apply(): empty global batch")
         k = self.accumulation_steps
         self._steps_done += 1
         if self.side is not None:
@@ -343,14 +354,11 @@ class TripletTrainer:
                 issue_next = None
             if ev is not None:
                 torch.cuda.current_stream(self.device).wait_event(ev)
+        del held  # the main stream is now ordered behind this batch's gather: its tensors may be reused
         if self.loss_kind == "inbatch":
-            self._inbatch_fwd_bwd(slot, local_B, query_ids, k)
-        else:
+            self._inbatch_fwd_bwd(slot, local_B, query_ids, k, global_B)
+        elif local_B > 0:
             self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B), neg_index=neg_index)
-        if self.side is not None:
-            done = self._slot_done[slot]
-            done.record()
-            self._slot_free[slot] = done
         self._micro += 1
         do_step = self._micro % k == 0
         if self.bucket is None:  # single replica, no accumulation: Adam folds the slab sum
@@ -362,7 +370,11 @@ class TripletTrainer:
             if issue_next is not None:
                 issue_next()
             return
-        self.engine.reduce_grads(self.bucket, accumulate=(k > 1 and self._micro % k != 1))
+        first_micro = not (k > 1 and self._micro % k != 1)
+        if local_B > 0:
+            self.engine.reduce_grads(self.bucket, accumulate=not first_micro)
+        elif first_micro:  # an empty shard contributes zero gradients but still takes part in the all-reduce
+            self.bucket.zero_()
         work = None
         if do_step and self.world > 1:
             work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
@@ -374,36 +386,102 @@ class TripletTrainer:
             self.step_count += 1
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
 
-    def _inbatch_fwd_bwd(self, slot: int, B: int, query_ids, k: int) -> None:
+    # -- data parallel: replicas --------------------------------------------------------
+    def _src0(self) -> int:
+        return dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+
+    def sync_replicas(self) -> None:
+        """Every replica takes rank 0's parameters, Adam moments and step count (what
+        DistributedDataParallel's constructor does for the parameters).  Called at construction —
+        nn.Linear's default init comes from each process's own RNG, and identical all-reduced Adam
+        updates never bring different starting points together — and after loading a checkpoint
+        on one rank."""
+        if self.world == 1:
+            return
+        src = self._src0()
+        for t in (self.flat, self.exp_avg, self.exp_avg_sq):
+            dist.broadcast(t, src=src, group=self.pg)
+        steps = torch.tensor([self.step_count, self._micro], dtype=torch.int64, device=self.device)
+        dist.broadcast(steps, src=src, group=self.pg)
+        self.step_count, self._micro = int(steps[0]), int(steps[1])
+
+    def replica_divergence(self) -> float:
+        """max over ranks of |parameter checksum - rank 0's| (0.0 when the replicas are in step);
+        a debug check, one small all-gather."""
+        if self.world == 1:
+            return 0.0
+        mine = torch.stack([self.flat.double().sum(), self.flat.double().abs().sum()])
+        allc = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(allc, mine, group=self.pg)
+        return float(max((c - allc[0]).abs().max() for c in allc))
+
+    def _inbatch_fwd_bwd(self, slot: int, B: int, query_ids, k: int, global_B: int) -> None:
         """In-batch-negatives loss between the two halves of the engine's phase B.  Data parallel
         (SURVEY.md §8e/f4): the documents' embeddings (and query ids) are all-gathered, each rank
         scores its queries against every document of the global batch, and the documents' gradient
         is summed over ranks before each rank keeps its own rows — the one real exchange of
-        activations on this path."""
+        activations on this path.  Shards may be uneven (`shard_batch`: the first global_B % world
+        ranks hold one row more) or empty; every rank takes part in every collective."""
         eng = self.engine
-        eng.forward(slot, B, 2)
-        emb, dout = eng.embeddings(B, 2), eng.d_out(B, 2)
-        qid = None if query_ids is None else query_ids.to(torch.int64).contiguous()
         if self.world == 1:
+            eng.forward(slot, B, 2)
+            emb, dout = eng.embeddings(B, 2), eng.d_out(B, 2)
+            qid = None if query_ids is None else query_ids.to(torch.int64).contiguous()
             z = float(B * (B - 1))
             loss, _, _ = ops.inbatch_triplet_fwd_bwd(emb[0], emb[1], self.margin, None, qid, qid, 1.0 / (z * k), z,
                                                      dq_out=dout[0], dd_out=dout[1])
+            eng.add_loss(loss)
+            eng.backward(slot, B, 2)
+            return
+        W, r = self.world, self.rank
+        sizes, offs = shard_sizes(global_B, W)
+        if B != sizes[r]:
+            raise ValueError(f"in-batch loss: rank {r} holds {B} rows of a global batch of {global_B}; the contiguous "
+                             f"split (shard_batch) gives it {sizes[r]}")
+        mb = sizes[0]  # largest shard: all-gathers run on equal, zero-padded blocks
+        have_qid = query_ids is not None
+        pad_d = torch.zeros((mb, self.P), dtype=torch.float32, device=self.device)
+        pad_q = torch.zeros(mb, dtype=torch.int64, device=self.device) if have_qid else None
+        if B > 0:
+            eng.forward(slot, B, 2)
+            emb, dout = eng.embeddings(B, 2), eng.d_out(B, 2)
+            pad_d[:B].copy_(emb[1])
+            if have_qid:
+                pad_q[:B].copy_(query_ids.to(torch.int64))
+        d_pad = torch.empty((W * mb, self.P), dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(d_pad, pad_d, group=self.pg)
+        even = sizes[-1] == mb
+        rows = None if even else self._valid_rows(sizes, mb)
+        d_all = d_pad if even else d_pad.index_select(0, rows)
+        qid_all = None
+        if have_qid:
+            q_pad = torch.empty(W * mb, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(q_pad, pad_q, group=self.pg)
+            qid_all = q_pad if even else q_pad.index_select(0, rows)
+        z = float(global_B * (global_B - 1))
+        if B > 0:
+            pos = (torch.arange(B, device=self.device, dtype=torch.int32) + offs[r]).contiguous()
+            loss, _, dd_all = ops.inbatch_triplet_fwd_bwd(emb[0], d_all.contiguous(), self.margin, pos,
+                                                          pad_q[:B].contiguous() if have_qid else None,
+                                                          None if qid_all is None else qid_all.contiguous(),
+                                                          1.0 / (z * k), z, dq_out=dout[0])
         else:
-            W, r = self.world, self.rank
-            d_all = torch.empty((W * B, self.P), dtype=torch.float32, device=self.device)
-            dist.all_gather_into_tensor(d_all, emb[1].contiguous(), group=self.pg)
-            qid_all = None
-            if qid is not None:
-                qid_all = torch.empty(W * B, dtype=torch.int64, device=self.device)
-                dist.all_gather_into_tensor(qid_all, qid, group=self.pg)
-            pos = (torch.arange(B, device=self.device, dtype=torch.int32) + r * B).contiguous()
-            z = float(W * B * (W * B - 1))
-            loss, _, dd_all = ops.inbatch_triplet_fwd_bwd(emb[0], d_all, self.margin, pos, qid, qid_all, 1.0 / (z * k), z,
-                                                          dq_out=dout[0])
-            dist.all_reduce(dd_all, op=dist.ReduceOp.SUM, group=self.pg)
-            dout[1].copy_(dd_all[r * B: (r + 1) * B])
-        eng.add_loss(loss)
-        eng.backward(slot, B, 2)
+            dd_all = torch.zeros((global_B, self.P), dtype=torch.float32, device=self.device)
+        dist.all_reduce(dd_all, op=dist.ReduceOp.SUM, group=self.pg)
+        if B > 0:
+            dout[1].copy_(dd_all[offs[r]: offs[r] + B])
+            eng.add_loss(loss)
+            eng.backward(slot, B, 2)
+
+    def _valid_rows(self, sizes, mb: int) -> torch.Tensor:
+        """Row indices of the real (non-padding) rows inside the [world * mb] all-gathered blocks."""
+        key = (tuple(sizes), mb)
+        cache = getattr(self, "_valid_rows_cache", None)
+        if cache is None or cache[0] != key:
+            idx = torch.cat([torch.arange(n) + i * mb for i, n in enumerate(sizes)])
+            cache = (key, idx.to(self.device))
+            self._valid_rows_cache = cache
+        return cache[1]
 
     # -- hipGraph replay ---------------------------------------------------------------
     def _graphable(self, entry, nxt: Optional[TripletBatch]) -> bool:
@@ -411,7 +489,7 @@ class TripletTrainer:
             return False
         if self.eager_every and self._steps_done % self.eager_every == self.eager_every - 1:
             return False
-        _, _, B, neg_index, _ = entry
+        _, _, B, neg_index, _, _ = entry
         if neg_index is not None or B != self.engine.max_B or self.loss_kind != "triplet":
             return False
         if nxt is None:
@@ -468,7 +546,7 @@ class TripletTrainer:
         if not self._graphable(entry, nxt):
             self.apply(global_B, issue_next=(lambda: self.gather(nxt)) if nxt is not None else None)
             return
-        slot_fb, ev, B, _, _ = self._pending.popleft()
+        slot_fb, ev, B, _, _, _held = self._pending.popleft()
         slot_k1 = None
         if nxt is not None:
             slot_k1 = self._next_slot
@@ -478,12 +556,11 @@ class TripletTrainer:
         if ev is not None:  # pooled by an eager K1 on the side stream
             torch.cuda.current_stream(self.device).wait_event(ev)
         g.replay()
-        self._main_dirty = True
         self._steps_done += 1
         self._micro += 1
         self.step_count += 1
         if slot_k1 is not None:
-            self._pending.append((slot_k1, None, B, None, None))
+            self._pending.append((slot_k1, None, B, None, None, None))
 
     # -- public ------------------------------------------------------------------
     def train_step(self, batch: Batch, global_batch: Optional[int] = None) -> None:
@@ -523,21 +600,34 @@ class TripletTrainer:
             t = torch.tensor([loss_sum], dtype=torch.float64, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
             loss_sum = float(t.item())
+            c = torch.tensor([n], dtype=torch.int64, device=self.device)  # a rank whose shard was empty counted fewer
+            dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.pg)
+            n = int(c.item())
         return loss_sum / max(n, 1)
+
+
+def shard_sizes(global_B: int, world: int):
+    """Contiguous split of `global_B` rows over `world` ranks: (sizes, offsets); the first
+    global_B % world ranks hold one row more."""
+    base, rem = divmod(int(global_B), int(world))
+    sizes = [base + (1 if r < rem else 0) for r in range(world)]
+    offs = [r * base + min(r, rem) for r in range(world)]
+    return sizes, offs
 
 
 def shard_batch(batch: Batch, rank: int, world: int) -> Tuple[Batch, int]:
     """Contiguous split of a global batch over `world` ranks; the
-    last ranks get one triplet fewer when B % world != 0.  Returns (shard, B_global)."""
+    last ranks get one triplet fewer when B % world != 0 (none at all when B < world: such a
+    rank still takes part in the step's collectives).  Returns (shard, B_global)."""
     tb = as_batch(batch).expand_negatives() if world > 1 else as_batch(batch)
     B = tb.size
-    base, rem = divmod(B, world)
-    lo = rank * base + min(rank, rem)
-    hi = lo + base + (1 if rank < rem else 0)
+    sizes, offs = shard_sizes(B, world)
+    lo, hi = offs[rank], offs[rank] + sizes[rank]
     cut = lambda t: None if t is None else t[:, lo:hi].contiguous()
     if isinstance(batch, TripletBatch):
         ni = tb.neg_index if world == 1 else None
-        return TripletBatch(cut(tb.ids), cut(tb.mask), cut(tb.lens), ni, cut(tb.cache_rows)), B
+        qid = None if tb.query_ids is None else tb.query_ids[lo:hi].contiguous()  # [B], not [roles, B]
+        return TripletBatch(cut(tb.ids), cut(tb.mask), cut(tb.lens), ni, cut(tb.cache_rows), qid), B
     return (cut(tb.ids), cut(tb.mask), cut(tb.lens)), B
 
 
@@ -555,7 +645,8 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
                  use_mixed_precision: bool = True, num_workers: int = 4,
                  run_comprehensive_test: bool = True, *, train_dataset=None, val_dataset=None, test_dataset=None,
                  tokenizer=None, pretrained_model=None, model_name: Optional[str] = None,
-                 seed: Optional[int] = None, feature_cache: bool = True) -> TwoTowersModel:
+                 seed: Optional[int] = None, feature_cache: bool = True, sampler: str = "device",
+                 encoder_mode: str = "embed") -> TwoTowersModel:
     """Same keyword surface and defaults as backend/training.py:383-397; builds the
     model / criterion / Adam exactly like :433-436 and runs `num_epochs` epochs on
     the fused engine.  Differences, all outside the hot path: the dataset is passed
@@ -563,7 +654,12 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
     reference's MSMarcoDataset is a network fetch), wandb and the NDCG evaluation
     harness (training.py:136-380) are not reproduced, `use_mixed_precision` /
     `num_workers` / `run_comprehensive_test` are accepted for signature parity and
-    ignored (fp32 is the parity path; tokenisation happens once, up front)."""
+    ignored (fp32 is the parity path; tokenisation happens once, up front).
+    `encoder_mode` is explicit here: the fused engine implements "embed" (word-embedding rows pooled
+    directly); for the reference's executed behaviour (frozen encoder between gather and pool) build
+    the model with encoder_mode="bert" and use `train_epoch`.  `sampler`: "device" draws the in-batch
+    negatives with tensor ops (same distribution, no per-batch host work); "reference" reproduces
+    backend/data.py:132-137's draws under `seed`, at its O(B^2) Python cost per batch."""
     from .data import TokenTripletLoader
 
     if train_dataset is None:
@@ -572,11 +668,13 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
     kw = {}
     if model_name is not None:
         kw["model_name"] = model_name
-    model = TwoTowersModel(projection_dim=projection_dim, tokenizer=tokenizer, pretrained_model=pretrained_model, **kw)
+    model = TwoTowersModel(projection_dim=projection_dim, tokenizer=tokenizer, pretrained_model=pretrained_model,
+                           encoder_mode=encoder_mode, **kw)
     model = model.to(device)
     if max_samples and max_samples > 0 and len(train_dataset) > max_samples:
         train_dataset = torch.utils.data.Subset(train_dataset, range(max_samples))
-    loader = TokenTripletLoader(train_dataset, model.query_tower.tokenizer, batch_size, device, seed=seed)
+    loader = TokenTripletLoader(train_dataset, model.query_tower.tokenizer, batch_size, device, seed=seed,
+                                sampler=sampler)
     max_S = int(max(loader.q_ids.shape[1], loader.p_ids.shape[1]))
     trainer = TripletTrainer(model, max_batch=batch_size, max_seq_len=max_S, margin=margin, lr=learning_rate,
                              accumulation_steps=accumulation_steps)

@@ -112,8 +112,9 @@ def run_e2e(args, trainer, cfg, device, rank, world, barrier):
     lens = torch.full((n_items,), S, dtype=torch.int32, device=device)
     qids = torch.arange(n_items) // 4  # four passages per query
     loader = TokenTripletLoader.from_tensors(mk(), lens, mk(), lens.clone(), qids, batch_size=B, device=device,
-                                             seed=11 + rank, sampler="device", emit=("ids3" if args.inputs == "ids3" else "index"))
-    as_b = (lambda it: ((ids, None, l) for ids, l in it)) if args.inputs == "ids3" else (lambda it: it)
+                                             seed=11 + rank, sampler="device", emit=("rows3" if args.inputs == "ids3" else "rows2"))
+    trainer.set_token_store(*loader.all_texts())  # [2N, S] token rows, resident; batches name their texts by row
+    as_b = lambda it: it
 
     def first(n):
         for i, b in enumerate(loader):
@@ -163,6 +164,9 @@ def main():
                     help="time one whole epoch of --steps batches produced by TokenTripletLoader (device sampler: shuffle, "
                          "in-batch negative draws and the [3,B,S] id gathers happen per batch, on the device) instead of "
                          "cycling pre-staged batches; reported under its own metric name")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="skip TripletTrainer.calibrate() in set-up (it times the two backward schedules on this device "
+                         "and keeps the faster; its ~130 dry steps also bring the GPU out of its idle power state)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the multi-process "
                          "path with several ranks sharing one GPU)")
@@ -295,6 +299,15 @@ def main():
         import gc
         gc.collect()
         gc.freeze()
+    if os.environ.get("TT_PREWARM_MS"):  # experiment: keep the GPU busy for a while before warm-up
+        a = torch.randn(4096, 4096, device=device)
+        tend = time.perf_counter() + float(os.environ["TT_PREWARM_MS"]) * 1e-3
+        while time.perf_counter() < tend:
+            a @ a
+            torch.cuda.synchronize(device)
+        del a
+    if not args.no_calibrate and not args.k1_only and args.loss == "triplet":
+        trainer.calibrate(batches[0])   # set-up: part of what run_training does before its first epoch
     if args.e2e:
         elapsed, e2e_info = run_e2e(args, trainer, cfg, device, rank, world, barrier)
         host_issue = elapsed
@@ -303,6 +316,8 @@ def main():
         fill()
         run(args.warmup, timed=False)
         barrier()
+        if os.environ.get("TT_IDLE_MS"):  # experiment: idle gap between warm-up and the timed region
+            time.sleep(float(os.environ["TT_IDLE_MS"]) * 1e-3)
         t0 = time.perf_counter()
         run(args.steps, timed=True)
         host_issue = time.perf_counter() - t0  # all K steps enqueued (no device sync inside the loop)
@@ -365,6 +380,8 @@ def main():
                                                        if trainer.engine_k1_cap < 0 else
                                                        "K1 capped at %d workgroups/CU" % trainer.engine_k1_cap))
                    if trainer.side is not None else "none (same stream)",
+                   "timed_region": ("one epoch: loader + pipeline fill and drain + loss read-back" if args.e2e else
+                                    "K steady-state steps (pipeline filled in warm-up, drained after)"),
                    "launch": "hipGraph replay (1 step per graph; every 8th step eager for K1 event timing)"
                    if trainer.use_graphs else "eager (kernel by kernel)"},
         "roofline": {"kernel": k1_label, "bound": "hbm",
@@ -381,6 +398,7 @@ def main():
                      "alone": {"avg_launch_ms": iso_ms, "achieved": alg / (iso_ms * 1e-3) / 1e9,
                                "frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "avg_loss": loss_avg,
+        "calibration": trainer.calibration,
     }
     if args.inputs == "cache":  # no gather in the step: the K1 roofline does not apply
         result["roofline"] = None
@@ -391,6 +409,8 @@ def main():
         hgaps = [round((trace_host[i + 1] - trace_host[i]) * 1e3, 2) for i in range(len(trace_host) - 1)]
         print("TRACE gpu ms per 10 steps:", gaps, file=sys.stderr)
         print("TRACE host ms per 10 steps:", hgaps, file=sys.stderr)
+        print("TRACE K1 in-loop ms (every %d-th launch):" % trainer.k1_event_every,
+              [round(a.elapsed_time(b), 3) for a, b in k1_ev], file=sys.stderr)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

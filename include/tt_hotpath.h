@@ -299,6 +299,19 @@ int tt_engine_grad_slabs(const tt_engine* e);
  */
 int tt_engine_set_sharing(tt_engine* e, int gathers_share_chip);
 
+/*
+ * Force phase B's backward schedule (host-side, no device work): TT_BWD_AUTO (default: the rule
+ * above), TT_BWD_FORK (loss mean + dW2/db2 on the engine's second stream under dH -> dW1/db1) or
+ * TT_BWD_FUSED (loss mean inside the triplet launch, dW2/db2 + dH in one launch).  Both write
+ * bitwise the same gradient slabs; the logged loss may differ in its last bit (summation order).
+ * Which is faster depends on shape and on what shares the chip; TripletTrainer.calibrate() times
+ * both on the device at hand.
+ */
+#define TT_BWD_AUTO 0
+#define TT_BWD_FORK 1
+#define TT_BWD_FUSED 2
+int tt_engine_set_backward(tt_engine* e, int mode);
+
 /* Borrow caller-owned device buffers (valid until rebound or destroy). */
 int tt_engine_bind(tt_engine* e, const float* table, float* params, float* exp_avg,
                    float* exp_avg_sq);
@@ -316,6 +329,20 @@ int tt_engine_bind(tt_engine* e, const float* table, float* params, float* exp_a
 int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask,
                    int mask_dtype, const int32_t* lens, int32_t roles, int32_t B, int32_t S,
                    tt_stream_t stream);
+
+/*
+ * Phase A through a row indirection: the collection's texts are tokenised once into a store
+ * (store_ids [n_store, S] int32/int64 zero-padded rows, store_lens [n_store] int32 prefix
+ * lengths or NULL = full length) that stays in HBM; a batch is then just rows [roles,B] int32 —
+ * text t of the batch reads store row rows[t] — so the reference's per-batch tokenizer call +
+ * `.to(device)` of three [B,S] int64 tensors (backend/model.py:43-48) becomes 12 bytes per
+ * triplet, and no [roles,B,S] id tensor is materialised.  Same arithmetic and bitwise the same
+ * result as tt_engine_pool on the gathered rows.  Rows outside [0, n_store) are clamped and
+ * reported by tt_engine_read_stats like out-of-range token ids.
+ */
+int tt_engine_pool_rows(tt_engine* e, int slot, const void* store_ids, int ids_dtype,
+                        const int32_t* store_lens, int64_t n_store, const int32_t* rows,
+                        int32_t roles, int32_t B, int32_t S, tt_stream_t stream);
 
 /*
  * Phase A from a frozen-feature cache.  The encoder is frozen (backend/model.py:29-30,51), so

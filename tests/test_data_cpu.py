@@ -155,6 +155,13 @@ def test_device_sampler_loader_needs_no_per_batch_shapes_and_keeps_triplet_struc
     ld = mk("cache")
     c = list(ld)
     assert ld.pad == "max"
+    r3, r2 = list(mk("rows3")), list(mk("rows2"))
+    all_ids, all_lens = ld.all_texts()
+    for (ids3, lens3), x3, x2, bc in zip(a, r3, r2, c):  # row forms name the same texts (store = all_texts())
+        assert x3.token_rows.dtype == torch.int32 and x3.token_rows.shape == (3, ids3.shape[1]) and x3.neg_index is None
+        assert torch.equal(all_ids[x3.token_rows.long()], ids3) and torch.equal(all_lens[x3.token_rows.long()], lens3)
+        assert torch.equal(x2.token_rows, bc.cache_rows) and torch.equal(x2.neg_index, bc.neg_index)
+        assert torch.equal(x2.expand_negatives().token_rows, x3.token_rows)
     Smax = max(ld.q_ids.shape[1], ld.p_ids.shape[1])
     qid = torch.tensor(ld.query_ids)
     total = 0

@@ -711,3 +711,97 @@ def test_pool_forms_fuzz(tt):
         close(a, ref, atol=2e-6)
         close(b, ref, atol=2e-6)
         assert (a - b).abs().max().item() <= 1e-6, (case, D, S, V, N, kind)
+
+
+# --------------------------------------------------------------------------- K1 through a token store (f3)
+@pytest.mark.parametrize("V,D,S,B,idt,sliced", [
+    (2000, 128, 24, 64, torch.int32, False),     # small table: per-text K1
+    (30522, 384, 128, 400, torch.int32, True),   # MiniLM-sized table, enough tokens: XCD-sliced K1
+    (9000, 384, 64, 700, torch.int64, True),     # int64 store, sliced
+    (200, 6, 7, 9, torch.int32, False),          # D % 4 != 0: generic kernel
+])
+def test_engine_pool_rows_is_bitwise_pool_of_the_gathered_rows(tt, V, D, S, B, idt, sliced, monkeypatch):
+    """tt_engine_pool_rows (batch = rows of a resident token store) == tt_engine_pool on the rows
+    gathered into a [roles,B,S] tensor, bit for bit, for roles 2 and 3, with and without lengths;
+    an out-of-range row is clamped and reported, never read."""
+    _, engine = tt
+    from two_towers_overlords_amd import _lib
+
+    if sliced:
+        monkeypatch.setenv("TT_K1_SLICED", "1")
+    N = 3000
+    gen = torch.Generator().manual_seed(17)
+    table = (orc.synthetic_table(V, D, seed=1) * 30).cuda()
+    store = torch.randint(0, V, (N, S), generator=gen).to(idt).cuda()
+    lens = torch.randint(0, S + 1, (N,), generator=gen).int().cuda()   # includes empty rows (clamp 1e-9 path)
+    eng = engine.HotPathEngine(table, 16, B, S)
+    flat = torch.zeros(eng.n_params, device="cuda")
+    eng.bind(flat, torch.zeros_like(flat), torch.zeros_like(flat))
+    for roles in (3, 2):
+        rows = torch.randint(0, N, (roles, B), generator=gen).int().cuda()
+        for ln in (lens, None):
+            eng.pool_rows(0, store, ln, rows)
+            a = eng.pooled(0, B, roles).clone()
+            eng.pool(1, store[rows.long()].contiguous(), None, None if ln is None else ln[rows.long()].contiguous())
+            b = eng.pooled(1, B, roles).clone()
+            assert torch.equal(a, b)
+    torch.cuda.synchronize()
+    assert eng.read_stats()[1] == 0
+    bad = rows.clone()
+    bad[0, 0] = N + 5
+    eng.pool_rows(0, store, lens, bad)
+    with pytest.raises(_lib.TTError):
+        eng.read_stats()
+    eng.close()
+
+
+def test_trainer_token_store_epoch_equals_materialised_ids_and_calibrate_is_neutral(tt):
+    """TokenTripletLoader(emit="rows3"/"rows2") + TripletTrainer.set_token_store: the same epoch, bit for
+    bit, as the materialised [3,B,S] / [2,B,S] id batches describing the same triplets; and
+    TripletTrainer.calibrate() (dry steps on both backward schedules) leaves parameters, Adam state,
+    step counters and loss statistics exactly as it found them."""
+    from two_towers_overlords_amd.data import TokenTripletLoader
+    from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
+
+    V, D, P, B, S, N = 5000, 384, 64, 96, 40, 500
+    gen = torch.Generator().manual_seed(23)
+    table = orc.synthetic_table(V, D, seed=1) * 30
+    params = orc.init_params(D, P, seed=2)
+    q = torch.randint(1, V, (N, 12), generator=gen).int()
+    p = torch.randint(1, V, (N, S), generator=gen).int()
+    ql = torch.randint(1, 13, (N,), generator=gen).int()
+    pl = torch.randint(1, S + 1, (N,), generator=gen).int()
+    qids = torch.arange(N) // 3
+
+    def epoch(emit, calibrate):
+        ld = TokenTripletLoader.from_tensors(q, ql, p, pl, qids, batch_size=B, device="cuda", seed=9, sampler="device", emit=emit)
+        tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B,
+                            max_seq_len=S, margin=0.3, lr=1e-3)
+        store_ids, store_lens = ld.all_texts()
+        tr.set_token_store(store_ids, store_lens)
+        batches = list(ld)
+        if calibrate:
+            before = (tr.flat.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.step_count, tr._micro)
+            info = tr.calibrate(batches[0], steps=6, rounds=1)
+            assert info["backward"] in ("fork", "fused") and set(info["ms_per_step"]) == {"fork", "fused"}
+            assert torch.equal(before[0], tr.flat) and torch.equal(before[1], tr.exp_avg) and torch.equal(before[2], tr.exp_avg_sq)
+            assert (tr.step_count, tr._micro) == before[3:] and tr.engine.read_stats(reset=False)[1] == 0
+        return tr, batches, tr.train_epoch(batches), store_ids, store_lens
+
+    tr3, b3, loss3, store_ids, store_lens = epoch("rows3", False)
+    # the same triplets as materialised id tensors
+    mat = [TripletBatch(ids=store_ids[b.token_rows.long()].contiguous(), lens=store_lens[b.token_rows.long()].contiguous())
+           for b in b3]
+    trm = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B, max_seq_len=S,
+                         margin=0.3, lr=1e-3)
+    lossm = trm.train_epoch(mat)
+    assert loss3 == lossm and torch.equal(tr3.flat, trm.flat)
+    # rows2 (negatives by in-batch index) describes the same triplets: equal up to fp32 summation order
+    tr2, b2, loss2, _, _ = epoch("rows2", False)
+    for x, y in zip(b2, b3):
+        assert torch.equal(x.expand_negatives().token_rows, y.token_rows)
+    assert abs(loss2 - loss3) <= 1e-6
+    assert_params_close(tr2.flat.cpu().numpy(), tr3.flat.cpu().numpy(), 1e-3, len(b3))
+    # calibrate() first: same parameters, bit for bit (the two backward schedules write the same gradients)
+    trc, _, lossc, _, _ = epoch("rows3", True)
+    assert torch.equal(trc.flat, tr3.flat) and abs(lossc - loss3) <= 1e-6

@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 TT_I32, TT_I64 = 4, 8
+TT_BWD_AUTO, TT_BWD_FORK, TT_BWD_FUSED = 0, 1, 2
 TT_K1_SHARE_AUTO = -1  # tt_engine_config.k1_blocks_per_cu: pair the K1 form with the projection tile
 ABI_VERSION = 1
 
@@ -71,6 +72,8 @@ SIGNATURES = {
     "tt_engine_create": (_i, [C.POINTER(TTEngineConfig), _vp, _sz, _vp, C.POINTER(_vp)]),
     "tt_engine_destroy": (_i, [_vp]),
     "tt_engine_set_sharing": (_i, [_vp, _i]),
+    "tt_engine_set_backward": (_i, [_vp, _i]),
+    "tt_engine_pool_rows": (_i, [_vp, _i, _vp, _i, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "tt_engine_param_count": (_i64, [_vp]),
     "tt_engine_grad_slabs": (_i, [_vp]),
     "tt_engine_bind": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -11,12 +11,14 @@
 #include <new>
 #include "proj.h"
 
+// text_rows != NULL: text t reads row text_rows[t] of a token store [n_store, S] (ids / mask / lens are the store's)
 int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                  const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                 unsigned lds_total, hipStream_t st);
+                 unsigned lds_total, hipStream_t st, const int32_t* text_rows, int64_t n_store);
 int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st);
+                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st,
+                        const int32_t* text_rows, int64_t n_store);
 int tt_k1_sliced_supported(int S, int D, const float* table, const float* out);
 int tt_launch_adam_auto(float* params, const float* grads, int nslabs, long long slab_stride, float* exp_avg,
                         float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
@@ -71,6 +73,7 @@ struct tt_engine {
   hipStream_t aux;
   hipEvent_t ev_fork, ev_join;
   bool gathers_share_chip;  // tt_engine_set_sharing: token-id gathers are running beside phase B
+  int bwd_mode;             // tt_engine_set_backward: TT_BWD_AUTO / TT_BWD_FORK / TT_BWD_FUSED
 };
 
 namespace {
@@ -198,6 +201,13 @@ extern "C" int tt_engine_set_sharing(tt_engine* e, int gathers_share_chip) {
   return TT_OK;
 }
 
+extern "C" int tt_engine_set_backward(tt_engine* e, int mode) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(mode == TT_BWD_AUTO || mode == TT_BWD_FORK || mode == TT_BWD_FUSED, TT_ERR_BAD_SHAPE);
+  e->bwd_mode = mode;
+  return TT_OK;
+}
+
 extern "C" int64_t tt_engine_param_count(const tt_engine* e) { return ok(e) ? e->nparam : -1; }
 extern "C" int tt_engine_grad_slabs(const tt_engine* e) { return ok(e) ? e->nslabs : -1; }
 extern "C" const float* tt_engine_pooled(const tt_engine* e, int slot) {
@@ -219,9 +229,9 @@ extern "C" int tt_engine_bind(tt_engine* e, const float* table, float* params, f
   return TT_OK;
 }
 
-extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask,
-                              int mask_dtype, const int32_t* lens, int32_t roles, int32_t B, int32_t S,
-                              tt_stream_t stream) {
+static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                     const int32_t* lens, int32_t roles, int32_t B, int32_t S, const int32_t* text_rows,
+                     int64_t n_store, tt_stream_t stream) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(e->table, TT_ERR_NULL_POINTER);
   TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (roles == 2 || roles == 3), TT_ERR_BAD_SHAPE);
@@ -237,10 +247,24 @@ extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_d
     if (e->shared && !e->tile_above && e->cfg.k1_blocks_per_cu == TT_K1_SHARE_AUTO) lds_total = tt_k1_lds_for_cap(3);
     return tt_k1_sliced_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B,
                                S, e->cfg.D, e->cfg.V, e->oob, e->k1_partial[slot], e->k1_partial_bytes, lds_total,
-                               static_cast<hipStream_t>(stream));
+                               static_cast<hipStream_t>(stream), text_rows, n_store);
   }
   return tt_k1_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B, S,
-                      e->cfg.D, e->cfg.V, e->oob, lds_total, static_cast<hipStream_t>(stream));
+                      e->cfg.D, e->cfg.V, e->oob, lds_total, static_cast<hipStream_t>(stream), text_rows, n_store);
+}
+
+extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask,
+                              int mask_dtype, const int32_t* lens, int32_t roles, int32_t B, int32_t S,
+                              tt_stream_t stream) {
+  return engine_k1(e, slot, ids, ids_dtype, mask, mask_dtype, lens, roles, B, S, nullptr, 0, stream);
+}
+
+extern "C" int tt_engine_pool_rows(tt_engine* e, int slot, const void* store_ids, int ids_dtype,
+                                   const int32_t* store_lens, int64_t n_store, const int32_t* rows, int32_t roles,
+                                   int32_t B, int32_t S, tt_stream_t stream) {
+  TT_REQUIRE(store_ids && rows, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(n_store >= 1 && n_store <= 0x7fffffffLL, TT_ERR_BAD_SHAPE);
+  return engine_k1(e, slot, store_ids, ids_dtype, nullptr, TT_I32, store_lens, roles, B, S, rows, n_store, stream);
 }
 
 extern "C" int tt_engine_pool_cached(tt_engine* e, int slot, const float* cache, int64_t cache_rows,
@@ -296,6 +320,8 @@ static int tile_policy(const tt_engine* e) {
 }
 
 static bool use_fork(const tt_engine* e) {
+  if (e->bwd_mode == TT_BWD_FORK) return e->aux != nullptr;
+  if (e->bwd_mode == TT_BWD_FUSED) return false;
   bool fork = e->shared && !e->tile_above && e->aux != nullptr && e->gathers_share_chip;
   if (const char* v = getenv("TT_BWD"))  // "fork" / "fused" force a schedule (A/B runs); anything else: automatic
     if (v[0] == 'f') fork = e->aux != nullptr && v[1] == 'o';

@@ -32,6 +32,15 @@ __device__ __forceinline__ void f4_fma(float4& acc, float w, const float4& r) {
   acc.w = fmaf(w, r.w, acc.w);
 }
 
+// Row of the token store a text reads from (tt_engine_pool_rows): never outside the store.
+__device__ __forceinline__ long long store_row(int row, long long n_store, int* __restrict__ oob_flag) {
+  if (row < 0 || row >= n_store) {
+    if (oob_flag) atomicOr(oob_flag, 1);
+    return row < 0 ? 0 : n_store - 1;
+  }
+  return row;
+}
+
 // Pops K token positions from `mine` (wave-uniform bit set), issues all K*C row
 // loads, then accumulates.  DENSE: rows are hidden[text_base + seg + pos].
 template <int K, int C, bool DENSE>
@@ -113,7 +122,7 @@ template <typename IdT, typename MaskT, int C, int U, bool DENSE, bool LDS_STAGE
 __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, int S, int D, long long V,
-    int* __restrict__ oob_flag) {
+    int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
   __shared__ float4 part[kWavesPerText][C * TT_WAVE];
   __shared__ float red[kWavesPerText];
   __shared__ __attribute__((aligned(16))) float stage[LDS_STAGE ? kWavesPerText * U * C * 256 : 4];
@@ -123,8 +132,10 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
   const int wave = threadIdx.x >> 6;
   const int nchunk = D >> 2;
   const bool last_ok = (C - 1) * TT_WAVE + lane < nchunk;
-  const long long tbase = text * (long long)S;
-  const int len = lens ? lens[text] : S;
+  // with text_rows, text t's ids / mask / length are row text_rows[t] of a token store [n_store, S]
+  const long long stext = text_rows ? store_row(text_rows[text], n_store, oob_flag) : text;
+  const long long tbase = stext * (long long)S;
+  const int len = lens ? lens[stext] : S;
 
   float4 acc[C];
 #pragma unroll
@@ -234,7 +245,7 @@ template <typename IdT, typename MaskT, int C, int U, int NS, int MAXSEG>
 __global__ __launch_bounds__(kThreads) void pool_sliced_kernel(
     const float* __restrict__ table, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ partial, float* __restrict__ wsum_out, long long N,
-    int S, int D, long long V, int* __restrict__ oob_flag) {
+    int S, int D, long long V, int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
   extern __shared__ int sliced_lds[];  // per wave: 2 x ([S] ids + [S] weights)
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const int wave = threadIdx.x >> 6;
@@ -253,8 +264,9 @@ __global__ __launch_bounds__(kThreads) void pool_sliced_kernel(
 
   // registers <- ids / mask of text t (loads only; nothing waits on them here)
   auto fetch = [&](long long t) {
-    len_r = lens ? lens[t] : S;
-    const long long tb = t * (long long)S;
+    const long long st = text_rows ? store_row(text_rows[t], n_store, oob_flag) : t;
+    len_r = lens ? lens[st] : S;
+    const long long tb = st * (long long)S;
 #pragma unroll
     for (int k = 0; k < MAXSEG; ++k) {
       const int tok = k * TT_WAVE + lane;
@@ -404,11 +416,12 @@ template <typename IdT, typename MaskT, bool DENSE>
 __global__ __launch_bounds__(kThreads) void pool_norm_generic_kernel(
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, int S, int D, long long V,
-    int* __restrict__ oob_flag) {
+    int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
   __shared__ float red[kWavesPerText];
   const long long text = blockIdx.x;
-  const long long tbase = text * (long long)S;
-  const int len = lens ? lens[text] : S;
+  const long long stext = text_rows ? store_row(text_rows[text], n_store, oob_flag) : text;
+  const long long tbase = stext * (long long)S;
+  const int len = lens ? lens[stext] : S;
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const int wave = threadIdx.x >> 6;
 
@@ -490,28 +503,29 @@ static unsigned k1_dynamic_lds(unsigned lds_total, unsigned static_lds) {
 
 template <typename IdT, typename MaskT, bool DENSE>
 int launch_pool(const float* src, const void* ids, const void* mask, const int32_t* lens, float* out,
-                int64_t N, int S, int D, int64_t V, int32_t* oob, unsigned lds_total, hipStream_t st) {
+                int64_t N, int S, int D, int64_t V, int32_t* oob, unsigned lds_total, hipStream_t st,
+                const int32_t* text_rows = nullptr, int64_t n_store = 0) {
   const IdT* ids_t = static_cast<const IdT*>(ids);
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
   const dim3 grid(static_cast<unsigned>(N)), block(kThreads);
   const bool fast = (D % 4 == 0) && D <= 1024 && tt_aligned16(src) && tt_aligned16(out);
   if (!fast) {
     hipLaunchKernelGGL((pool_norm_generic_kernel<IdT, MaskT, DENSE>), grid, block, 0, st, src, ids_t,
-                       mask_t, lens, out, S, D, (long long)V, oob);
+                       mask_t, lens, out, S, D, (long long)V, oob, text_rows, (long long)n_store);
     TT_CHECK_LAUNCH();
     return TT_OK;
   }
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
   if (!DENSE && (D / 4 + TT_WAVE - 1) / TT_WAVE == 2 && getenv("TT_K1_LDS")) {  // A/B experiment, D in (256, 512]
     hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, 2, 8, false, true>), grid, block, 0, st, src, ids_t, mask_t, lens,
-                       out, S, D, (long long)V, oob);
+                       out, S, D, (long long)V, oob, text_rows, (long long)n_store);
     TT_CHECK_LAUNCH();
     return TT_OK;
   }
 #define TT_POOL_CASE(CC, UU)                                                                      \
   hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, CC, UU, DENSE>), grid, block,                    \
                      k1_dynamic_lds(lds_total, CC * 4096u + 16u), st, src, ids_t, mask_t, lens, out, S, D, \
-                     (long long)V, oob)
+                     (long long)V, oob, text_rows, (long long)n_store)
   switch (C) {
     case 1: TT_POOL_CASE(1, 8); break;
     case 2: TT_POOL_CASE(2, 8); break;
@@ -526,13 +540,13 @@ int launch_pool(const float* src, const void* ids, const void* mask, const int32
 template <bool DENSE>
 int dispatch_pool(const float* src, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                   const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob,
-                  unsigned lds_total, hipStream_t st) {
+                  unsigned lds_total, hipStream_t st, const int32_t* text_rows = nullptr, int64_t n_store = 0) {
   // without a mask the MaskT instantiation is irrelevant: use int32
   const int md = mask ? mask_dtype : TT_I32;
-  if (ids_dtype == TT_I32 && md == TT_I32) return launch_pool<int32_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st);
-  if (ids_dtype == TT_I32 && md == TT_I64) return launch_pool<int32_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st);
-  if (ids_dtype == TT_I64 && md == TT_I32) return launch_pool<int64_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st);
-  if (ids_dtype == TT_I64 && md == TT_I64) return launch_pool<int64_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st);
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_pool<int32_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st, text_rows, n_store);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_pool<int32_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st, text_rows, n_store);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_pool<int64_t, int32_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st, text_rows, n_store);
+  if (ids_dtype == TT_I64 && md == TT_I64) return launch_pool<int64_t, int64_t, DENSE>(src, ids, mask, lens, out, N, S, D, V, oob, lds_total, st, text_rows, n_store);
   return TT_ERR_BAD_DTYPE;
 }
 
@@ -554,7 +568,8 @@ static int cu_count() {
 
 template <typename IdT, typename MaskT>
 int launch_sliced(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
-                  int S, int D, int64_t V, int32_t* oob, float* ws, unsigned lds_total, hipStream_t st) {
+                  int S, int D, int64_t V, int32_t* oob, float* ws, unsigned lds_total, hipStream_t st,
+                  const int32_t* text_rows, int64_t n_store) {
   const IdT* ids_t = static_cast<const IdT*>(ids);
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
   float* partial = ws;
@@ -578,7 +593,7 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
 #define TT_SLICED_LAUNCH(CC, UU, MS)                                                                          \
   hipLaunchKernelGGL((pool_sliced_kernel<IdT, MaskT, CC, UU, kSlices, MS>), dim3((unsigned)(G * kSlices)),     \
                      dim3(kThreads), lds, st, table, ids_t, mask_t, lens, partial, wsum, (long long)N, S, D,   \
-                     (long long)V, oob)
+                     (long long)V, oob, text_rows, (long long)n_store)
 #define TT_SLICED_CASE(CC, UU)                  \
   do {                                          \
     if (nseg <= 2) TT_SLICED_LAUNCH(CC, UU, 2); \
@@ -605,14 +620,15 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
 // internal (engine.hip): K1 with an LDS reservation (0 = none)
 int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                  const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                 unsigned lds_total, hipStream_t st) {
+                 unsigned lds_total, hipStream_t st, const int32_t* text_rows, int64_t n_store) {
   TT_REQUIRE(table && ids && out, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(!text_rows || n_store >= 1, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x7fffffffLL, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   if (N == 0) return TT_OK;
   return dispatch_pool<false>(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag,
-                              lds_total, st);
+                              lds_total, st, text_rows, n_store);
 }
 
 extern "C" int tt_gather_pool_norm_f32(const float* table, const void* ids, int ids_dtype,
@@ -620,7 +636,7 @@ extern "C" int tt_gather_pool_norm_f32(const float* table, const void* ids, int 
                                        float* out, int64_t N, int S, int D, int64_t V,
                                        int32_t* oob_flag, tt_stream_t stream) {
   return tt_k1_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, 0,
-                      static_cast<hipStream_t>(stream));
+                      static_cast<hipStream_t>(stream), nullptr, 0);
 }
 
 extern "C" int tt_pool_norm_dense_f32(const float* hidden, const void* mask, int mask_dtype,
@@ -683,8 +699,10 @@ extern "C" int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S) {
 // internal (engine.hip): sliced K1 with an LDS reservation (0 = none)
 int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st) {
+                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st,
+                        const int32_t* text_rows, int64_t n_store) {
   TT_REQUIRE(table && ids && out && workspace, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(!text_rows || n_store >= 1, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x0fffffffLL, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
@@ -693,10 +711,10 @@ int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, cons
   if (N == 0) return TT_OK;
   float* ws = static_cast<float*>(workspace);
   const int md = mask ? mask_dtype : TT_I32;
-  if (ids_dtype == TT_I32 && md == TT_I32) return launch_sliced<int32_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st);
-  if (ids_dtype == TT_I32 && md == TT_I64) return launch_sliced<int32_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st);
-  if (ids_dtype == TT_I64 && md == TT_I32) return launch_sliced<int64_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st);
-  return launch_sliced<int64_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st);
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_sliced<int32_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st, text_rows, n_store);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_sliced<int32_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st, text_rows, n_store);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_sliced<int64_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st, text_rows, n_store);
+  return launch_sliced<int64_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st, text_rows, n_store);
 }
 
 extern "C" int tt_gather_pool_norm_sliced_f32(const float* table, const void* ids, int ids_dtype, const void* mask,
@@ -704,5 +722,5 @@ extern "C" int tt_gather_pool_norm_sliced_f32(const float* table, const void* id
                                               int64_t V, int32_t* oob_flag, void* workspace, size_t workspace_bytes,
                                               tt_stream_t stream) {
   return tt_k1_sliced_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, workspace,
-                             workspace_bytes, 0, static_cast<hipStream_t>(stream));
+                             workspace_bytes, 0, static_cast<hipStream_t>(stream), nullptr, 0);
 }

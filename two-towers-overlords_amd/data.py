@@ -48,27 +48,29 @@ def sample_negative_indices_device(query_ids: torch.Tensor, generator: Optional[
     whole batch at once on `query_ids`' device, exactly and without rejection: sort the batch by
     query id, so the items item i must NOT draw form one contiguous run [a_i, b_i) of the sorted
     order; draw u uniformly from the B - (b_i - a_i) admissible positions and skip over the run.
+    `query_ids` is [B] (one batch) or [n_batches, B] (independent batches, e.g. a whole epoch in
+    one call); the result has the same shape and holds in-batch indices.
     O(B log B) tensor work against the reference's O(B^2) Python list building per batch, and no
-    host synchronisation when `check=False` (the caller has then verified on the host that the
+    host synchronisation when `check=False` (the caller has then verified on the host that every
     batch holds at least two distinct query ids).  Not the same *draws* as the reference under a
     shared seed.  With `check=True` raises like the reference fails: IndexError for a batch of
     one (`random.choice([])`), RuntimeError when every item shares one query id (the reference
     never returns)."""
-    B = query_ids.numel()
+    B = query_ids.shape[-1]
     if B < 2:
         raise IndexError("cannot draw an in-batch negative from a batch of one")  # reference: random.choice([])
-    q = query_ids.reshape(-1)
-    sorted_q, perm = torch.sort(q)
+    q = query_ids.reshape(-1, B)
+    sorted_q, perm = torch.sort(q, dim=1)
     run_lo = torch.searchsorted(sorted_q, q, right=False)
     run_hi = torch.searchsorted(sorted_q, q, right=True)
     run = run_hi - run_lo
     admissible = B - run
     if check and int(admissible.min()) == 0:
         raise RuntimeError("every item of the batch shares one query_id: no admissible negative")
-    u = torch.rand(B, generator=generator, device=q.device, dtype=torch.float64)
+    u = torch.rand(q.shape, generator=generator, device=q.device, dtype=torch.float64)
     pick = torch.minimum((u * admissible).long(), (admissible - 1).clamp_(min=0))
     pick = torch.where(pick < run_lo, pick, pick + run)
-    return perm[pick.clamp_(max=B - 1)]
+    return perm.gather(1, pick.clamp_(max=B - 1)).reshape(query_ids.shape)
 
 
 class PackedTokens:
@@ -191,13 +193,19 @@ class TokenTripletLoader:
                  "cache" -> TripletBatch(cache_rows [2,B], neg_index)      rows of a frozen-feature cache
                             laid out [queries (N); positives (N)] — build it with
                             `trainer.build_feature_cache(*loader.all_texts())`
+                 "rows3" -> TripletBatch(token_rows [3,B])                 three gathers per batch, the ids read
+                            through a row indirection into `trainer.set_token_store(*loader.all_texts())`
+                            (same layout as the cache: query i -> row i, positive i -> row N + i)
+                 "rows2" -> TripletBatch(token_rows [2,B], neg_index)      the same with negatives by index
+                 With sampler="device" the rows / cache forms cost the host nothing per batch but a tensor
+                 view: the whole epoch's shuffle, negative draws and row triples are a dozen device ops.
         pad: "batch" — S = the longest row of the batch, what `padding=True` gives each call of
                     backend/model.py:43-45 (costs one device->host read per batch); "max" — S = the
                     longest row of the collection (no read-back; K1 never fetches past a row's length,
                     so the extra padding is free).  Default: "batch" with the reference sampler,
                     "max" with the device sampler."""
-        if emit not in ("ids3", "index", "cache"):
-            raise ValueError("emit must be 'ids3', 'index' or 'cache'")
+        if emit not in ("ids3", "index", "cache", "rows3", "rows2"):
+            raise ValueError("emit must be 'ids3', 'index', 'cache', 'rows3' or 'rows2'")
         if sampler not in ("reference", "device"):
             raise ValueError("sampler must be 'reference' or 'device'")
         if pad not in (None, "batch", "max"):
@@ -226,10 +234,7 @@ class TokenTripletLoader:
             self.query_ids = [int(it["query_id"]) for it in items]
             self.q_ids, self.q_lens = self._tokenize(tokenizer, [it["query"] for it in items], max_length)
             self.p_ids, self.p_lens = self._tokenize(tokenizer, [it["positive"] for it in items], max_length)
-        import numpy as np
-
-        self._qid_np = np.asarray(self.query_ids, dtype=np.int64)
-        self._qid_t = torch.from_numpy(self._qid_np).to(self.device)
+        self._qid_t = torch.tensor(self.query_ids, dtype=torch.int64, device=self.device)
         self._padded = None  # (q_ids, p_ids) padded to one common S (pad="max")
 
     def _tokenize(self, tokenizer, texts, max_length):
@@ -284,44 +289,80 @@ class TokenTripletLoader:
             self._padded = (pad(self.q_ids), pad(self.p_ids))
         return self._padded
 
-    def _negatives(self, idx, it) -> torch.Tensor:
-        """In-batch negative indices (int64 [B] on the device) of the batch whose items are `idx`."""
-        if self.sampler == "device":
-            qb = self._qid_np[idx]
-            if len(idx) < 2:
-                raise IndexError("cannot draw an in-batch negative from a batch of one")
-            if qb.min() == qb.max():  # checked on the host, so that the device draw needs no read-back
-                raise RuntimeError("every item of the batch shares one query_id: no admissible negative")
-            return sample_negative_indices_device(self._qid_t[it], self.gen, check=False)
-        return torch.tensor(sample_negative_indices([self.query_ids[i] for i in idx], self.rng), device=self.device)
+    def _epoch_negatives(self, order_t):
+        """sampler="device": the in-batch negative indices of EVERY batch of the epoch in one vectorised
+        draw — full batches as one [n_batches, B] call, the ragged last batch on its own.  Returns
+        (neg_full [n_full, B] | None, neg_tail [r] | None), int64 in-batch indices on the device.
+        One host read per EPOCH (is some batch without two distinct query ids?), none per batch."""
+        n, B = order_t.numel(), self.batch_size
+        n_full, r = divmod(n, B)
+        if r == 1 or (B == 1 and n_full):
+            raise IndexError("cannot draw an in-batch negative from a batch of one")
+        qt = self._qid_t[order_t]
+        full = qt[: n_full * B].view(n_full, B) if n_full else None
+        tail = qt[n_full * B:] if r else None
+        bad = torch.zeros((), dtype=torch.bool, device=self.device)
+        if n_full:
+            bad = bad | (full.min(1).values == full.max(1).values).any()
+        if r:
+            bad = bad | (tail.min() == tail.max())
+        if bool(bad):  # the reference would spin forever in create_triplets (backend/data.py:124-128)
+            raise RuntimeError("every item of a batch shares one query_id: no admissible negative")
+        neg_full = sample_negative_indices_device(full, self.gen, check=False) if n_full else None
+        neg_tail = sample_negative_indices_device(tail, self.gen, check=False) if r else None
+        return neg_full, neg_tail
 
     def __iter__(self):
-        import numpy as np
+        n, B = len(self.query_ids), self.batch_size
+        if self.sampler == "device":  # shuffle on the device too: nothing of the epoch's set-up is O(n) host work
+            order_t = (torch.randperm(n, generator=self.gen, device=self.device) if self.shuffle
+                       else torch.arange(n, device=self.device))
+            order = None
+        else:
+            order = list(range(n))
+            if self.shuffle:
+                self.rng.shuffle(order)
+            order_t = torch.tensor(order, dtype=torch.int64, device=self.device)  # one host->device copy per epoch
+        n_full = n // B
+        neg_full = neg_tail = rows_full = None
+        by_rows = self.emit in ("cache", "rows3", "rows2")
+        if self.sampler == "device":
+            neg_full, neg_tail = self._epoch_negatives(order_t)
+            if by_rows and n_full:  # the whole epoch's row triples at once: [n_full, roles, B] int32
+                it_all = order_t[: n_full * B].view(n_full, B)
+                parts = [it_all, it_all + n]
+                if self.emit == "rows3":
+                    parts.append(it_all.gather(1, neg_full) + n)
+                rows_full = torch.stack(parts, dim=1).to(torch.int32).contiguous()
+                neg_full32 = neg_full.to(torch.int32)
+        if by_rows:
+            from .training import TripletBatch
 
-        n = len(self.query_ids)
-        order = list(range(n))
-        if self.shuffle:
-            self.rng.shuffle(order)
-        order_np = np.asarray(order, dtype=np.int64)
-        order_t = torch.from_numpy(order_np).to(self.device)  # one host->device copy per epoch
-        n_items = n
-        for s in range(0, n, self.batch_size):
-            idx = order_np[s: s + self.batch_size]
-            it = order_t[s: s + self.batch_size]
-            neg_t = self._negatives(idx, it)
-            B = len(idx)
-            if self.emit == "cache":
-                from .training import TripletBatch
-
-                rows = torch.stack([it, it + n_items]).to(torch.int32).contiguous()
-                yield TripletBatch(cache_rows=rows, neg_index=neg_t.to(torch.int32))
+            def as_batch(rows, ni):
+                if self.emit == "cache":
+                    return TripletBatch(cache_rows=rows, neg_index=ni)
+                return TripletBatch(token_rows=rows) if self.emit == "rows3" else TripletBatch(token_rows=rows, neg_index=ni)
+        for bi, s in enumerate(range(0, n, B)):
+            if rows_full is not None and bi < n_full:  # per batch: two tensor views, nothing else
+                yield as_batch(rows_full[bi], neg_full32[bi])
+                continue
+            it = order_t[s: s + B]
+            nb = it.shape[0]
+            if self.sampler == "device":
+                neg_t = neg_full[bi] if bi < n_full else neg_tail
+            else:
+                neg_t = torch.tensor(sample_negative_indices([self.query_ids[i] for i in order[s: s + B]], self.rng),
+                                     device=self.device)
+            if by_rows:
+                parts = [it, it + n] + ([it[neg_t] + n] if self.emit == "rows3" else [])
+                yield as_batch(torch.stack(parts).to(torch.int32).contiguous(), neg_t.to(torch.int32))
                 continue
             roles = 3 if self.emit == "ids3" else 2
             ql, pl = self.q_lens[it], self.p_lens[it]
             if self.pad == "max":  # no read-back: every batch is padded to the collection's longest row
                 qsrc, psrc = self._common()
                 S = qsrc.shape[1]
-                ids = torch.empty((roles, B, S), dtype=torch.int32, device=self.device)
+                ids = torch.empty((roles, nb, S), dtype=torch.int32, device=self.device)
                 torch.index_select(qsrc, 0, it, out=ids[0])
                 torch.index_select(psrc, 0, it, out=ids[1])
                 if roles == 3:
@@ -337,7 +378,7 @@ class TokenTripletLoader:
                     S = int(torch.stack([ql.max(), pl.max(), nl.max()]).max())
                 else:
                     S = int(torch.stack([ql.max(), pl.max()]).max())
-                ids = torch.zeros((roles, B, S), dtype=torch.int32, device=self.device)
+                ids = torch.zeros((roles, nb, S), dtype=torch.int32, device=self.device)
                 ids[0, :, : min(S, q.shape[1])] = q[:, :S]
                 ids[1, :, : min(S, p.shape[1])] = p[:, :S]
                 if roles == 3:

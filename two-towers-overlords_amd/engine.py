@@ -107,6 +107,31 @@ class HotPathEngine:
         call("tt_engine_pool", self._h, slot, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7],
              self._stream() if stream is None else stream)
 
+    def pool_rows(self, slot: int, store_ids: torch.Tensor, store_lens: Optional[torch.Tensor], rows: torch.Tensor,
+                  stream: Optional[int] = None) -> None:
+        """K1 through a row indirection: text t of the batch is row rows[t] of the token store
+        (store_ids [N, S] int32/int64, store_lens [N] int32 or None = full length); rows [roles, B] int32."""
+        _req(store_ids, "store_ids", ndim=2)
+        _req(rows, "rows", torch.int32, 2)
+        if store_ids.dtype not in _INT_WIDTH or store_ids.device != self.device or rows.device != self.device:
+            raise ValueError("pool_rows: store_ids must be an int32/int64 [N, S] tensor on the engine device")
+        if rows.shape[0] not in (2, 3):
+            raise ValueError("pool_rows: rows must be [roles, B] with roles 2 or 3")
+        lp = None
+        if store_lens is not None:
+            _req(store_lens, "store_lens", torch.int32, 1)
+            if store_lens.numel() != store_ids.shape[0] or store_lens.device != self.device:
+                raise ValueError("pool_rows: store_lens must be int32 [N] on the engine device")
+            lp = store_lens.data_ptr()
+        call("tt_engine_pool_rows", self._h, slot, store_ids.data_ptr(), _INT_WIDTH[store_ids.dtype], lp,
+             store_ids.shape[0], rows.data_ptr(), rows.shape[0], rows.shape[1], store_ids.shape[1],
+             self._stream() if stream is None else stream)
+
+    def set_backward(self, mode: str) -> None:
+        """"auto" | "fork" | "fused": phase B's backward schedule (include/tt_hotpath.h, tt_engine_set_backward)."""
+        call("tt_engine_set_backward", self._h, {"auto": _lib.TT_BWD_AUTO, "fork": _lib.TT_BWD_FORK,
+                                                 "fused": _lib.TT_BWD_FUSED}[mode])
+
     def pool_cached(self, slot: int, cache: torch.Tensor, rows: torch.Tensor, stream: Optional[int] = None) -> None:
         """Phase A from a frozen-feature cache: pooled[slot] = cache[rows], rows [roles, B]."""
         _req(cache, "cache", torch.float32, 2)

@@ -132,10 +132,12 @@ Batch = Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]  # i
 
 @dataclasses.dataclass
 class TripletBatch:
-    """One batch for the fused engine.  Either token ids (`ids` [roles,B,S] + `mask` or `lens`)
-    or rows of the trainer's frozen-feature cache (`cache_rows` [roles,B]).  roles = 3: query,
-    positive, negative.  roles = 2 + `neg_index` (int32 [B]): the negatives are in-batch
-    positives (backend/data.py:113-137), negative i = positive neg_index[i] — no third encode."""
+    """One batch for the fused engine.  Either token ids (`ids` [roles,B,S] + `mask` or `lens`),
+    or rows of the trainer's token store (`token_rows` [roles,B] int32: the texts were tokenised
+    once into `TripletTrainer.set_token_store`, a batch is 12 bytes per triplet), or rows of the
+    trainer's frozen-feature cache (`cache_rows` [roles,B]).  roles = 3: query, positive,
+    negative.  roles = 2 + `neg_index` (int32 [B]): the negatives are in-batch positives
+    (backend/data.py:113-137), negative i = positive neg_index[i] — no third encode."""
 
     ids: Optional[torch.Tensor] = None
     mask: Optional[torch.Tensor] = None
@@ -143,10 +145,14 @@ class TripletBatch:
     neg_index: Optional[torch.Tensor] = None
     cache_rows: Optional[torch.Tensor] = None
     query_ids: Optional[torch.Tensor] = None  # int64 [B]; in-batch-negatives loss: same-query documents are not negatives
+    token_rows: Optional[torch.Tensor] = None
 
     @property
     def size(self) -> int:
-        return (self.ids if self.ids is not None else self.cache_rows).shape[1]
+        for t in (self.ids, self.token_rows, self.cache_rows):
+            if t is not None:
+                return t.shape[1]
+        raise ValueError("empty TripletBatch")
 
     def expand_negatives(self) -> "TripletBatch":
         """roles 2 + neg_index -> roles 3 (negatives materialised by a row gather)."""
@@ -154,7 +160,8 @@ class TripletBatch:
             return self
         ni = self.neg_index.long()
         cat = lambda t: None if t is None else torch.cat([t, t[1:2].index_select(1, ni)], dim=0).contiguous()
-        return TripletBatch(cat(self.ids), cat(self.mask), cat(self.lens), None, cat(self.cache_rows), self.query_ids)
+        return TripletBatch(cat(self.ids), cat(self.mask), cat(self.lens), None, cat(self.cache_rows), self.query_ids,
+                            cat(self.token_rows))
 
 
 def as_batch(b) -> TripletBatch:
@@ -247,6 +254,9 @@ class TripletTrainer:
         self.k1_event_every = 4               # ... of every 4th launch
         self._k1_count = 0
         self.feature_cache = None             # [N_texts, D] pooled-normalised vectors (build_feature_cache)
+        self.token_store = None               # (ids [N_texts, S], lens [N_texts] | None) behind TripletBatch.token_rows
+        self.calibration = None               # what calibrate() measured and chose
+        self._dry = False                     # calibrate(): apply() stops after fwd + bwd (no exchange, no optimizer)
         self.table = table
         # hipGraph replay of whole steps (single replica, no accumulation; opt-in).  Measured on
         # ROCm 7.2 / MI355X it does NOT pay: replaying the 3-stream, ~15-node step graph costs the
@@ -316,11 +326,25 @@ class TripletTrainer:
             if self.feature_cache is None:
                 raise RuntimeError("batch carries cache_rows but build_feature_cache() has not been called")
             self.engine.pool_cached(slot, self.feature_cache, batch.cache_rows, stream=raw)
+        elif batch.token_rows is not None:
+            if self.token_store is None:
+                raise RuntimeError("batch carries token_rows but set_token_store() has not been called")
+            self.engine.pool_rows(slot, self.token_store[0], self.token_store[1], batch.token_rows, stream=raw)
         else:
             self.engine.pool(slot, batch.ids, batch.mask, batch.lens, stream=raw)
         if timed:
             e1.record(stream)
             self.k1_events.append((e0, e1))
+
+    def set_token_store(self, ids: torch.Tensor, lens: Optional[torch.Tensor] = None) -> None:
+        """The collection's texts, tokenised once: ids [N, S] int32/int64 zero-padded rows,
+        lens [N] int32 prefix lengths (None: full length), resident on the device.  Batches then name their
+        texts by row (`TripletBatch.token_rows`) and K1 reads the ids through that indirection."""
+        if ids.dim() != 2 or ids.device != self.device:
+            raise ValueError("set_token_store: ids must be [N, S] on the trainer's device")
+        if ids.shape[1] > self.engine.max_S:
+            raise ValueError(f"set_token_store: rows of {ids.shape[1]} tokens exceed the engine's max_seq_len")
+        self.token_store = (ids.contiguous(), None if lens is None else lens.to(torch.int32).contiguous())
 
     @torch.no_grad()
     def build_feature_cache(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None,
@@ -359,6 +383,10 @@ class TripletTrainer:
             self._inbatch_fwd_bwd(slot, local_B, query_ids, k, global_B)
         elif local_B > 0:
             self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B), neg_index=neg_index)
+        if self._dry:
+            if issue_next is not None:
+                issue_next()
+            return
         self._micro += 1
         do_step = self._micro % k == 0
         if self.bucket is None:  # single replica, no accumulation: Adam folds the slab sum
@@ -385,6 +413,53 @@ class TripletTrainer:
         if do_step:
             self.step_count += 1
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
+
+    # -- calibration ----------------------------------------------------------------------
+    def calibrate(self, batch: Batch, steps: int = 32, rounds: int = 2) -> dict:
+        """Time phase B's two backward schedules (include/tt_hotpath.h, tt_engine_set_backward) on THIS
+        device with THIS batch shape — gathers running beside them exactly as in training — and keep the
+        faster one.  The two tie at some shapes and differ by 5-10 % at others, and the
+        balance moves with what else shares the chip; both write bitwise the same gradients, so the choice
+        never changes a training run's parameters.  Parameters, Adam state, step counters and loss
+        statistics are untouched: the timed steps stop after the backward (no exchange, no optimizer).
+        A side effect worth knowing: the ~2*rounds*steps steps also bring the GPU from its idle power
+        state to sustained clocks, which otherwise takes the first ~70 training steps (the first steps
+        after any idle period run 10-20 % slower; measured)."""
+        if self._pending:
+            raise RuntimeError("calibrate(): call it between epochs (batches are still in flight)")
+        if self.device.type != "cuda" or not hasattr(self.engine, "set_backward") or self.loss_kind != "triplet":
+            return {}
+        b = as_batch(batch)
+        depth = self.SLOTS - 1 if self.side is not None else 1
+        times = {"fused": [], "fork": []}
+        self._dry = True
+        try:
+            for _ in range(rounds):
+                for mode in ("fused", "fork"):
+                    self.engine.set_backward(mode)
+                    while len(self._pending) < depth:
+                        self.gather(b)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(steps):
+                        self.apply(None, issue_next=lambda: self.gather(b))
+                    e1.record()
+                    while self._pending:
+                        self.apply(None)
+                    e1.synchronize()
+                    times[mode].append(e0.elapsed_time(e1) / steps)
+        finally:
+            self._dry = False
+        best = {m: min(v) for m, v in times.items()}
+        if self.world > 1:  # every replica must take the same decision: decide on the slowest rank's times
+            t = torch.tensor([best["fused"], best["fork"]], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+            best = {"fused": float(t[0]), "fork": float(t[1])}
+        pick = min(best, key=best.get)
+        self.engine.set_backward(pick)
+        self.engine.read_stats(reset=True)  # the dry steps' losses do not belong to any epoch
+        self.calibration = {"backward": pick, "ms_per_step": best, "steps": steps, "rounds": rounds}
+        return self.calibration
 
     # -- data parallel: replicas --------------------------------------------------------
     def _src0(self) -> int:
@@ -496,7 +571,7 @@ class TripletTrainer:
             return True
         return (nxt.ids is not None and nxt.ids.shape[0] == 3 and nxt.ids.shape[1] == B
                 and nxt.ids.shape[2] <= self.engine.max_S and nxt.mask is None and nxt.neg_index is None
-                and nxt.cache_rows is None)
+                and nxt.cache_rows is None and nxt.token_rows is None)
 
     def _ring_load(self, slot: int, nxt: TripletBatch) -> None:
         """Stage a batch's ids in the fixed ring buffer the captured K1 launch reads (main stream)."""
@@ -627,7 +702,7 @@ def shard_batch(batch: Batch, rank: int, world: int) -> Tuple[Batch, int]:
     if isinstance(batch, TripletBatch):
         ni = tb.neg_index if world == 1 else None
         qid = None if tb.query_ids is None else tb.query_ids[lo:hi].contiguous()  # [B], not [roles, B]
-        return TripletBatch(cut(tb.ids), cut(tb.mask), cut(tb.lens), ni, cut(tb.cache_rows), qid), B
+        return TripletBatch(cut(tb.ids), cut(tb.mask), cut(tb.lens), ni, cut(tb.cache_rows), qid, cut(tb.token_rows)), B
     return (cut(tb.ids), cut(tb.mask), cut(tb.lens)), B
 
 
@@ -646,7 +721,7 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
                  run_comprehensive_test: bool = True, *, train_dataset=None, val_dataset=None, test_dataset=None,
                  tokenizer=None, pretrained_model=None, model_name: Optional[str] = None,
                  seed: Optional[int] = None, feature_cache: bool = True, sampler: str = "device",
-                 encoder_mode: str = "embed") -> TwoTowersModel:
+                 encoder_mode: str = "embed", calibrate: bool = True) -> TwoTowersModel:
     """Same keyword surface and defaults as backend/training.py:383-397; builds the
     model / criterion / Adam exactly like :433-436 and runs `num_epochs` epochs on
     the fused engine.  Differences, all outside the hot path: the dataset is passed
@@ -683,12 +758,16 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
         # takes its negatives by in-batch index
         loader.emit = "cache"
         trainer.build_feature_cache(*_ids_lens(loader.all_texts()))
+    else:
+        # three gathers per batch like the reference's three encodes; the token rows stay on the device
+        # and a batch names its texts by row
+        loader.emit = "rows3"
+        trainer.set_token_store(*loader.all_texts())
+    if calibrate and len(loader) > 0:
+        trainer.calibrate(next(iter(loader)))
     print(f"Starting training for {num_epochs} epochs...")
     for epoch in range(num_epochs):
-        if feature_cache:
-            avg = trainer.train_epoch(loader)
-        else:
-            avg = trainer.train_epoch((ids, None, lens) for ids, lens in loader)
+        avg = trainer.train_epoch(loader)
         print(f"Epoch {epoch + 1}/{num_epochs}  avg_train_loss {avg:.6f}")
         if val_dataset is not None:  # per-epoch validation NDCG@10 (training.py:490)
             from .evaluation import evaluate_model

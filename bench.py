@@ -164,6 +164,10 @@ def main():
                     help="time one whole epoch of --steps batches produced by TokenTripletLoader (device sampler: shuffle, "
                          "in-batch negative draws and the [3,B,S] id gathers happen per batch, on the device) instead of "
                          "cycling pre-staged batches; reported under its own metric name")
+    ap.add_argument("--h2d", action="store_true",
+                    help="PCIe-inclusive rate: every step's ids [3,B,S] int32 come from pinned HOST memory by a "
+                         "non_blocking copy on a copy stream (what the reference's `.to(device)` of the tokenizer "
+                         "output is, backend/model.py:48); reported under its own metric name")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="skip TripletTrainer.calibrate() in set-up (it times the two backward schedules on this device "
                          "and keeps the faster; its ~130 dry steps also bring the GPU out of its idle power state)")
@@ -258,10 +262,23 @@ def main():
     depth = trainer.SLOTS - 1 if trainer.side is not None else 1
     issued = [0]
 
+    if args.h2d:
+        from two_towers_overlords_amd.training import TripletBatch as _TB
+
+        host_ids = [ids.cpu().pin_memory() for ids in id_batches]
+        copy_stream = torch.cuda.Stream(device)
+        copy_events = [torch.cuda.Event() for _ in range(4)]
+
     def next_batch():
-        b = batches[issued[0] % n_distinct]
+        k = issued[0]
         issued[0] += 1
-        return b
+        if args.h2d:  # host -> device on the copy stream; the gather waits for the copy's event
+            with torch.cuda.stream(copy_stream):
+                ids = host_ids[k % n_distinct].to(device, non_blocking=True)
+                ev = copy_events[k % 4]
+                ev.record(copy_stream)
+            return _TB(ids=ids, ready_event=ev)
+        return batches[k % n_distinct]
 
     def fill():
         while len(trainer._pending) < depth:
@@ -360,6 +377,8 @@ def main():
     metric = (("triplets/sec (q,pos,neg @ seq128/d384), full training step" if args.config == "c2"
                else "triplets/sec, full training step") if args.inputs == "ids3"
               else f"triplets/sec, full training step, inputs={args.inputs}, loss={args.loss} (NOT the BASELINE metric)")
+    if args.h2d:
+        metric = "triplets/sec, full training step, ids copied from pinned host memory every step (PCIe-inclusive; NOT the BASELINE metric)"
     if args.e2e:
         metric = (f"triplets/sec, one whole epoch of {args.steps} batches through TokenTripletLoader(sampler=device) + "
                   f"TripletTrainer.train_epoch, inputs={args.inputs} (end-to-end loop; NOT the BASELINE metric)")

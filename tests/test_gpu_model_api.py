@@ -363,3 +363,55 @@ def test_token_loader_device_sampler_trains_like_reference_sampler_statistically
     for _ in range(4):
         l1 = tr.train_epoch((ids, None, lens) for ids, lens in ld)
     assert l1 < l0
+
+
+def test_batches_produced_on_a_copy_stream_are_waited_for_through_ready_event():
+    """Same hazard, other producer: the batch is copied host->device on a COPY stream (busy with other work, so
+    the copy lands late), handed over with `TripletBatch.ready_event`, dropped at once and its memory re-requested on
+    the copy stream.  The gather has to wait for the event, and the allocator has to know both the side stream (K1)
+    and the main stream (neg_index in phase B) still use the tensors."""
+    from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
+
+    V, D, P, B, S, NB = 5000, 384, 64, 256, 64, 6
+    table = orc.synthetic_table(V, D, seed=1) * 30
+    params = orc.init_params(D, P, seed=2)
+    gen = torch.Generator().manual_seed(5)
+    host = []
+    for i in range(NB):
+        b = orc.synthetic_batch(B, S, V, seed=950 + i, ragged=True)
+        neg = ((torch.arange(B) + 1 + torch.randint(0, B - 1, (B,), generator=gen)) % B).int()
+        host.append((torch.stack([r[0] for r in b[:2]]).int().pin_memory(), torch.stack([r[1].sum(1) for r in b[:2]]).int().pin_memory(),
+                     neg.pin_memory()))
+
+    def trainer():
+        return TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B,
+                              max_seq_len=S, margin=0.3, lr=1e-3, overlap_streams=True)
+
+    staged = [TripletBatch(ids=i.cuda(), lens=l.cuda(), neg_index=n.cuda()) for i, l, n in host]
+    torch.cuda.synchronize()
+    ref = trainer()
+    ref_loss = ref.train_epoch(staged)
+
+    cs = torch.cuda.Stream()
+    busy = torch.randn(4096, 4096, device="cuda")
+
+    def late_batches():
+        for ids_h, lens_h, neg_h in host:
+            with torch.cuda.stream(cs):
+                for _ in range(6):
+                    busy @ busy
+                ids, lens, neg = (t.to("cuda", non_blocking=True) for t in (ids_h, lens_h, neg_h))
+                ev = torch.cuda.Event()
+                ev.record(cs)
+            yield TripletBatch(ids=ids, lens=lens, neg_index=neg, ready_event=ev)
+            del ids, lens, neg
+            with torch.cuda.stream(cs):  # same-sized requests on the producer's stream, overwritten at once
+                s1 = torch.full((2, B, S), V - 1, dtype=torch.int32, device="cuda")
+                s2 = torch.full((2, B), 1, dtype=torch.int32, device="cuda")
+                s3 = torch.full((B,), 0, dtype=torch.int32, device="cuda")
+                del s1, s2, s3
+
+    tr = trainer()
+    loss = tr.train_epoch(late_batches())
+    assert loss == ref_loss
+    assert torch.equal(tr.flat, ref.flat)

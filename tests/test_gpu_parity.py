@@ -557,12 +557,18 @@ def test_inbatch_triplet_vs_oracle(tt, Bq, Bd, P, ids):
 
 
 # --------------------------------------------------------------------------- BASELINE size: properties
-def test_metric_size_properties(tt):
-    """BASELINE.json configs[1] at its full size (V=30522, D=P=384, S=128, B=2048 triplets), where the
-    oracle would take minutes: size-independent properties + the oracle on a row subsample (the forward is
+@pytest.mark.parametrize("V,D,P,B,S", [
+    pytest.param(30522, 384, 384, 2048, 128, id="configs1_b2048_p384"),
+    pytest.param(30522, 384, 512, 1024, 128, id="configs2_one_gpu_share_b1024_p512"),
+    pytest.param(250000, 768, 768, 16384, 256, id="configs3_v250k_d768_b16384_s256"),
+])
+def test_metric_size_properties(tt, V, D, P, B, S):
+    """BASELINE.json configs[1], [2] (one GPU's share) and [3] at their full sizes, where the oracle would
+    take minutes to hours: size-independent properties + the oracle on a row subsample (the forward is
     row-independent, so any subset of rows must agree with the oracle run on just those rows)."""
     ops, engine = tt
-    V, D, P, B, S = 30522, 384, 384, 2048, 128
+    from two_towers_overlords_amd import _lib
+
     gen = torch.Generator().manual_seed(77)
     table = orc.synthetic_table(V, D, seed=1)
     params = orc.init_params(D, P, seed=2)
@@ -610,7 +616,9 @@ def test_metric_size_properties(tt):
     emb, pooled, g, loss, flat1 = run()
     emb2, pooled2, g2, loss2, flat2 = run()
     assert torch.equal(emb, emb2) and torch.equal(g, g2) and loss == loss2 and torch.equal(flat1, flat2)
-    assert torch.equal(pooled.reshape(3 * B, D), sliced)  # the engine's gather is the public entry point's
+    # the engine's gather is the public entry point's (XCD-sliced form where the library prefers it)
+    engine_form = sliced if _lib.load().tt_k1_prefers_sliced(V, D, 3 * B, S) else per_text
+    assert torch.equal(pooled.reshape(3 * B, D), engine_form)
 
     # oracle on a subsample of rows: pooled vectors and projected embeddings
     pick = torch.randperm(B, generator=gen)[:48]
@@ -634,7 +642,10 @@ def test_metric_size_properties(tt):
     ref_loss.backward()
     assert abs(loss - ref_loss.item()) <= 1e-6
     ref_g = torch.cat([p64[k].grad.reshape(-1) for k in orc.PARAM_KEYS]).float()
-    close(g, ref_g, atol=1e-6)
+    # fp32 weight gradients are sums over B (query tower) / 2B (document tower) rows: the rounding error of such a
+    # sum grows like sqrt(rows) — 1e-6 at the 2048 triplets of configs[1], 2.8e-6 at the 16384 of configs[3]
+    # (measured there: 1.8e-6); BASELINE's own bound is 1e-5
+    close(g, ref_g, atol=1e-6 * max(1.0, B / 2048) ** 0.5)
     # Adam's first step moves every parameter by at most lr (and by ~lr where the gradient is not noise)
     step = (flat1 - _flat(params).cuda()).abs()
     assert step.max().item() <= 1e-3 * (1 + 1e-5)

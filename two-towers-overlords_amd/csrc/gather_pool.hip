@@ -241,8 +241,8 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
 // A second launch adds a text's NS partials in slice order (fixed order: bitwise reproducible),
 // divides by the mask sum and L2-normalises.  Costs N*NS*D*4 bytes written + read.
 // (NS = 16 in two grid phases, so that a slice fits the L2 whole, doubles the partials: 114 vs 96 us.)
-template <typename IdT, typename MaskT, int C, int U, int NS, int MAXSEG>
-__global__ __launch_bounds__(kThreads) void pool_sliced_kernel(
+template <typename IdT, typename MaskT, int C, int U, int NS, int MAXSEG, int WPB = kWavesPerText>
+__global__ __launch_bounds__(WPB * TT_WAVE) void pool_sliced_kernel(
     const float* __restrict__ table, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ partial, float* __restrict__ wsum_out, long long N,
     int S, int D, long long V, int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(kThreads) void pool_sliced_kernel(
   const int wave = threadIdx.x >> 6;
   static_assert(NS == 8, "one residue class per XCD");
   const int slice = (int)(blockIdx.x % NS);
-  const long long tstride = (long long)(gridDim.x / NS) * kWavesPerText;
-  long long text = (long long)(blockIdx.x / NS) * kWavesPerText + wave;
+  const long long tstride = (long long)(gridDim.x / NS) * WPB;
+  long long text = (long long)(blockIdx.x / NS) * WPB + wave;
   if (text >= N) return;  // wave-uniform; no workgroup barrier anywhere below
   int* const lbase = sliced_lds + wave * (4 * S);
   const int nchunk = D >> 2;
@@ -574,13 +574,16 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
   float* partial = ws;
   float* wsum = ws + (size_t)N * kSlices * D;
-  const long long groups_all = (N + kWavesPerText - 1) / kWavesPerText;
+  // waves (= texts) per gather workgroup: TT_K1_WAVES=4|6|8 (A/B)
+  static const int wpb = getenv("TT_K1_WAVES") ? atoi(getenv("TT_K1_WAVES")) : kWavesPerText;
+  const long long groups_all = (N + wpb - 1) / wpb;
+  const long long combine_groups = (N + kWavesPerText - 1) / kWavesPerText;
   // Default: one workgroup per (4 texts, slice), residency steered through dynamic LDS like the per-text
   // form.  TT_K1_SLICED_BPC=n (A/B) makes the grid persistent instead: n workgroups per CU walking the
   // texts — within 5 % alone, 4 % slower beside the projection kernels (213-216 vs 205 us per step).
   static const int persist_bpc = getenv("TT_K1_SLICED_BPC") ? atoi(getenv("TT_K1_SLICED_BPC")) : 0;
   long long G = groups_all;
-  unsigned lds = (unsigned)(4 * kWavesPerText * S * sizeof(int));
+  unsigned lds = (unsigned)(4 * wpb * S * sizeof(int));
   if (persist_bpc > 0) {
     G = (long long)cu_count() * persist_bpc / 8;
     if (G > groups_all) G = groups_all;
@@ -590,17 +593,23 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   }
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
   const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
-#define TT_SLICED_LAUNCH(CC, UU, MS)                                                                          \
-  hipLaunchKernelGGL((pool_sliced_kernel<IdT, MaskT, CC, UU, kSlices, MS>), dim3((unsigned)(G * kSlices)),     \
-                     dim3(kThreads), lds, st, table, ids_t, mask_t, lens, partial, wsum, (long long)N, S, D,   \
+#define TT_SLICED_LAUNCH_W(CC, UU, MS, WW)                                                                    \
+  hipLaunchKernelGGL((pool_sliced_kernel<IdT, MaskT, CC, UU, kSlices, MS, WW>), dim3((unsigned)(G * kSlices)), \
+                     dim3(WW * TT_WAVE), lds, st, table, ids_t, mask_t, lens, partial, wsum, (long long)N, S, D, \
                      (long long)V, oob, text_rows, (long long)n_store)
+#define TT_SLICED_LAUNCH(CC, UU, MS)                       \
+  do {                                                     \
+    if (wpb == 6) TT_SLICED_LAUNCH_W(CC, UU, MS, 6);       \
+    else if (wpb == 8) TT_SLICED_LAUNCH_W(CC, UU, MS, 8);  \
+    else TT_SLICED_LAUNCH_W(CC, UU, MS, 4);                \
+  } while (0)
 #define TT_SLICED_CASE(CC, UU)                  \
   do {                                          \
     if (nseg <= 2) TT_SLICED_LAUNCH(CC, UU, 2); \
     else if (nseg <= 4) TT_SLICED_LAUNCH(CC, UU, 4); \
     else TT_SLICED_LAUNCH(CC, UU, 8);           \
     TT_CHECK_LAUNCH();                          \
-    hipLaunchKernelGGL((pool_combine_kernel<CC, kSlices>), dim3((unsigned)groups_all), dim3(kThreads), 0, st, \
+    hipLaunchKernelGGL((pool_combine_kernel<CC, kSlices>), dim3((unsigned)combine_groups), dim3(kThreads), 0, st, \
                        partial, wsum, out, (long long)N, D); \
   } while (0)
   switch (C) {
@@ -611,6 +620,7 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   }
 #undef TT_SLICED_CASE
 #undef TT_SLICED_LAUNCH
+#undef TT_SLICED_LAUNCH_W
   TT_CHECK_LAUNCH();
   return TT_OK;
 }

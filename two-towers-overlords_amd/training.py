@@ -146,6 +146,10 @@ class TripletBatch:
     cache_rows: Optional[torch.Tensor] = None
     query_ids: Optional[torch.Tensor] = None  # int64 [B]; in-batch-negatives loss: same-query documents are not negatives
     token_rows: Optional[torch.Tensor] = None
+    # recorded by the producer on ITS stream once the batch's tensors are complete (e.g. after the non_blocking
+    # host->device copies on a copy stream); the gather then waits for it.  Not needed for tensors produced on the
+    # stream that calls gather(): that stream is fenced anyway.
+    ready_event: Optional["torch.cuda.Event"] = None
 
     @property
     def size(self) -> int:
@@ -161,7 +165,7 @@ class TripletBatch:
         ni = self.neg_index.long()
         cat = lambda t: None if t is None else torch.cat([t, t[1:2].index_select(1, ni)], dim=0).contiguous()
         return TripletBatch(cat(self.ids), cat(self.mask), cat(self.lens), None, cat(self.cache_rows), self.query_ids,
-                            cat(self.token_rows))
+                            cat(self.token_rows), self.ready_event)
 
 
 def as_batch(b) -> TripletBatch:
@@ -239,14 +243,13 @@ class TripletTrainer:
         if self.world > 1:
             self.sync_replicas()   # replicas start from rank 0's weights (what DDP's constructor broadcast does)
         self.side = torch.cuda.Stream(self.device) if (overlap_streams and self.device.type == "cuda") else None
-        # gathered, not yet applied: (slot, ready event, local B, neg_index, query_ids, batch).  The batch is
-        # kept referenced until apply() has made the main stream wait for its gather: K1 reads ids / mask /
-        # lens on the side stream, and a tensor dropped earlier could be handed out again by the caching
-        # allocator (which orders reuse on the main stream only) while K1 still reads it.
+        # gathered, not yet applied: (slot, ready event, local B, neg_index, query_ids)
         self._pending = collections.deque()
         self._next_slot = 0
+        self._apply_stream = None             # the stream the last apply() ran phase B on
         if self.side is not None:             # events are reused: one "fence" and one "ready" per slot
             self._slot_fence = [torch.cuda.Event() for _ in range(self.SLOTS)]
+            self._slot_fence2 = [torch.cuda.Event() for _ in range(self.SLOTS)]
             self._slot_ready = [torch.cuda.Event() for _ in range(self.SLOTS)]
             # tt_engine_create cleared the workspace on the main stream: order the side stream behind it
             self.side.wait_stream(torch.cuda.current_stream(self.device))
@@ -292,24 +295,37 @@ class TripletTrainer:
         if batch.neg_index is not None and self.world > 1:
             batch = batch.expand_negatives()  # an in-batch index does not survive sharding across ranks
         if batch.size == 0:  # an empty shard (global batch smaller than the world): nothing to pool
-            self._pending.append((slot, None, 0, None, batch.query_ids, None))
+            self._pending.append((slot, None, 0, None, batch.query_ids))
             return
         if self.side is None:
             self._timed_pool(slot, batch, None)
-            self._pending.append((slot, None, batch.size, batch.neg_index, batch.query_ids, None))
+            self._pending.append((slot, None, batch.size, batch.neg_index, batch.query_ids))
             return
         # Order the side stream behind everything the caller's stream holds at this point: (a) the kernels or
-        # copies that PRODUCE this batch's ids / mask / lens / cache_rows (a loader's index ops, a
-        # non_blocking H2D copy), (b) the fwd_bwd that last read this pooled-input slot (enqueued earlier on
-        # the same stream), (c) graph replays.  K1 runs two batches ahead, so this wait is off the critical path.
+        # copies that PRODUCE this batch's ids / mask / lens / rows (a loader's index ops, a non_blocking
+        # H2D copy), (b) the fwd_bwd that last read this pooled-input slot (enqueued earlier on the same
+        # stream), (c) graph replays.  K1 runs two batches ahead, so this wait is off the critical path.
+        cur = torch.cuda.current_stream(self.device)
         fence = self._slot_fence[slot]
-        fence.record(torch.cuda.current_stream(self.device))
+        fence.record(cur)
         self.side.wait_event(fence)
+        if self._apply_stream is not None and cur != self._apply_stream:
+            # the batch was produced on a stream of its own (a copy stream): (b) lives on the stream apply() uses
+            fence2 = self._slot_fence2[slot]
+            fence2.record(self._apply_stream)
+            self.side.wait_event(fence2)
+        if batch.ready_event is not None:  # produced on a stream of its own (a copy stream)
+            self.side.wait_event(batch.ready_event)
+        # K1 reads these tensors on the side stream: tell the caching allocator, so that memory the producer
+        # drops right after this call is not handed out again before K1 has finished with it
+        for t in (batch.ids, batch.mask, batch.lens, batch.cache_rows, batch.token_rows):
+            if t is not None:
+                t.record_stream(self.side)
         # launch on the side stream by handle (no stream context switch on the host)
         self._timed_pool(slot, batch, self.side)
         ev = self._slot_ready[slot]
         ev.record(self.side)
-        self._pending.append((slot, ev, batch.size, batch.neg_index, batch.query_ids, batch))
+        self._pending.append((slot, ev, batch.size, batch.neg_index, batch.query_ids))
 
     def _timed_pool(self, slot, batch: TripletBatch, stream) -> None:
         timed = False
@@ -366,7 +382,7 @@ class TripletTrainer:
         `issue_next()` (optional) is called where enqueueing further gathers overlaps best:
         before the projection kernels when gathers have their own stream, else right after
         the gradient all-reduce has been launched."""
-        slot, ev, local_B, neg_index, query_ids, held = self._pending.popleft()
+        slot, ev, local_B, neg_index, query_ids = self._pending.popleft()
         global_B = global_B or local_B * self.world
         if global_B <= 0:
             raise ValueError("apply(): empty global batch")
@@ -376,9 +392,13 @@ class TripletTrainer:
             if issue_next is not None:
                 issue_next()
                 issue_next = None
-            if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
-        del held  # the main stream is now ordered behind this batch's gather: its tensors may be reused
+            self._apply_stream = torch.cuda.current_stream(self.device)
+            if ev is not None and not ev.query():  # (a gather issued two batches ago has usually finished:
+                self._apply_stream.wait_event(ev)  #  then no wait packet goes into this stream at all)
+        if self.device.type == "cuda":  # read by phase B on this stream, possibly allocated on a producer's stream
+            for t in (neg_index, query_ids):
+                if t is not None:
+                    t.record_stream(torch.cuda.current_stream(self.device))
         if self.loss_kind == "inbatch":
             self._inbatch_fwd_bwd(slot, local_B, query_ids, k, global_B)
         elif local_B > 0:
@@ -564,7 +584,7 @@ class TripletTrainer:
             return False
         if self.eager_every and self._steps_done % self.eager_every == self.eager_every - 1:
             return False
-        _, _, B, neg_index, _, _ = entry
+        _, _, B, neg_index, _ = entry
         if neg_index is not None or B != self.engine.max_B or self.loss_kind != "triplet":
             return False
         if nxt is None:
@@ -621,7 +641,7 @@ class TripletTrainer:
         if not self._graphable(entry, nxt):
             self.apply(global_B, issue_next=(lambda: self.gather(nxt)) if nxt is not None else None)
             return
-        slot_fb, ev, B, _, _, _held = self._pending.popleft()
+        slot_fb, ev, B, _, _ = self._pending.popleft()
         slot_k1 = None
         if nxt is not None:
             slot_k1 = self._next_slot
@@ -635,7 +655,7 @@ class TripletTrainer:
         self._micro += 1
         self.step_count += 1
         if slot_k1 is not None:
-            self._pending.append((slot_k1, None, B, None, None, None))
+            self._pending.append((slot_k1, None, B, None, None))
 
     # -- public ------------------------------------------------------------------
     def train_step(self, batch: Batch, global_batch: Optional[int] = None) -> None:
@@ -702,7 +722,8 @@ def shard_batch(batch: Batch, rank: int, world: int) -> Tuple[Batch, int]:
     if isinstance(batch, TripletBatch):
         ni = tb.neg_index if world == 1 else None
         qid = None if tb.query_ids is None else tb.query_ids[lo:hi].contiguous()  # [B], not [roles, B]
-        return TripletBatch(cut(tb.ids), cut(tb.mask), cut(tb.lens), ni, cut(tb.cache_rows), qid, cut(tb.token_rows)), B
+        return TripletBatch(cut(tb.ids), cut(tb.mask), cut(tb.lens), ni, cut(tb.cache_rows), qid, cut(tb.token_rows),
+                            tb.ready_event), B
     return (cut(tb.ids), cut(tb.mask), cut(tb.lens)), B
 
 

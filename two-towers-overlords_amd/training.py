@@ -435,7 +435,7 @@ class TripletTrainer:
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
 
     # -- calibration ----------------------------------------------------------------------
-    def calibrate(self, batch: Batch, steps: int = 32, rounds: int = 2) -> dict:
+    def calibrate(self, batch: Batch, steps: int = 48, rounds: int = 2) -> dict:
         """Time phase B's two backward schedules (include/tt_hotpath.h, tt_engine_set_backward) on THIS
         device with THIS batch shape — gathers running beside them exactly as in training — and keep the
         faster one.  The two tie at some shapes and differ by 5-10 % at others, and the

@@ -415,3 +415,68 @@ def test_batches_produced_on_a_copy_stream_are_waited_for_through_ready_event():
     loss = tr.train_epoch(late_batches())
     assert loss == ref_loss
     assert torch.equal(tr.flat, ref.flat)
+
+
+def test_bert_mode_trains_on_the_frozen_feature_cache_like_the_module_path():
+    """`bert` encoder mode (what backend/model.py:51-52 executes): the module path re-runs the frozen encoder three
+    times per step like the reference does; the fused trainer runs it once per text into the feature cache and then
+    trains cache-fed.  Same triplets (same loader seed) -> same losses and parameters."""
+    transformers = pytest.importorskip("transformers")
+    from two_towers_overlords_amd.data import TokenTripletLoader
+    from two_towers_overlords_amd.model import TripletLoss, TwoTowersModel
+    from two_towers_overlords_amd.training import FusedAdam, TripletTrainer, train_epoch
+
+    torch.manual_seed(11)
+    cfg = transformers.BertConfig(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=4,
+                                  intermediate_size=64, max_position_embeddings=32)
+    bert = transformers.BertModel(cfg).eval()
+    N, B, Sq, Sp, P = 90, 32, 6, 20, 16
+    gen = torch.Generator().manual_seed(4)
+    q = torch.randint(1, 120, (N, Sq), generator=gen).int()
+    p = torch.randint(1, 120, (N, Sp), generator=gen).int()
+    ql = torch.randint(2, Sq + 1, (N,), generator=gen).int()
+    pl = torch.randint(3, Sp + 1, (N,), generator=gen).int()
+    q = q * (torch.arange(Sq).unsqueeze(0) < ql.unsqueeze(1))
+    p = p * (torch.arange(Sp).unsqueeze(0) < pl.unsqueeze(1))
+    qids = torch.arange(N) // 3
+
+    def model():
+        torch.manual_seed(5)  # same projection init for both paths
+        return TwoTowersModel(projection_dim=P, tokenizer=lambda *a, **k: None, pretrained_model=bert,
+                              encoder_mode="bert").cuda()
+
+    def loader(emit):
+        return TokenTripletLoader.from_tensors(q, ql, p, pl, qids, batch_size=B, device="cuda", seed=3,
+                                               sampler="reference", emit=emit)
+
+    # module path: three encoder passes per step (the reference's loop, training.py:36-53)
+    ma = model()
+    opt = FusedAdam(ma.parameters(), lr=1e-3)
+    crit = TripletLoss(margin=0.3)
+    la = loader("ids3")
+
+    def as_pairs(it):
+        for ids, lens in it:
+            S = ids.shape[2]
+            m = (torch.arange(S, device="cuda").view(1, 1, S) < lens.unsqueeze(-1)).long()
+            yield tuple((ids[r].long(), m[r]) for r in range(3))
+
+    loss_a = [train_epoch(ma, as_pairs(la), crit, opt, log_wandb=False) for _ in range(2)]
+
+    # fused path: encoder once per text, then cache-fed epochs
+    mb = model()
+    lb = loader("cache")
+    tr = TripletTrainer(mb, max_batch=B, max_seq_len=Sp, margin=0.3, lr=1e-3)
+    with pytest.raises(RuntimeError):   # token batches have no meaning without the encoder
+        tr.train_epoch(as_b for as_b in [next(iter(loader("ids3")))])
+    tr._pending.clear()
+    ids_all, lens_all = lb.all_texts()
+    cache = tr.build_feature_cache(ids_all, lens=lens_all, chunk=40)
+    assert cache.shape == (2 * N, 32) and float((cache.norm(dim=1) - 1).abs().max()) <= 1e-5
+    loss_b = [tr.train_epoch(lb) for _ in range(2)]
+
+    for a, b in zip(loss_a, loss_b):
+        assert abs(a - b) <= 2e-5
+    steps = 2 * ((N + B - 1) // B)
+    for pa, pb in zip(ma.trainable_parameters(), mb.trainable_parameters()):
+        assert_params_close(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), 1e-3, steps, tight=2e-6)

@@ -196,14 +196,19 @@ class TripletTrainer:
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
                  freeze_gc: bool = True):
         if model is not None:
-            if model.query_tower.encoder_mode != "embed":
-                raise ValueError("the fused engine implements the `embed` encoder mode; use train_epoch for `bert`")
+            # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
+            # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
+            # once per text by build_feature_cache() (stock PyTorch ops + the dense pool kernel) and the step is fed
+            # from that cache; the table is bound only because the engine wants one.
+            encoder_mode = model.query_tower.encoder_mode
             table = model.query_tower.embedding_table().detach()
             tensors = [p.detach() for p in model.trainable_parameters()]
         else:
             if table is None or params is None:
                 raise ValueError("pass a TwoTowersModel or table= and params=")
+            encoder_mode = "embed"
             tensors = [params[name] for name, _, _ in flat_param_slices(table.shape[1], _proj_dim(params))]
+        self.encoder_mode = encoder_mode
         if loss not in ("triplet", "inbatch"):
             raise ValueError("loss must be 'triplet' (the reference's sampled-negative triplet loss) or 'inbatch'")
         self.loss_kind = loss
@@ -338,6 +343,9 @@ class TripletTrainer:
             e0.record(stream)
         if hasattr(self.engine, "set_sharing"):  # a row copy from the cache does not compete with phase B
             self.engine.set_sharing(batch.cache_rows is None and self.side is not None)
+        if batch.cache_rows is None and self.encoder_mode != "embed":
+            raise RuntimeError("`bert` encoder mode: the frozen encoder is not part of the fused step; call "
+                               "build_feature_cache() once and feed cache_rows batches (TokenTripletLoader emit='cache')")
         if batch.cache_rows is not None:
             if self.feature_cache is None:
                 raise RuntimeError("batch carries cache_rows but build_feature_cache() has not been called")
@@ -364,16 +372,42 @@ class TripletTrainer:
 
     @torch.no_grad()
     def build_feature_cache(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None,
-                            lens: Optional[torch.Tensor] = None, chunk: int = 65536) -> torch.Tensor:
+                            lens: Optional[torch.Tensor] = None, chunk: Optional[int] = None) -> torch.Tensor:
         """Frozen-feature cache: the encoder is frozen (backend/model.py:29-30,51),
-        so every text's pooled-normalised vector is computed ONCE here (K1 over ids [N,S]) and later
-        batches only copy rows (`TripletBatch.cache_rows`).  Returns the [N, D] cache."""
+        so every text's pooled-normalised vector is computed ONCE here and later batches only copy rows
+        (`TripletBatch.cache_rows`).  `embed` mode: K1 over ids [N,S].  `bert` mode: the frozen encoder
+        (stock PyTorch-ROCm ops, `chunk` texts at a time) + the dense pool kernel — what the reference
+        recomputes three times per step in every epoch (training.py:40-42) runs once per text, and every
+        epoch after that is the fused cache-fed step.  Returns the [N, D] cache."""
         N = ids.shape[0]
         out = torch.empty((N, self.D), dtype=torch.float32, device=self.device)
-        for s in range(0, N, chunk):
-            e = min(N, s + chunk)
-            ops.gather_pool_norm(self.table, ids[s:e].contiguous(), None if mask is None else mask[s:e].contiguous(),
-                                 None if lens is None else lens[s:e].contiguous(), out=out[s:e])
+        bert = self.encoder_mode != "embed"
+        if bert:
+            if self.model is None:
+                raise RuntimeError("`bert` mode needs the TwoTowersModel the trainer was built from")
+            _require_same_frozen_encoder(self.model)
+            if mask is None and lens is not None:
+                mask = (torch.arange(ids.shape[1], device=ids.device).unsqueeze(0) < lens.unsqueeze(1)).to(torch.int64)
+        chunk = chunk or (512 if bert else 65536)
+        if bert:
+            # encoder cost grows with the padded length: walk the texts in length order, each chunk cut to its own
+            # longest row (queries are a tenth of a passage) — the per-chunk read-back is set-up cost, once per run
+            if mask is not None:
+                order = mask.sum(1).argsort()
+            else:
+                order = torch.arange(N, device=ids.device)
+            for s in range(0, N, chunk):
+                sel = order[s: s + chunk]
+                cut = ids.shape[1] if mask is None else max(int(mask[sel].sum(1).max()), 1)
+                tokens = {"input_ids": ids[sel][:, :cut].long().contiguous()}
+                if mask is not None:
+                    tokens["attention_mask"] = mask[sel][:, :cut].contiguous()
+                out[sel] = self.model.query_tower.pool_tokens(tokens)
+        else:
+            for s in range(0, N, chunk):
+                e = min(N, s + chunk)
+                ops.gather_pool_norm(self.table, ids[s:e].contiguous(), None if mask is None else mask[s:e].contiguous(),
+                                     None if lens is None else lens[s:e].contiguous(), out=out[s:e])
         self.feature_cache = out
         return out
 
@@ -727,6 +761,17 @@ def shard_batch(batch: Batch, rank: int, world: int) -> Tuple[Batch, int]:
     return (cut(tb.ids), cut(tb.mask), cut(tb.lens)), B
 
 
+def _require_same_frozen_encoder(model: TwoTowersModel) -> None:
+    """One feature cache serves both towers only if they hold the same frozen encoder — the reference loads the same
+    pretrained model into each tower (backend/model.py:84-85), this package shares one object by default."""
+    a, b = model.query_tower.pretrained_model, model.document_tower.pretrained_model
+    if a is b:
+        return
+    sa, sb = a.state_dict(), b.state_dict()
+    if sa.keys() != sb.keys() or any(not torch.equal(sa[k], sb[k]) for k in sa):
+        raise ValueError("the two towers hold different frozen encoders: one feature cache cannot serve both")
+
+
 def _proj_dim(params: dict) -> int:
     return params["query_tower.projection.0.bias"].shape[0]
 
@@ -742,7 +787,7 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
                  run_comprehensive_test: bool = True, *, train_dataset=None, val_dataset=None, test_dataset=None,
                  tokenizer=None, pretrained_model=None, model_name: Optional[str] = None,
                  seed: Optional[int] = None, feature_cache: bool = True, sampler: str = "device",
-                 encoder_mode: str = "embed", calibrate: bool = True) -> TwoTowersModel:
+                 encoder_mode: str = "embed", calibrate: bool = True, three_encodes: bool = False) -> TwoTowersModel:
     """Same keyword surface and defaults as backend/training.py:383-397; builds the
     model / criterion / Adam exactly like :433-436 and runs `num_epochs` epochs on
     the fused engine.  Differences, all outside the hot path: the dataset is passed
@@ -751,9 +796,11 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
     harness (training.py:136-380) are not reproduced, `use_mixed_precision` /
     `num_workers` / `run_comprehensive_test` are accepted for signature parity and
     ignored (fp32 is the parity path; tokenisation happens once, up front).
-    `encoder_mode` is explicit here: the fused engine implements "embed" (word-embedding rows pooled
-    directly); for the reference's executed behaviour (frozen encoder between gather and pool) build
-    the model with encoder_mode="bert" and use `train_epoch`.  `sampler`: "device" draws the in-batch
+    `encoder_mode` is explicit here.  "embed": word-embedding rows pooled directly (the HIP gather).  "bert": the
+    reference's executed behaviour (frozen encoder between gather and pool, backend/model.py:51-52) — the encoder
+    runs ONCE per text into the frozen-feature cache (it is frozen: its outputs never change), every epoch is then
+    the fused cache-fed step, where the reference re-runs the encoder three times per step (99 % of its step
+    time); needs feature_cache=True.  `sampler`: "device" draws the in-batch
     negatives with tensor ops (same distribution, no per-batch host work); "reference" reproduces
     backend/data.py:132-137's draws under `seed`, at its O(B^2) Python cost per batch."""
     from .data import TokenTripletLoader
@@ -774,15 +821,20 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
     max_S = int(max(loader.q_ids.shape[1], loader.p_ids.shape[1]))
     trainer = TripletTrainer(model, max_batch=batch_size, max_seq_len=max_S, margin=margin, lr=learning_rate,
                              accumulation_steps=accumulation_steps)
+    if encoder_mode != "embed" and not feature_cache:
+        raise ValueError("run_training(encoder_mode='bert') runs on the frozen-feature cache: feature_cache=True "
+                         "(or use train_epoch on the module path, which re-runs the encoder every step like the reference)")
     if feature_cache:
         # the encoder is frozen: pool every query / passage once, every epoch then only copies rows and
         # takes its negatives by in-batch index
         loader.emit = "cache"
         trainer.build_feature_cache(*_ids_lens(loader.all_texts()))
     else:
-        # three gathers per batch like the reference's three encodes; the token rows stay on the device
-        # and a batch names its texts by row
-        loader.emit = "rows3"
+        # the token rows stay on the device and a batch names its texts by row; the negatives ARE
+        # in-batch positives (backend/data.py:113-137), so by default they are taken by index from the positives'
+        # embeddings (two gathers; same triplets, same numbers up to fp32 summation order) instead of being encoded
+        # a third time (three_encodes=True: the reference's three encodes, training.py:40-42)
+        loader.emit = "rows3" if three_encodes else "rows2"
         trainer.set_token_store(*loader.all_texts())
     if calibrate and len(loader) > 0:
         trainer.calibrate(next(iter(loader)))

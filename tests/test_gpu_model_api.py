@@ -286,7 +286,7 @@ def test_gather_is_ordered_behind_batches_produced_on_the_callers_stream():
     gather.  Result must be bitwise the run on pre-staged, synchronised batches."""
     from two_towers_overlords_amd.training import TripletTrainer
 
-    V, D, P, B, S, NB = 5000, 384, 64, 256, 64, 6
+    V, D, P, B, S, NB = 5000, 384, 64, 256, 64, 24
     table = orc.synthetic_table(V, D, seed=1) * 30
     params = orc.init_params(D, P, seed=2)
     host = []
@@ -372,7 +372,7 @@ def test_batches_produced_on_a_copy_stream_are_waited_for_through_ready_event():
     and the main stream (neg_index in phase B) still use the tensors."""
     from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
 
-    V, D, P, B, S, NB = 5000, 384, 64, 256, 64, 6
+    V, D, P, B, S, NB = 5000, 384, 64, 256, 64, 24
     table = orc.synthetic_table(V, D, seed=1) * 30
     params = orc.init_params(D, P, seed=2)
     gen = torch.Generator().manual_seed(5)

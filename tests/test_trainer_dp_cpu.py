@@ -209,3 +209,30 @@ def test_neg_index_and_feature_cache_equal_three_encodes():
         assert abs(runs[mode][0] - runs["ids3"][0]) < 1e-6
         for k in orc.PARAM_KEYS:
             np.testing.assert_allclose(runs[mode][1][k].numpy(), runs["ids3"][1][k].numpy(), atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("accum", [1, 3])
+def test_trainer_state_dict_resumes_exactly(accum):
+    """Two epochs straight == one epoch, state_dict() -> a NEW trainer -> load_state_dict(), one more epoch: parameters,
+    Adam moments, step counters and (with accumulation) the carried gradient bucket all continue bit for bit."""
+    from oracle_engine import OracleEngine
+    from two_towers_overlords_amd.training import TripletTrainer
+
+    torch.set_num_threads(1)
+    table, params, batches = _setup()
+    gbs = _global_batches(batches)
+
+    def trainer(p):
+        return TripletTrainer(table=table, params={k: v.clone() for k, v in p.items()}, max_batch=B, max_seq_len=S,
+                              margin=0.3, lr=1e-3, accumulation_steps=accum, engine=OracleEngine(table, P, B, S))
+
+    a = trainer(params)
+    la = [a.train_epoch(gbs), a.train_epoch(gbs)]
+    b = trainer(params)
+    lb = [b.train_epoch(gbs)]
+    sd = b.state_dict()
+    c = trainer(orc.init_params(D, P, seed=999))  # different weights: everything must come from the checkpoint
+    c.load_state_dict(sd)
+    lb.append(c.train_epoch(gbs))
+    assert la == lb and a.step_count == c.step_count and a._micro == c._micro
+    assert torch.equal(a.flat, c.flat) and torch.equal(a.exp_avg, c.exp_avg) and torch.equal(a.exp_avg_sq, c.exp_avg_sq)

@@ -468,6 +468,37 @@ class TripletTrainer:
             self.step_count += 1
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
 
+    # -- checkpoint / resume of the optimizer side ---------------------------------------------
+    def state_dict(self) -> dict:
+        """Everything a later `load_state_dict` needs to continue this run exactly: the flat parameters (the
+        model's `state_dict()` holds the same values under the reference's key names, backend/main.py:137-150
+        saves only those), both Adam moments, the optimizer-step and micro-batch counters and the gradient
+        bucket of an unfinished accumulation window (backend/training.py:99-102 carries it across epochs).
+        The reference itself cannot resume: it saves no optimizer state."""
+        if self._pending:
+            raise RuntimeError("state_dict(): batches are still in flight; call it between epochs")
+        cpu = lambda t: None if t is None else t.detach().to("cpu", copy=True)
+        return {"flat": cpu(self.flat), "exp_avg": cpu(self.exp_avg), "exp_avg_sq": cpu(self.exp_avg_sq),
+                "bucket": cpu(self.bucket) if self.accumulation_steps > 1 else None,
+                "step_count": self.step_count, "micro": self._micro, "D": self.D, "P": self.P,
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "margin": self.margin,
+                          "accumulation_steps": self.accumulation_steps}}
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Inverse of `state_dict()`.  Under data parallelism load on every rank, or on one rank and call
+        `sync_replicas()`."""
+        if self._pending:
+            raise RuntimeError("load_state_dict(): batches are still in flight")
+        if sd["D"] != self.D or sd["P"] != self.P or sd["flat"].numel() != self.flat.numel():
+            raise ValueError("checkpoint was written for another embedding / projection size")
+        for name in ("flat", "exp_avg", "exp_avg_sq"):
+            getattr(self, name).copy_(sd[name].to(self.device))   # in place: the engine and the modules alias these
+        if sd.get("bucket") is not None and self.bucket is not None:
+            self.bucket.copy_(sd["bucket"].to(self.device))
+        self.step_count, self._micro = int(sd["step_count"]), int(sd["micro"])
+        if self._auto_step:
+            self.engine.set_step(self.step_count)
+
     # -- calibration ----------------------------------------------------------------------
     def calibrate(self, batch: Batch, steps: int = 48, rounds: int = 2) -> dict:
         """Time phase B's two backward schedules (include/tt_hotpath.h, tt_engine_set_backward) on THIS
@@ -530,6 +561,8 @@ class TripletTrainer:
         src = self._src0()
         for t in (self.flat, self.exp_avg, self.exp_avg_sq):
             dist.broadcast(t, src=src, group=self.pg)
+        if self.bucket is not None:
+            dist.broadcast(self.bucket, src=src, group=self.pg)  # an unfinished accumulation window travels too
         steps = torch.tensor([self.step_count, self._micro], dtype=torch.int64, device=self.device)
         dist.broadcast(steps, src=src, group=self.pg)
         self.step_count, self._micro = int(steps[0]), int(steps[1])

@@ -306,6 +306,8 @@ def inbatch_triplet_fwd_bwd(q: torch.Tensor, d: torch.Tensor, margin: float, pos
     if qid_q is not None:
         _req(qid_q, "qid_q", torch.int64, 1)
         _req(qid_d, "qid_d", torch.int64, 1)
+    if Bq < 1 or Bd < 2:
+        raise ValueError("inbatch: needs at least one query and two documents (every negative is another document)")
     z = float(Bq * (Bd - 1))
     gs = (1.0 / z) if grad_scale is None else grad_scale
     den = z if loss_denominator is None else loss_denominator

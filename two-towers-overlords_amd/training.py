@@ -585,6 +585,8 @@ class TripletTrainer:
         activations on this path.  Shards may be uneven (`shard_batch`: the first global_B % world
         ranks hold one row more) or empty; every rank takes part in every collective."""
         eng = self.engine
+        if global_B < 2:
+            raise ValueError("in-batch-negatives loss: a (global) batch of one has no negatives")
         if self.world == 1:
             eng.forward(slot, B, 2)
             emb, dout = eng.embeddings(B, 2), eng.d_out(B, 2)

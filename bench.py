@@ -168,6 +168,10 @@ def main():
                     help="PCIe-inclusive rate: every step's ids [3,B,S] int32 come from pinned HOST memory by a "
                          "non_blocking copy on a copy stream (what the reference's `.to(device)` of the tokenizer "
                          "output is, backend/model.py:48); reported under its own metric name")
+    ap.add_argument("--simulate-allreduce-us", type=float, default=None,
+                    help="one GPU only, diagnostic: run the data-parallel step (bucket reduce, exchange, Adam from the "
+                         "bucket) with the all-reduce replaced by a kernel of this duration on its own stream — how much of "
+                         "an N-GPU all-reduce's latency the step would expose (RCCL's own CU use is not modelled)")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="skip TripletTrainer.calibrate() in set-up (it times the two backward schedules on this device "
                          "and keeps the faster; its ~130 dry steps also bring the GPU out of its idle power state)")
@@ -214,6 +218,21 @@ def main():
     for name, _, shape in flat_param_slices(D, P):
         bound = 1.0 / (shape[-1] if len(shape) == 2 else (D if ".0." in name else P)) ** 0.5
         params[name] = ((torch.rand(*shape, generator=gp) * 2 - 1) * bound).to(device)
+    if args.simulate_allreduce_us is not None and world == 1:
+        class TripletTrainer(TripletTrainer):  # noqa: F811  (diagnostic subclass: the exchange is a timed stand-in)
+            def __init__(self, *a, **kw):
+                super().__init__(*a, **kw)
+                self._exchange = True
+                self.bucket = torch.empty_like(self.flat)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(1000); torch.cuda.synchronize()
+                e0.record(); torch.cuda._sleep(10_000_000); e1.record(); e1.synchronize()
+                self._cycles = int(args.simulate_allreduce_us * 10_000_000 / (e0.elapsed_time(e1) * 1e3))
+
+            def _all_reduce(self, bucket):  # on the caller's stream, like a synchronous-op collective
+                if self._cycles > 0:
+                    torch.cuda._sleep(self._cycles)
+
     trainer = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
                              overlap_streams=(False if (args.no_overlap or args.k1_only) else None),
                              k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss)
@@ -377,6 +396,9 @@ def main():
     metric = (("triplets/sec (q,pos,neg @ seq128/d384), full training step" if args.config == "c2"
                else "triplets/sec, full training step") if args.inputs == "ids3"
               else f"triplets/sec, full training step, inputs={args.inputs}, loss={args.loss} (NOT the BASELINE metric)")
+    if args.simulate_allreduce_us is not None:
+        metric = (f"triplets/sec, data-parallel step on ONE GPU with the all-reduce replaced by a {args.simulate_allreduce_us:g} us "
+                  "stand-in kernel (diagnostic; NOT the BASELINE metric)")
     if args.h2d:
         metric = "triplets/sec, full training step, ids copied from pinned host memory every step (PCIe-inclusive; NOT the BASELINE metric)"
     if args.e2e:

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import collections
 import gc
+import os
 import dataclasses
 import math
 from typing import Iterable, Optional, Sequence, Tuple
@@ -242,7 +243,9 @@ class TripletTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
-        self.bucket = torch.empty_like(self.flat) if (self.world > 1 or self.accumulation_steps > 1) else None
+        self._exchange = self.world > 1        # gradients are exchanged between replicas (see _all_reduce)
+        self._gather_under_exchange = os.environ.get("TT_GATHER_UNDER_EXCHANGE", "1") != "0"  # A/B knob
+        self.bucket = torch.empty_like(self.flat) if (self._exchange or self.accumulation_steps > 1) else None
         self.step_count = 0        # optimizer steps taken
         self._micro = 0            # batches since the last optimizer step (carried across epochs, like the reference)
         if self.world > 1:
@@ -423,7 +426,13 @@ class TripletTrainer:
         k = self.accumulation_steps
         self._steps_done += 1
         if self.side is not None:
-            if issue_next is not None:
+            # Where the next gather goes.  Single replica: ahead of this batch's projection kernels (both streams
+            # stay busy back to back).  With a gradient exchange: right before the all-reduce (below), so that the
+            # gather starts when the chain goes idle for the exchange and the chain's own kernels run beside less
+            # of it — measured with a stand-in exchange on one GPU (bench.py --simulate-allreduce-us): placed ahead
+            # of the projection kernels instead, the gather is over before the exchange starts and the exchange's
+            # latency is fully exposed (a 60 us exchange: 286 vs 249 us per step).
+            if issue_next is not None and not (self._exchange and self._gather_under_exchange):
                 issue_next()
                 issue_next = None
             self._apply_stream = torch.cuda.current_stream(self.device)
@@ -457,13 +466,10 @@ class TripletTrainer:
             self.engine.reduce_grads(self.bucket, accumulate=not first_micro)
         elif first_micro:  # an empty shard contributes zero gradients but still takes part in the all-reduce
             self.bucket.zero_()
-        work = None
-        if do_step and self.world > 1:
-            work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         if issue_next is not None:
-            issue_next()  # weight-independent: runs under the all-reduce
-        if work is not None:
-            work.wait()
+            issue_next()  # weight-independent; enqueued BEFORE the exchange so that its fence does not wait for it
+        if do_step and self._exchange:
+            self._all_reduce(self.bucket)
         if do_step:
             self.step_count += 1
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
@@ -545,6 +551,15 @@ class TripletTrainer:
         self.engine.read_stats(reset=True)  # the dry steps' losses do not belong to any epoch
         self.calibration = {"backward": pick, "ms_per_step": best, "steps": steps, "rounds": rounds}
         return self.calibration
+
+    def _all_reduce(self, bucket: torch.Tensor) -> None:
+        """The step's one gradient exchange: sum of the flat bucket over the replicas (RCCL over xGMI on GPUs).
+        A synchronous-op call on purpose: torch's NCCL backend enqueues such a collective on the CALLER's stream,
+        where an async_op=True call hops to the backend's own stream and back — two cross-queue event waits of
+        10-15 us each on this hardware (tools/nccl_stream_probe.py: 45 vs 31 us per iteration), right on the critical
+        chain reduce -> exchange -> Adam.  Nothing blocks on the host either way; the gather of the next batch runs
+        beside it on the side stream."""
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
 
     # -- data parallel: replicas --------------------------------------------------------
     def _src0(self) -> int:

@@ -160,3 +160,71 @@ def test_inbatch_negatives_trainer_vs_oracle(world, Bg):
 
     for k in orc.PARAM_KEYS:
         assert_params_close(params[k], ref_params[k].numpy(), 1e-3, 3)
+
+
+# --------------------------------------------------------------------------- run_training under data parallelism
+def _rt_items():
+    import random
+
+    rng = random.Random(3)
+    V, items = 300, []
+    for qid in range(80):
+        qt = [rng.randrange(1, V) for _ in range(rng.randint(3, 6))]
+        for _ in range(rng.randint(1, 3)):
+            doc = [rng.choice(qt) if rng.random() < 0.6 else rng.randrange(1, V) for _ in range(rng.randint(6, 20))]
+            items.append({"query_id": qid, "query": " ".join(map(str, qt)), "positive": " ".join(map(str, doc))})
+    return V, items
+
+
+def _rt_worker(rank, world, port, cache, q):
+    try:
+        from test_gpu_eval import IntTokenizer
+        from two_towers_overlords_amd.model import EmbeddingOnlyEncoder
+        from two_towers_overlords_amd.training import run_training
+
+        if world > 1:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        V, items = _rt_items()
+        table = orc.synthetic_table(V, 64, seed=9) * 30
+        torch.manual_seed(100 + rank)  # every rank initialises its projections differently, like unseeded nn.Linear
+        m = run_training(num_epochs=2, batch_size=33, learning_rate=1e-2, max_samples=10 ** 6, projection_dim=32, margin=0.3,
+                         use_wandb=False, accumulation_steps=1, train_dataset=items, tokenizer=IntTokenizer(),
+                         pretrained_model=EmbeddingOnlyEncoder(table), seed=5 if rank == 0 else None, feature_cache=cache)
+        flat = torch.cat([p.detach().reshape(-1).cpu() for p in m.trainable_parameters()])
+        init = None
+        if rank == 0:
+            q.put(("ok", flat.numpy().copy(), init))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put(("error", f"rank {rank}: {e}\\n{traceback.format_exc()}", None))
+        raise
+
+
+@pytest.mark.parametrize("cache", [False, True])
+def test_run_training_two_ranks_equal_one_rank(cache):
+    """run_training launched on two ranks (global batches built identically from a broadcast seed, each rank trains its
+    contiguous shard, replicas start from rank 0's projections) ends with the parameters of the one-rank run that
+    starts from the same projections."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in (1, 2):
+        q = ctx.SimpleQueue()
+        port = 29800 + os.getpid() % 1000 + world + (10 if cache else 0)
+        procs = [ctx.Process(target=_rt_worker, args=(r, world, port, cache, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = q.get()
+        for p in procs:
+            p.join(180)
+        assert out[0] == "ok", out[1]
+        res[world] = out[1]
+    from conftest import assert_params_close
+
+    # both runs start from rank 0's torch.manual_seed(100) initialisation and see the same triplets
+    assert_params_close(res[2], res[1], 1e-2, 2 * 5, tight=5e-5)

@@ -17,6 +17,7 @@ from __future__ import annotations
 import collections
 import gc
 import os
+import random
 import dataclasses
 import math
 from typing import Iterable, Optional, Sequence, Tuple
@@ -857,7 +858,15 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
 
     if train_dataset is None:
         raise ValueError("run_training: pass train_dataset= (MS MARCO loading is outside the hot path)")
-    device = torch.device("cuda")
+    device = torch.device("cuda", torch.cuda.current_device())
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if world > 1:
+        # data parallel (launched one process per GPU, process group initialised by the caller): every rank builds
+        # the SAME global batches — same loader seed — and trains on its contiguous shard of each
+        s = torch.tensor([seed if seed is not None else random.getrandbits(60)], dtype=torch.int64, device=device)
+        dist.broadcast(s, src=0)
+        seed = int(s.item())
     kw = {}
     if model_name is not None:
         kw["model_name"] = model_name
@@ -886,18 +895,32 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
         # a third time (three_encodes=True: the reference's three encodes, training.py:40-42)
         loader.emit = "rows3" if three_encodes else "rows2"
         trainer.set_token_store(*loader.all_texts())
+    def epoch_batches():
+        if world == 1:
+            return loader, None
+        shards, sizes = [], []
+        for b in loader:  # views and tiny index ops per batch; the global batch never leaves the device
+            sh, n = shard_batch(b, rank, world)
+            shards.append(sh)
+            sizes.append(n)
+        return shards, sizes
+
     if calibrate and len(loader) > 0:
-        trainer.calibrate(next(iter(loader)))
-    print(f"Starting training for {num_epochs} epochs...")
+        first = next(iter(loader))
+        trainer.calibrate(first if world == 1 else shard_batch(first, rank, world)[0])
+    if rank == 0:
+        print(f"Starting training for {num_epochs} epochs...")
     for epoch in range(num_epochs):
-        avg = trainer.train_epoch(loader)
-        print(f"Epoch {epoch + 1}/{num_epochs}  avg_train_loss {avg:.6f}")
-        if val_dataset is not None:  # per-epoch validation NDCG@10 (training.py:490)
+        batches, sizes = epoch_batches()
+        avg = trainer.train_epoch(batches, global_batch_sizes=sizes)
+        if rank == 0:
+            print(f"Epoch {epoch + 1}/{num_epochs}  avg_train_loss {avg:.6f}")
+        if val_dataset is not None and rank == 0:  # per-epoch validation NDCG@10 (training.py:490)
             from .evaluation import evaluate_model
 
             val_ndcg = evaluate_model(model, val_dataset, batch_size=batch_size)
             print(f"Validation NDCG@10: {val_ndcg:.4f}")
-    if test_dataset is not None and run_comprehensive_test:  # final comprehensive test (training.py:505-521)
+    if test_dataset is not None and run_comprehensive_test and rank == 0:  # final comprehensive test (training.py:505-521)
         from .evaluation import evaluate_model
 
         evaluate_model(model, test_dataset, sample_size=len(test_dataset), min_query_groups=200, candidate_pool_size=-1,

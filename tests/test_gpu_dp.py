@@ -228,3 +228,45 @@ def test_run_training_two_ranks_equal_one_rank(cache):
 
     # both runs start from rank 0's torch.manual_seed(100) initialisation and see the same triplets
     assert_params_close(res[2], res[1], 1e-2, 2 * 5, tight=5e-5)
+
+
+def _rccl_one_rank_worker(port, q):
+    try:
+        from two_towers_overlords_amd.training import TripletTrainer
+
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        table, params, _, gb = _setup()
+        dev_batches = [tuple(None if t is None else t.cuda() for t in b) for b in gb]
+        out = []
+        for exchange in (False, True):
+            tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B,
+                                max_seq_len=S, margin=0.3, lr=1e-3, exchange=exchange)
+            assert (tr.bucket is not None) == exchange
+            losses = [tr.train_epoch(dev_batches) for _ in range(3)]
+            out.append((losses, tr.flat.cpu().numpy().copy()))
+        q.put(("ok", out, None))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put(("error", f"{e}\\n{traceback.format_exc()}", None))
+        raise
+
+
+def test_data_parallel_step_over_rccl_single_rank_is_the_single_replica_step():
+    """The data-parallel step's own code path (slab reduce -> flat bucket -> RCCL all-reduce issued on the caller's
+    stream, the next gather enqueued right before it -> Adam from the bucket) on a ONE-rank NCCL(RCCL) group, where the
+    exchange is an identity: bitwise the single-replica step.  Exercises the real RCCL backend and its stream ordering
+    against the engine's raw-stream launches (the multi-rank arithmetic is covered over gloo above)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(29900 + os.getpid() % 1000, q))
+    p.start()
+    out = q.get()
+    p.join(180)
+    assert out[0] == "ok", out[1]
+    (l0, f0), (l1, f1) = out[1]
+    assert l0 == l1
+    assert np.array_equal(f0, f1)

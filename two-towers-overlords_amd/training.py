@@ -196,7 +196,7 @@ class TripletTrainer:
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
                  process_group=None, engine=None, overlap_streams: Optional[bool] = None,
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
-                 freeze_gc: bool = True):
+                 freeze_gc: bool = True, exchange: Optional[bool] = None):
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -244,7 +244,9 @@ class TripletTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
-        self._exchange = self.world > 1        # gradients are exchanged between replicas (see _all_reduce)
+        # gradients are exchanged between replicas (see _all_reduce); `exchange=True` forces the data-parallel step's
+        # code path on a single-rank group too (tests: the exchange is then an identity)
+        self._exchange = (self.world > 1) if exchange is None else bool(exchange)
         self._gather_under_exchange = os.environ.get("TT_GATHER_UNDER_EXCHANGE", "1") != "0"  # A/B knob
         self.bucket = torch.empty_like(self.flat) if (self._exchange or self.accumulation_steps > 1) else None
         self.step_count = 0        # optimizer steps taken

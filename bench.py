@@ -344,6 +344,8 @@ def main():
         del a
     if not args.no_calibrate and not args.k1_only and args.loss == "triplet":
         trainer.calibrate(batches[0])   # set-up: part of what run_training does before its first epoch
+    trainer.k1_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                             for _ in range(args.steps // max(trainer.k1_event_every, 1) + 8)]
     if args.e2e:
         elapsed, e2e_info = run_e2e(args, trainer, cfg, device, rank, world, barrier)
         host_issue = elapsed

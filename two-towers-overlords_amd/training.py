@@ -266,6 +266,7 @@ class TripletTrainer:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
         self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
         self.k1_event_every = 4               # ... of every 4th launch
+        self.k1_event_pool = []               # optional pre-created (start, end) pairs for those
         self._k1_count = 0
         self.feature_cache = None             # [N_texts, D] pooled-normalised vectors (build_feature_cache)
         self.token_store = None               # (ids [N_texts, S], lens [N_texts] | None) behind TripletBatch.token_rows
@@ -345,7 +346,8 @@ class TripletTrainer:
             timed = self._k1_count % self.k1_event_every == 0  # events cost ~5 us of stream time each
         raw = None if stream is None else stream.cuda_stream
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pool = self.k1_event_pool  # events created ahead of time (bench): no hipEventCreate inside a timed region
+            e0, e1 = pool.pop() if pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             e0.record(stream)
         if hasattr(self.engine, "set_sharing"):  # a row copy from the cache does not compete with phase B
             self.engine.set_sharing(batch.cache_rows is None and self.side is not None)

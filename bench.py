@@ -346,6 +346,9 @@ def main():
         trainer.calibrate(batches[0])   # set-up: part of what run_training does before its first epoch
     trainer.k1_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                              for _ in range(args.steps // max(trainer.k1_event_every, 1) + 8)]
+    for e0, e1 in trainer.k1_event_pool:  # torch creates the HIP event at its first record(): do that now
+        e0.record()
+        e1.record()
     if args.e2e:
         elapsed, e2e_info = run_e2e(args, trainer, cfg, device, rank, world, barrier)
         host_issue = elapsed

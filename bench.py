@@ -170,11 +170,12 @@ def main():
                          "output is, backend/model.py:48); reported under its own metric name")
     ap.add_argument("--simulate-allreduce-us", type=float, default=None,
                     help="one GPU only, diagnostic: run the data-parallel step (bucket reduce, exchange, Adam from the "
-                         "bucket) with the all-reduce replaced by a kernel of this duration on its own stream — how much of "
-                         "an N-GPU all-reduce's latency the step would expose (RCCL's own CU use is not modelled)")
+                         "bucket) with the all-reduce replaced by a kernel of this duration on the caller's stream (where a "
+                         "synchronous-op RCCL collective runs) — how much of an N-GPU all-reduce's latency the step would "
+                         "expose (RCCL's own CU use is not modelled)")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="skip TripletTrainer.calibrate() in set-up (it times the two backward schedules on this device "
-                         "and keeps the faster; its ~130 dry steps also bring the GPU out of its idle power state)")
+                         "and keeps the faster; its ~190 dry steps also bring the GPU out of its idle power state)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the multi-process "
                          "path with several ranks sharing one GPU)")

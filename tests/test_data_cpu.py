@@ -182,3 +182,31 @@ def test_device_sampler_loader_needs_no_per_batch_shapes_and_keeps_triplet_struc
 
     with pytest.raises(RuntimeError):
         list(TokenTripletLoader(_One(), _tok, batch_size=4, device="cpu", seed=1, sampler="device"))
+
+
+def test_loader_shards_are_the_columns_of_the_global_batches():
+    """shard=(rank, world): every rank sees the same global batches (same seed) and gets its contiguous columns of
+    each, negatives as a third row; the ragged tail batch may leave a rank with nothing."""
+    import pytest
+
+    from two_towers_overlords_amd.training import shard_sizes
+
+    ds = _DS(26, 7)  # batches of 8, 8, 8, 2
+    for sampler in ("device", "reference"):
+        for emit in ("rows2", "cache"):
+            glob = list(TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit=emit, sampler=sampler))
+            parts = [list(TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit=emit, sampler=sampler,
+                                             shard=(r, 3))) for r in range(3)]
+            sizes = TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit=emit, sampler=sampler,
+                                       shard=(0, 3)).global_batch_sizes()
+            assert sizes == [8, 8, 8, 2]
+            for bi, g in enumerate(glob):
+                full = g.expand_negatives()
+                rows = full.cache_rows if emit == "cache" else full.token_rows
+                got = [p[bi].cache_rows if emit == "cache" else p[bi].token_rows for p in parts]
+                assert all(x.shape[0] == 3 and p[bi].neg_index is None for x, p in zip(got, parts))
+                assert [x.shape[1] for x in got] == shard_sizes(sizes[bi], 3)[0]
+                assert torch.equal(torch.cat(got, dim=1), rows)
+    assert parts[2][3].size == 0  # 2 items over 3 ranks
+    with pytest.raises(ValueError):
+        TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit="ids3", shard=(0, 2))

@@ -182,7 +182,7 @@ class TokenTripletLoader:
     def __init__(self, dataset, tokenizer: Optional[Callable], batch_size: int, device, max_length: int = 512,
                  seed: Optional[int] = None, shuffle: bool = True, emit: str = "ids3", sampler: str = "reference",
                  packed: Optional[Tuple["PackedTokens", "PackedTokens", Sequence[int]]] = None,
-                 pad: Optional[str] = None):
+                 pad: Optional[str] = None, shard: Optional[Tuple[int, int]] = None):
         """sampler: "reference" — `sample_negative_indices`, the reference's draws under the same seed
                     (O(B^2) Python per batch, like backend/data.py:132-137); "device" — the same
                     distribution drawn with tensor ops (`sample_negative_indices_device`), no host
@@ -199,6 +199,10 @@ class TokenTripletLoader:
                  "rows2" -> TripletBatch(token_rows [2,B], neg_index)      the same with negatives by index
                  With sampler="device" the rows / cache forms cost the host nothing per batch but a tensor
                  view: the whole epoch's shuffle, negative draws and row triples are a dozen device ops.
+        shard: (rank, world) — data parallel: every rank builds the SAME global batches (same seed) and this
+                    loader yields only rank's contiguous shard of each (`training.shard_sizes`); row emits
+                    ("cache", "rows3", "rows2") only, negatives always as a third row (an in-batch index does
+                    not survive the cut).  `global_batch_sizes()` gives the sizes `train_epoch` wants beside it.
         pad: "batch" — S = the longest row of the batch, what `padding=True` gives each call of
                     backend/model.py:43-45 (costs one device->host read per batch); "max" — S = the
                     longest row of the collection (no read-back; K1 never fetches past a row's length,
@@ -210,6 +214,9 @@ class TokenTripletLoader:
             raise ValueError("sampler must be 'reference' or 'device'")
         if pad not in (None, "batch", "max"):
             raise ValueError("pad must be 'batch' or 'max'")
+        if shard is not None and emit not in ("cache", "rows3", "rows2"):
+            raise ValueError("shard= needs a row emit ('cache', 'rows3' or 'rows2')")
+        self.shard = None if shard is None or shard[1] <= 1 else (int(shard[0]), int(shard[1]))
         self.emit = emit
         self.sampler = sampler
         self.pad = pad or ("max" if sampler == "device" else "batch")
@@ -249,6 +256,12 @@ class TokenTripletLoader:
 
     def __len__(self) -> int:
         return (len(self.query_ids) + self.batch_size - 1) // self.batch_size
+
+    def global_batch_sizes(self):
+        """Sizes of the epoch's (global) batches, in order — what `TripletTrainer.train_epoch(...,
+        global_batch_sizes=)` needs when this loader yields per-rank shards."""
+        n, B = len(self.query_ids), self.batch_size
+        return [B] * (n // B) + ([n % B] if n % B else [])
 
     def save_packed(self, prefix: str) -> None:
         """Write `<prefix>.q.*`, `<prefix>.p.*` (PackedTokens) and `<prefix>.query_ids.bin` (int64)."""
@@ -331,17 +344,28 @@ class TokenTripletLoader:
             if by_rows and n_full:  # the whole epoch's row triples at once: [n_full, roles, B] int32
                 it_all = order_t[: n_full * B].view(n_full, B)
                 parts = [it_all, it_all + n]
-                if self.emit == "rows3":
+                if self.emit == "rows3" or self.shard is not None:
                     parts.append(it_all.gather(1, neg_full) + n)
-                rows_full = torch.stack(parts, dim=1).to(torch.int32).contiguous()
+                rows_full = torch.stack(parts, dim=1).to(torch.int32)
                 neg_full32 = neg_full.to(torch.int32)
+                if self.shard is not None:  # this rank's columns of every full batch, cut once per epoch
+                    from .training import shard_sizes
+
+                    sizes, offs = shard_sizes(B, self.shard[1])
+                    lo = offs[self.shard[0]]
+                    rows_full = rows_full[:, :, lo: lo + sizes[self.shard[0]]]
+                rows_full = rows_full.contiguous()
         if by_rows:
-            from .training import TripletBatch
+            from .training import TripletBatch, shard_sizes
+
+            three = self.emit == "rows3" or self.shard is not None
 
             def as_batch(rows, ni):
+                if three:
+                    ni = None
                 if self.emit == "cache":
                     return TripletBatch(cache_rows=rows, neg_index=ni)
-                return TripletBatch(token_rows=rows) if self.emit == "rows3" else TripletBatch(token_rows=rows, neg_index=ni)
+                return TripletBatch(token_rows=rows, neg_index=ni)
         for bi, s in enumerate(range(0, n, B)):
             if rows_full is not None and bi < n_full:  # per batch: two tensor views, nothing else
                 yield as_batch(rows_full[bi], neg_full32[bi])
@@ -354,8 +378,13 @@ class TokenTripletLoader:
                 neg_t = torch.tensor(sample_negative_indices([self.query_ids[i] for i in order[s: s + B]], self.rng),
                                      device=self.device)
             if by_rows:
-                parts = [it, it + n] + ([it[neg_t] + n] if self.emit == "rows3" else [])
-                yield as_batch(torch.stack(parts).to(torch.int32).contiguous(), neg_t.to(torch.int32))
+                parts = [it, it + n] + ([it[neg_t] + n] if three else [])
+                rows = torch.stack(parts).to(torch.int32)
+                if self.shard is not None:
+                    sizes, offs = shard_sizes(nb, self.shard[1])
+                    lo = offs[self.shard[0]]
+                    rows = rows[:, lo: lo + sizes[self.shard[0]]]
+                yield as_batch(rows.contiguous(), neg_t.to(torch.int32))
                 continue
             roles = 3 if self.emit == "ids3" else 2
             ql, pl = self.q_lens[it], self.p_lens[it]

@@ -880,7 +880,7 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
     if max_samples and max_samples > 0 and len(train_dataset) > max_samples:
         train_dataset = torch.utils.data.Subset(train_dataset, range(max_samples))
     loader = TokenTripletLoader(train_dataset, model.query_tower.tokenizer, batch_size, device, seed=seed,
-                                sampler=sampler)
+                                sampler=sampler, emit="rows3", shard=(rank, world))
     max_S = int(max(loader.q_ids.shape[1], loader.p_ids.shape[1]))
     trainer = TripletTrainer(model, max_batch=batch_size, max_seq_len=max_S, margin=margin, lr=learning_rate,
                              accumulation_steps=accumulation_steps)
@@ -899,24 +899,13 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
         # a third time (three_encodes=True: the reference's three encodes, training.py:40-42)
         loader.emit = "rows3" if three_encodes else "rows2"
         trainer.set_token_store(*loader.all_texts())
-    def epoch_batches():
-        if world == 1:
-            return loader, None
-        shards, sizes = [], []
-        for b in loader:  # views and tiny index ops per batch; the global batch never leaves the device
-            sh, n = shard_batch(b, rank, world)
-            shards.append(sh)
-            sizes.append(n)
-        return shards, sizes
-
+    sizes = loader.global_batch_sizes() if world > 1 else None  # the loader yields this rank's shard of every batch
     if calibrate and len(loader) > 0:
-        first = next(iter(loader))
-        trainer.calibrate(first if world == 1 else shard_batch(first, rank, world)[0])
+        trainer.calibrate(next(iter(loader)))
     if rank == 0:
         print(f"Starting training for {num_epochs} epochs...")
     for epoch in range(num_epochs):
-        batches, sizes = epoch_batches()
-        avg = trainer.train_epoch(batches, global_batch_sizes=sizes)
+        avg = trainer.train_epoch(loader, global_batch_sizes=sizes)
         if rank == 0:
             print(f"Epoch {epoch + 1}/{num_epochs}  avg_train_loss {avg:.6f}")
         if val_dataset is not None and rank == 0:  # per-epoch validation NDCG@10 (training.py:490)

@@ -253,6 +253,10 @@ class TripletTrainer:
         self._micro = 0            # batches since the last optimizer step (carried across epochs, like the reference)
         if self.world > 1:
             self.sync_replicas()   # replicas start from rank 0's weights (what DDP's constructor broadcast does)
+            # one all-reduce of the step's exact shape now, so that whatever the backend sets up lazily at the first use
+            # of a collective / message size (connections, buffers, algorithm choice) is not paid by the first step
+            self.bucket.zero_()
+            self._all_reduce(self.bucket)
         self.side = torch.cuda.Stream(self.device) if (overlap_streams and self.device.type == "cuda") else None
         # gathered, not yet applied: (slot, ready event, local B, neg_index, query_ids)
         self._pending = collections.deque()

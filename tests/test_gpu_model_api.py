@@ -480,3 +480,32 @@ def test_bert_mode_trains_on_the_frozen_feature_cache_like_the_module_path():
     steps = 2 * ((N + B - 1) // B)
     for pa, pb in zip(ma.trainable_parameters(), mb.trainable_parameters()):
         assert_params_close(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), 1e-3, steps, tight=2e-6)
+
+
+def test_trainer_checkpoint_resumes_bitwise_on_the_device():
+    """state_dict() after one epoch -> a fresh trainer (different initial weights) -> load_state_dict() -> second epoch:
+    bit for bit the uninterrupted two-epoch run (flat parameters aliasing the modules, Adam moments, step counter)."""
+    from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
+
+    V, D, P, B, S = 3000, 128, 32, 64, 24
+    table = orc.synthetic_table(V, D, seed=1) * 30
+    batches = [orc.synthetic_batch(B, S, V, seed=600 + i, ragged=True) for i in range(5)]
+    dev = [TripletBatch(ids=torch.stack([r[0] for r in b]).int().cuda(), lens=torch.stack([r[1].sum(1) for r in b]).int().cuda())
+           for b in batches]
+
+    def trainer(seed):
+        p = orc.init_params(D, P, seed=seed)
+        return TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in p.items()}, max_batch=B, max_seq_len=S,
+                              margin=0.3, lr=1e-3)
+
+    a = trainer(2)
+    la = [a.train_epoch(dev), a.train_epoch(dev)]
+    b = trainer(2)
+    lb = [b.train_epoch(dev)]
+    sd = b.state_dict()
+    assert all(t.device.type == "cpu" for t in (sd["flat"], sd["exp_avg"], sd["exp_avg_sq"]))
+    c = trainer(77)
+    c.load_state_dict(sd)
+    lb.append(c.train_epoch(dev))
+    assert la == lb and c.step_count == a.step_count == 10
+    assert torch.equal(a.flat, c.flat) and torch.equal(a.exp_avg, c.exp_avg) and torch.equal(a.exp_avg_sq, c.exp_avg_sq)

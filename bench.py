@@ -22,12 +22,23 @@ were produced by warm-up; the last steps' gathers are consumed by the drain).
 and drain included.
 
 Extra objects: `roofline` (K1 gather+pool kernel, HBM bound, live HIP-event
-timing) and `cpu_baseline` (the CPU oracle — a torch-CPU restatement of the
-reference loop — on a bounded sample of the same workload, rank 0 at N=1 only).
+timing), `cpu_baseline` (the CPU oracle — a torch-CPU restatement of the
+reference loop — on a bounded sample of the same workload, `embed` mode),
+`cpu_baseline_bert` (the same loop with the frozen MiniLM-L6-shaped encoder the
+reference actually executes, backend/model.py:51-52) and `secondary` (the same
+measurement at BASELINE.json configs[3], the one configuration whose table
+streams from HBM) — the last three on rank 0 at N=1 only.
+
+`--gpus N` with N > 1 from a plain shell starts itself under
+`python -m torch.distributed.run` (one rank per GPU) as a child process, before
+anything in this process has touched the GPU, and exits with the child's code.
 """
 import argparse
+import copy
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -94,6 +105,47 @@ def cpu_baseline(cfg, budget_s=20.0):
     return {
         "value": n * B / el, "unit": "triplets/s", "cores": cores, "kind": "port",
         "sample": f"{n} batches of {B} triplets (S={S}, D={D}, P={P}, V={V}, embed mode, fp32) in {el:.1f} s, "
+                  f"oracle/two_towers_oracle.train_epoch, torch {torch.__version__} CPU, {cores} threads",
+    }
+
+
+def cpu_baseline_bert(cfg, budget_s=10.0):
+    """The reference's EXECUTED CPU path (backend/model.py:51-52: the frozen 6-layer MiniLM between gather and pool,
+    SURVEY.md F2/F3) on the same host threads: oracle train_epoch with a random-weight MiniLM-L6-shaped
+    `transformers.BertModel` per tower (weights are not in the image; the arithmetic and its cost do not depend on
+    their values), eval mode like the reference's CPU loop.  Bounded to about `budget_s` seconds."""
+    from oracle import two_towers_oracle as orc
+
+    try:
+        from transformers import BertConfig, BertModel
+    except Exception as e:  # transformers missing on the box: say so instead of inventing a number
+        return {"value": None, "unit": "triplets/s", "kind": "port", "sample": f"not measured: {type(e).__name__}: {e}"}
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
+    V, D, P, S = cfg["V"], cfg["D"], cfg["P"], cfg["S"]
+    B = 64
+    bc = BertConfig(vocab_size=V, hidden_size=D, num_hidden_layers=6, num_attention_heads=12, intermediate_size=4 * D,
+                    max_position_embeddings=512)
+    torch.manual_seed(3)
+    enc_q, enc_d = BertModel(bc).eval(), BertModel(bc).eval()  # one frozen model PER tower (backend/model.py:84-85)
+    params = orc.init_params(D, P, seed=2)
+    st = orc.AdamState(lr=1e-3)
+    batch = orc.synthetic_batch(B, S, V, seed=1234)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.train_epoch(enc_q, [batch], params, st, 0.3, doc_table=enc_d)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 16:
+            break
+    return {
+        "value": n * B / el, "unit": "triplets/s", "cores": cores, "kind": "port",
+        "sample": f"{n} batches of {B} triplets (S={S}, D={D}, P={P}, V={V}, bert mode: random-weight 6-layer/12-head/"
+                  f"{4 * D}-ffn BertModel per tower under no_grad, eval mode, fp32) in {el:.1f} s, first batch included, "
                   f"oracle/two_towers_oracle.train_epoch, torch {torch.__version__} CPU, {cores} threads",
     }
 
@@ -179,14 +231,19 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the multi-process "
                          "path with several ranks sharing one GPU)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` object (the same measurement at configs[3], V=250k d=768 S=256 B=16384: "
+                         "the one configuration whose table streams from HBM; ~10 s extra on the default run)")
+    ap.add_argument("--no-cpu-baseline-bert", action="store_true",
+                    help="skip `cpu_baseline_bert` (the reference's executed CPU path: frozen MiniLM-shaped encoder, ~10 s)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # nothing above has touched the GPU (device_count() does not initialise it)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP library is the only implementation of the hot path")
@@ -202,6 +259,62 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    result = run_config(args, world, rank, device)
+    default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
+                    and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
+                    and not args.zipf and not args.ragged)
+    if rank == 0 and world == 1 and default_line:
+        if not args.no_secondary:
+            result["secondary"] = secondary_c4(args, world, rank, device)
+        if not args.no_cpu_baseline and not args.no_cpu_baseline_bert:
+            result["cpu_baseline_bert"] = cpu_baseline_bert(CONFIGS[args.config])
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def self_launch(args) -> int:
+    """`bench.py --gpus N` (N > 1) from a plain shell: one rank per GPU under torch.distributed.run, started as a
+    CHILD process (a process that has initialised the GPU must never exec another program on this pool); the rank-0
+    JSON line arrives on the inherited stdout.  Returns the child's exit code."""
+    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if args.backend == "nccl" and args.gpus > ndev:
+        print(f"bench.py --gpus {args.gpus}: this node shows {ndev} GPU(s); RCCL needs one GPU per rank "
+              "(--backend gloo rehearses the multi-process flow with ranks sharing a GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool's host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def secondary_c4(args, world, rank, device) -> dict:
+    """BASELINE.json configs[3] (V=250k, d=768, proj 768, S=256, B=16384: a 768 MB table, three times the Infinity
+    Cache — the configuration where K1 really streams from HBM), measured in this same run with the same code path:
+    step rate, K1 in the loop and K1 alone.  `traffic` is null: PMC counters are not collected in a timed run."""
+    a = copy.copy(args)
+    a.config, a.steps, a.warmup, a.no_cpu_baseline = "c4", 12, 3, True
+    a.n_distinct, a.calibrate_steps, a.calibrate_rounds, a.iso_launches = 2, 8, 1, 8
+    torch.cuda.empty_cache()
+    r = run_config(a, world, rank, device)
+    torch.cuda.empty_cache()
+    keep = ("metric", "value", "unit", "steps", "warmup", "effective_warmup_steps", "ms_per_step", "dtype", "config",
+            "roofline", "calibration")
+    out = {k: r[k] for k in keep}
+    out["roofline_hbm_triplets_per_s"] = HBM_PEAK_GBS * 1e9 / (3 * (CONFIGS["c4"]["S"] * CONFIGS["c4"]["D"] * 4
+                                                                   + CONFIGS["c4"]["S"] * 4 + CONFIGS["c4"]["D"] * 4))
+    return out
+
+
+def run_config(args, world, rank, device) -> dict:
+    """Set-up, warm-up, K timed steady-state steps and the result object for one configuration."""
+    n_distinct = getattr(args, "n_distinct", 8)
     import two_towers_overlords_amd as pkg
     from two_towers_overlords_amd.training import TripletTrainer
 
@@ -240,7 +353,6 @@ def main():
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1
-    n_distinct = 8
     id_batches = make_ids(V, B, S, n_distinct, seed=1234 + rank, device=device, zipf=args.zipf)
     batches = [(ids, None, None) for ids in id_batches]  # full-length: no mask, no lens
     valid_tokens = 3 * B * S
@@ -344,12 +456,16 @@ def main():
             torch.cuda.synchronize(device)
         del a
     if not args.no_calibrate and not args.k1_only and args.loss == "triplet":
-        trainer.calibrate(batches[0])   # set-up: part of what run_training does before its first epoch
+        trainer.calibrate(batches[0], steps=getattr(args, "calibrate_steps", 48),
+                          rounds=getattr(args, "calibrate_rounds", 2))   # set-up: part of what run_training does before its first epoch
     trainer.k1_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                              for _ in range(args.steps // max(trainer.k1_event_every, 1) + 8)]
     for e0, e1 in trainer.k1_event_pool:  # torch creates the HIP event at its first record(): do that now
         e0.record()
         e1.record()
+    set_up_steps = 0  # steps of this workload executed before the timed region besides --warmup
+    if trainer.calibration:
+        set_up_steps += 2 * trainer.calibration["rounds"] * (trainer.calibration["steps"] + depth)  # dry fwd+bwd (no optimizer)
     if args.e2e:
         elapsed, e2e_info = run_e2e(args, trainer, cfg, device, rank, world, barrier)
         host_issue = elapsed
@@ -359,6 +475,7 @@ def main():
         if not args.no_calibrate:  # set-up, like calibrate(): run the event-timed code path once before anything is timed
             run(4, timed=True)
             k1_ev.clear()
+            set_up_steps += 4
         run(args.warmup, timed=False)
         barrier()
         if os.environ.get("TT_IDLE_MS"):  # experiment: idle gap between warm-up and the timed region
@@ -377,25 +494,28 @@ def main():
 
     # K1 alone (nothing else on the chip), same engine / residency cap, after the timed region
     iso_ev = []
-    for i in range(20):
+    n_iso = getattr(args, "iso_launches", 20)
+    for i in range(n_iso):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         bb = batches[i % n_distinct] if (args.ragged and args.inputs == "ids3") else (id_batches[i % n_distinct], None, None)
         e0.record(); trainer.engine.pool(i & 1, bb[0], None, bb[2]); e1.record()
         iso_ev.append((e0, e1))
     torch.cuda.synchronize(device)
-    iso_ms = sum(a.elapsed_time(b) for a, b in iso_ev[4:]) / len(iso_ev[4:])
+    iso_ms = sum(a.elapsed_time(b) for a, b in iso_ev[n_iso // 5:]) / len(iso_ev[n_iso // 5:])
     k1_ms = sum(a.elapsed_time(b) for a, b in k1_ev) / max(len(k1_ev), 1)
     roles = 3 if args.inputs == "ids3" else 2
     alg = k1_algorithmic_bytes(roles * B, S, D)
     if args.ragged and args.inputs == "ids3":  # n_valid*D*4 + S*4 + D*4 per text with the actual lengths
         alg = int(valid_tokens * D * 4 + roles * B * (S * 4 + D * 4))
-    traffic = None  # HBM-side bytes per K1 launch from the committed PMC passes of this same workload, if any
+    traffic = traffic_source = None  # fabric-side bytes per K1 launch: from the committed PMC passes of this same workload, if any
     import glob
     tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_k1_traffic_{args.config}.json")))
     if tpaths and not args.zipf:  # the newest round's PMC passes
         tj = json.load(open(tpaths[-1]))
         if int(tj.get("algorithmic_bytes_per_launch", -1)) == alg and args.inputs == "ids3":
             traffic = tj["traffic_bytes_per_launch"]
+            traffic_source = (os.path.relpath(tpaths[-1], ROOT) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "workload (`bench.py --k1-only`), committed; PMC counters are not collected in a timed run")
     achieved = alg / (k1_ms * 1e-3) / 1e9
     from two_towers_overlords_amd import _lib as _ttlib
     sliced = bool(_ttlib.load().tt_k1_prefers_sliced(V, D, roles * B, S))
@@ -418,12 +538,15 @@ def main():
         "value": args.steps * B * world / elapsed,
         "unit": "triplets/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "effective_warmup_steps": args.warmup + set_up_steps,  # + calibrate()'s dry fwd+bwd steps + the 4 event-timed set-up steps
         "ms_per_step": elapsed / args.steps * 1e3,
         "host_issue_ms_per_step": host_issue / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["label"], "encoder_mode": "embed", "vocab": V, "embed_dim": D, "proj_dim": P,
-                   "seq_len": S, "batch_per_gpu": B, "global_batch": B * world, "ids": "int32 [3,B,S], "
+                   "seq_len": S, "batch_per_gpu": B, "global_batch": B * world,
+                   "rccl_ranks": (dist.get_world_size() if (world > 1 and args.backend == "nccl") else (1 if world == 1 else 0)),
+                   "backend": (args.backend if world > 1 else None), "ids": "int32 [3,B,S], "
                    + ("zipf" if args.zipf else "uniform") + (", ragged lengths" if args.ragged else ", full length"), "parallelism": f"dp{world}", "inputs": args.inputs,
                    "k1_only": bool(args.k1_only),
                    "gather_overlap": ("side stream, " + ("K1's LDS reservation paired with the projection tile (auto)"
@@ -435,8 +558,12 @@ def main():
                    "launch": "hipGraph replay (1 step per graph; every 8th step eager for K1 event timing)"
                    if trainer.use_graphs else "eager (kernel by kernel)"},
         "roofline": {"kernel": k1_label, "bound": "hbm",
+                     "bound_note": ("nominal: the 8 TB/s HBM figure the metric names; this table (%.0f MB) is cache-resident, "
+                                    "so the bound that binds is the L2 / Infinity-Cache hierarchy — see `secondary` for the "
+                                    "configuration that streams from HBM" % (V * D * 4 / 1e6)) if V * D * 4 <= 200e6 else
+                                   "binding: the table (%.0f MB) exceeds the 256 MiB Infinity Cache" % (V * D * 4 / 1e6),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
                      "launches_timed": len(k1_ev),
                      "note": "timed inside the step loop; with gather_overlap the launch shares the chip with the "
                              "projection kernels of the previous batch, so its duration is longer than alone.  "
@@ -461,10 +588,8 @@ def main():
         print("TRACE host ms per 10 steps:", hgaps, file=sys.stderr)
         print("TRACE K1 in-loop ms (every %d-th launch):" % trainer.k1_event_every,
               [round(a.elapsed_time(b), 3) for a, b in k1_ev], file=sys.stderr)
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    trainer.engine.close()  # the workspace goes back to the allocator before a `secondary` configuration is set up
+    return result
 
 
 if __name__ == "__main__":

@@ -41,9 +41,14 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------- #
 
 
-def embed_lookup(table: torch.Tensor, input_ids: torch.Tensor) -> torch.Tensor:
-    """`embed` encoder mode of backend/model.py:51-52 — the pretrained model
-    reduced to its word-embedding table: out[b,s,:] = table[input_ids[b,s],:]."""
+def embed_lookup(table, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """backend/model.py:51-52, `output = self.pretrained_model(**tokens)`, `output[0]`.
+    `embed` encoder mode (a tensor `table`): the pretrained model reduced to its word-embedding
+    table, out[b,s,:] = table[input_ids[b,s],:].  `bert` mode (`table` is the frozen encoder
+    module itself, e.g. a transformers BertModel): what the reference executes — the module is
+    called with the tokenizer's outputs and its first output (last_hidden_state) is pooled."""
+    if isinstance(table, torch.nn.Module):
+        return table(input_ids=input_ids, attention_mask=attention_mask)[0]
     return F.embedding(input_ids, table)
 
 
@@ -93,7 +98,7 @@ def tower_forward(
 ) -> torch.Tensor:
     """backend/model.py:40-60 (`AveragePoolingTower.forward`) from token ids on."""
     with torch.no_grad():  # model.py:51 — the encoder is frozen and runs under no_grad
-        token_embeddings = embed_lookup(table, input_ids)
+        token_embeddings = embed_lookup(table, input_ids, attention_mask)
     pooled = pool_normalize(token_embeddings, attention_mask)
     return projection(pooled, w1, b1, w2, b2)
 
@@ -305,18 +310,20 @@ def train_epoch_accum(
 # --------------------------------------------------------------------------- #
 
 
-def create_triplet_indices(query_ids: Sequence[int], rng: random.Random) -> List[int]:
+def create_triplet_indices(query_ids: Sequence[int], rng: random.Random,
+                           positive_nonempty: Optional[Sequence[bool]] = None) -> List[int]:
     """backend/data.py:113-137 (`create_triplets` + `_get_random_negative`) on
     indices: for item i draw j uniformly from the other in-batch items
     (`rng.choice([j for j != i])`, same call sequence as the reference so a
-    shared seed gives the same draws), reject while query_id equal; the negative
-    *text* is item j's positive.  Returns neg_idx[i] = j."""
+    shared seed gives the same draws), reject while query_id equal OR item j's
+    positive text is empty (data.py:126 `if negative and ...`: an empty string is
+    falsy); the negative *text* is item j's positive.  Returns neg_idx[i] = j."""
     n = len(query_ids)
     out = []
     for i in range(n):
         while True:
             j = rng.choice([k for k in range(n) if k != i])
-            if query_ids[j] != query_ids[i]:
+            if (positive_nonempty is None or positive_nonempty[j]) and query_ids[j] != query_ids[i]:
                 out.append(j)
                 break
     return out

@@ -291,22 +291,29 @@ def g_bert_mode():
 
 def g_triplets():
     """`TripletDataLoader.create_triplets` (data.py:113-137) on fake items with
-    seeded `random`: expected negative index per item for several seeds."""
+    seeded `random`: expected negative index per item for several seeds.  Cases 4-5
+    hold items whose passage is the empty string: data.py:126 (`if negative and ...`)
+    never takes such a passage as a negative."""
     dl = ref_data.TripletDataLoader.__new__(ref_data.TripletDataLoader)
     out = {}
-    for case, (n_items, n_q, seed) in enumerate(((8, 3, 0), (32, 5, 1), (64, 40, 2), (5, 2, 3))):
+    cases = ((8, 3, 0, 0), (32, 5, 1, 0), (64, 40, 2, 0), (5, 2, 3, 0), (24, 6, 4, 5), (9, 3, 5, 3))
+    for case, (n_items, n_q, seed, n_empty) in enumerate(cases):
         rq = random.Random(1000 + case)
         qids = [rq.randrange(n_q) for _ in range(n_items)]
         if len(set(qids)) == 1:
             qids[0] = (qids[0] + 1) % n_q
-        batch = [{"query": f"q{qids[i]}", "positive": f"doc{i}", "query_id": qids[i]} for i in range(n_items)]
+        empty = set(rq.sample(range(n_items), n_empty))
+        docs = ["" if i in empty else f"doc{i}" for i in range(n_items)]
+        batch = [{"query": f"q{qids[i]}", "positive": docs[i], "query_id": qids[i]} for i in range(n_items)]
         random.seed(seed)
         queries, positives, negatives = dl.create_triplets(batch)
+        assert all(negatives), "the reference never returns an empty negative"
         neg_idx = [int(s[3:]) for s in negatives]
-        assert positives == [f"doc{i}" for i in range(n_items)]
+        assert positives == docs
         out[f"case{case}/query_ids"] = np.array(qids, dtype=np.int64)
         out[f"case{case}/seed"] = np.int64(seed)
         out[f"case{case}/neg_idx"] = np.array(neg_idx, dtype=np.int64)
+        out[f"case{case}/positive_nonempty"] = np.array([bool(d) for d in docs])
     np.savez_compressed(os.path.join(HERE, "triplets.npz"), **out)
     print("triplets.npz written")
 
@@ -392,6 +399,9 @@ def g_eval():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["triplets"]:  # regenerate only the sampling fixture
+        g_triplets()
+        sys.exit(0)
     r = g_kat0()
     g_step_mid()
     g_step_minilm_shape()

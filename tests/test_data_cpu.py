@@ -9,10 +9,14 @@ from two_towers_overlords_amd.data import TokenTripletLoader, TripletDataLoader,
 
 def test_negative_sampling_matches_reference_draws():
     g = load_golden("triplets.npz")
-    for case in range(4):
+    for case in range(6):  # cases 4-5: some passages are empty strings (backend/data.py:126 never draws those)
         qids = g[f"case{case}/query_ids"].tolist()
         random.seed(int(g[f"case{case}/seed"]))
-        assert sample_negative_indices(qids) == g[f"case{case}/neg_idx"].tolist()
+        ok = g[f"case{case}/positive_nonempty"].tolist()
+        assert sample_negative_indices(qids, positive_nonempty=ok) == g[f"case{case}/neg_idx"].tolist()
+        if all(ok):
+            random.seed(int(g[f"case{case}/seed"]))
+            assert sample_negative_indices(qids) == g[f"case{case}/neg_idx"].tolist()
 
 
 class _DS(torch.utils.data.Dataset):
@@ -210,3 +214,54 @@ def test_loader_shards_are_the_columns_of_the_global_batches():
     assert parts[2][3].size == 0  # 2 items over 3 ranks
     with pytest.raises(ValueError):
         TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=5, emit="ids3", shard=(0, 2))
+
+
+def test_empty_passages_are_never_negatives():
+    """backend/data.py:126 (`if negative and ...`): an item whose passage is the empty string is never the negative —
+    string loader, reference sampler and device sampler alike; the device sampler stays uniform over the rest."""
+    from two_towers_overlords_amd.data import sample_negative_indices_device
+
+    ds = _DS(40, 7)
+    empties = {3, 8, 21, 22, 37}
+    for i in empties:
+        ds.items[i]["positive"] = ""
+    dl = TripletDataLoader(ds, batch_size=16, num_workers=0)
+    for q, p, n in dl:
+        assert all(n)
+    for sampler in ("reference", "device"):
+        tl = TokenTripletLoader(ds, lambda t, **k: _tok([x or "pad" for x in t], **k), batch_size=16, device="cpu", seed=3,
+                                sampler=sampler, emit="index")
+        assert tl.p_nonempty is not None and sum(not x for x in tl.p_nonempty) == len(empties)
+        empty_rows = {tuple(tl.p_ids[i].tolist()) for i in empties}
+        for _ in range(3):
+            for b in tl:
+                negs = b.ids[1][b.neg_index.long()]
+                assert not any(tuple(r.tolist()) in empty_rows for r in negs)
+    q = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3])
+    ok = torch.tensor([1, 0, 1, 1, 0, 1, 1, 0]).bool()
+    g = torch.Generator().manual_seed(0)
+    counts = torch.zeros(8, 8)
+    for _ in range(3000):
+        n = sample_negative_indices_device(q, g, positive_nonempty=ok)
+        counts[torch.arange(8), n] += 1
+    for i in range(8):
+        adm = [j for j in range(8) if ok[j] and q[j] != q[i]]
+        assert counts[i].sum() == counts[i, adm].sum()
+        assert (counts[i, adm] / 3000 - 1 / len(adm)).abs().max() < 0.04
+
+
+def test_peek_does_not_advance_the_loaders_random_streams():
+    """run_training calibrates on loader.peek(): epochs after it must be the ones a fresh loader yields."""
+    ds = _DS(37, 6)
+    for sampler, emit in (("reference", "ids3"), ("device", "rows3"), ("device", "index")):
+        a = TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=9, sampler=sampler, emit=emit)
+        b = TokenTripletLoader(ds, _tok, batch_size=8, device="cpu", seed=9, sampler=sampler, emit=emit)
+        first = a.peek()
+        flat = lambda x: [t for t in (x if isinstance(x, tuple) else (x.ids, x.lens, x.neg_index, x.token_rows)) if t is not None]
+        for _ in range(2):
+            ea, eb = list(a), list(b)
+            assert len(ea) == len(eb)
+            for x, y in zip(ea, eb):
+                assert all(torch.equal(u, v) for u, v in zip(flat(x), flat(y)))
+        assert all(torch.equal(u, v) for u, v in zip(flat(first), flat(next(iter(TokenTripletLoader(
+            ds, _tok, batch_size=8, device="cpu", seed=9, sampler=sampler, emit=emit))))))

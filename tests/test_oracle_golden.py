@@ -102,12 +102,26 @@ def test_bert_mode_dense_pool():
     np.testing.assert_allclose(out.numpy(), g["out"], atol=TOL, rtol=0)
 
 
+def test_tower_forward_through_an_encoder_module():
+    """`bert` mode of the oracle (bench.py's cpu_baseline_bert): the frozen encoder module stands where the table
+    does and its first output is pooled (backend/model.py:51-56) — pinned by the reference's own tower output."""
+    g = load_golden("bert_mode.npz")
+
+    class Encoder(torch.nn.Module):
+        def forward(self, input_ids=None, attention_mask=None):
+            assert torch.equal(input_ids, T(g["ids"])) and torch.equal(attention_mask, T(g["mask"]))
+            return (T(g["hidden"]),)
+
+    out = orc.tower_forward(Encoder(), T(g["ids"]), T(g["mask"]), T(g["w1"]), T(g["b1"]), T(g["w2"]), T(g["b2"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], atol=TOL, rtol=0)
+
+
 def test_create_triplets_matches_reference():
     g = load_golden("triplets.npz")
-    for case in range(4):
+    for case in range(6):  # cases 4-5 hold empty passages (data.py:126)
         qids = g[f"case{case}/query_ids"].tolist()
         rng = random.Random(int(g[f"case{case}/seed"]))
-        assert orc.create_triplet_indices(qids, rng) == g[f"case{case}/neg_idx"].tolist()
+        assert orc.create_triplet_indices(qids, rng, g[f"case{case}/positive_nonempty"].tolist()) == g[f"case{case}/neg_idx"].tolist()
 
 
 def test_adam_restatement_equals_torch_adam():

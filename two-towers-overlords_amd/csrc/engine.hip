@@ -74,6 +74,7 @@ struct tt_engine {
   hipEvent_t ev_fork, ev_join;
   bool gathers_share_chip;  // tt_engine_set_sharing: token-id gathers are running beside phase B
   int bwd_mode;             // tt_engine_set_backward: TT_BWD_AUTO / TT_BWD_FORK / TT_BWD_FUSED
+  int env_bwd;              // TT_BWD read once at creation: -1 unset, 0 "fused", 1 "fork" (A/B runs)
 };
 
 namespace {
@@ -173,6 +174,9 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
     e->aux = nullptr;
   }
   e->gathers_share_chip = true;
+  e->env_bwd = -1;
+  if (const char* v = getenv("TT_BWD"))  // "fork" / "fused" force a schedule (A/B runs); anything else: automatic
+    if (v[0] == 'f') e->env_bwd = (v[1] == 'o') ? 1 : 0;
   e->shared = cfg->k1_blocks_per_cu != 0;
   e->tile_above = cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO && e->k1_partial_bytes != 0 &&
                   tt_k1_prefers_sliced(cfg->V, cfg->D, 3 * (int64_t)cfg->max_B, cfg->max_S);
@@ -320,12 +324,10 @@ static int tile_policy(const tt_engine* e) {
 }
 
 static bool use_fork(const tt_engine* e) {
+  if (e->env_bwd >= 0) return e->env_bwd == 1 && e->aux != nullptr;  // TT_BWD forces a schedule, also over calibrate()'s pick
   if (e->bwd_mode == TT_BWD_FORK) return e->aux != nullptr;
   if (e->bwd_mode == TT_BWD_FUSED) return false;
-  bool fork = e->shared && !e->tile_above && e->aux != nullptr && e->gathers_share_chip;
-  if (const char* v = getenv("TT_BWD"))  // "fork" / "fused" force a schedule (A/B runs); anything else: automatic
-    if (v[0] == 'f') fork = e->aux != nullptr && v[1] == 'o';
-  return fork;
+  return e->shared && !e->tile_above && e->aux != nullptr && e->gathers_share_chip;
 }
 
 static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_rows, float loss_denominator,
@@ -488,6 +490,9 @@ extern "C" int tt_engine_read_stats(tt_engine* e, double* loss_sum, int64_t* n_b
     TT_HIP(hipMemsetAsync(e->loss_sum, 0, sizeof(double), st));
     TT_HIP(hipMemsetAsync(e->loss_cnt, 0, sizeof(long long), st));
     TT_HIP(hipMemsetAsync(e->oob, 0, sizeof(int32_t), st));  // the out-of-range flag is reported once
+    // the in-launch loss mean's arrival ticket: zero between launches by construction (the last workgroup
+    // re-zeroes it); cleared here as well so that a launch torn down mid-grid cannot leave it poisoned
+    TT_HIP(hipMemsetAsync(e->mean_ticket, 0, sizeof(unsigned), st));
   }
   TT_HIP(hipStreamSynchronize(st));
   if (loss_sum) *loss_sum = s;

@@ -575,7 +575,10 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   float* partial = ws;
   float* wsum = ws + (size_t)N * kSlices * D;
   // waves (= texts) per gather workgroup: TT_K1_WAVES=4|6|8 (A/B)
-  static const int wpb = getenv("TT_K1_WAVES") ? atoi(getenv("TT_K1_WAVES")) : kWavesPerText;
+  static const int wpb = [] {
+    const int v = getenv("TT_K1_WAVES") ? atoi(getenv("TT_K1_WAVES")) : kWavesPerText;
+    return (v == 4 || v == 6 || v == 8) ? v : kWavesPerText;  // only these are instantiated; anything else: the default
+  }();
   const long long groups_all = (N + wpb - 1) / wpb;
   const long long combine_groups = (N + kWavesPerText - 1) / kWavesPerText;
   // Default: one workgroup per (4 texts, slice), residency steered through dynamic LDS like the per-text
@@ -700,7 +703,7 @@ int tt_k1_sliced_supported(int S, int D, const float* table, const float* out) {
 // second launch (512 texts: equal).  TT_K1_SLICED=0/1 overrides (A/B runs).
 extern "C" int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S) {
   if (D < 4 || (D % 4) != 0 || D > 1024 || S > kSlicedMaxS || S < 1 || V < 1 || N < 1) return 0;
-  if (const char* v = getenv("TT_K1_SLICED"))
+  if (const char* v = getenv("TT_K1_SLICED"))  // (looked up per call: tests and tools/k1_sliced_ab.py flip it in-process)
     if (*v) return *v != '0';
   const double table_bytes = (double)V * D * 4.0;
   return table_bytes >= 10e6 && table_bytes <= 128e6 && S >= 48 && (double)N * S >= 131072.0;

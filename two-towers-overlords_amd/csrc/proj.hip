@@ -23,7 +23,8 @@ int choose_nsplit(long long M) {
 // block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
 static void pick_tile(long long total_rows, int N, int& wm, int& wn, int policy = kTileAuto) {
   const bool low_traffic = policy == kTileLowTraffic;
-  if (const char* v = getenv("TT_TILE")) {  // A/B: "11", "21", "22"
+  static const char* const tile_env = getenv("TT_TILE");  // read once (A/B: "11", "21", "22")
+  if (const char* v = tile_env) {
     if (v[0] == '1' || v[0] == '2') { wm = v[0] - '0'; wn = (v[1] == '2') ? 2 : 1; if (wm == 1) wn = 1; return; }
   }
   const long long tiles64 = ((total_rows + 63) / 64) * ((N + 63) / 64);

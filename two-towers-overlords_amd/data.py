@@ -24,49 +24,62 @@ from torch.utils.data import DataLoader
 Triplet = Tuple[List[str], List[str], List[str]]
 
 
-def sample_negative_indices(query_ids: Sequence[int], rng=random) -> List[int]:
+def sample_negative_indices(query_ids: Sequence[int], rng=random,
+                            positive_nonempty: Optional[Sequence[bool]] = None) -> List[int]:
     """backend/data.py:113-137 on indices: neg_idx[i] = j, drawn like
     `_get_random_negative` (same `choice` call sequence, so the same seed gives the
-    same draws as the reference) and rejected while query_ids[j] == query_ids[i].
-    Like the reference this never terminates if every item shares one query_id and
-    raises IndexError for a batch of one."""
+    same draws as the reference) and rejected while query_ids[j] == query_ids[i] or
+    item j's positive is an empty string (data.py:126, `if negative and ...`;
+    `positive_nonempty[j]` False).  Like the reference this never terminates if no
+    other item qualifies and raises IndexError for a batch of one."""
     n = len(query_ids)
     out = []
     for i in range(n):
         while True:
             j = rng.choice([k for k in range(n) if k != i])
-            if query_ids[j] != query_ids[i]:
+            if (positive_nonempty is None or positive_nonempty[j]) and query_ids[j] != query_ids[i]:
                 out.append(j)
                 break
     return out
 
 
 def sample_negative_indices_device(query_ids: torch.Tensor, generator: Optional[torch.Generator] = None,
-                                   check: bool = True) -> torch.Tensor:
+                                   check: bool = True, positive_nonempty: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Same distribution as `sample_negative_indices` (uniform over the in-batch items of a
-    different query — what backend/data.py:113-137's rejection loop converges to), drawn for the
-    whole batch at once on `query_ids`' device, exactly and without rejection: sort the batch by
-    query id, so the items item i must NOT draw form one contiguous run [a_i, b_i) of the sorted
-    order; draw u uniformly from the B - (b_i - a_i) admissible positions and skip over the run.
+    different query whose positive is not empty — what backend/data.py:113-137's rejection loop
+    converges to), drawn for the whole batch at once on `query_ids`' device, exactly and without
+    rejection: sort the batch by query id with the empty-positive items moved to the end, so the
+    admissible items are the first n_ok sorted positions minus ONE contiguous run [a_i, b_i) (the
+    non-empty items of item i's own query); draw u uniformly from the n_ok - (b_i - a_i)
+    admissible positions and skip over the run.
     `query_ids` is [B] (one batch) or [n_batches, B] (independent batches, e.g. a whole epoch in
-    one call); the result has the same shape and holds in-batch indices.
+    one call), `positive_nonempty` a bool tensor of the same shape (None: all non-empty); the
+    result has the same shape and holds in-batch indices.
     O(B log B) tensor work against the reference's O(B^2) Python list building per batch, and no
     host synchronisation when `check=False` (the caller has then verified on the host that every
-    batch holds at least two distinct query ids).  Not the same *draws* as the reference under a
-    shared seed.  With `check=True` raises like the reference fails: IndexError for a batch of
-    one (`random.choice([])`), RuntimeError when every item shares one query id (the reference
-    never returns)."""
+    item of every batch has an admissible negative).  Not the same *draws* as the reference under
+    a shared seed.  With `check=True` raises like the reference fails: IndexError for a batch of
+    one (`random.choice([])`), RuntimeError when some item has no admissible negative (the
+    reference never returns)."""
     B = query_ids.shape[-1]
     if B < 2:
         raise IndexError("cannot draw an in-batch negative from a batch of one")  # reference: random.choice([])
     q = query_ids.reshape(-1, B)
-    sorted_q, perm = torch.sort(q, dim=1)
-    run_lo = torch.searchsorted(sorted_q, q, right=False)
-    run_hi = torch.searchsorted(sorted_q, q, right=True)
+    if positive_nonempty is None:
+        key, n_ok = q, B
+    else:
+        ok = positive_nonempty.reshape(-1, B).to(torch.bool)
+        big = torch.iinfo(q.dtype).max
+        key = torch.where(ok, q, torch.full_like(q, big))  # empty positives sort behind every real query id
+        n_ok = ok.sum(1, keepdim=True)
+    sorted_k, perm = torch.sort(key, dim=1)
+    run_lo = torch.searchsorted(sorted_k, q, right=False)
+    run_hi = torch.searchsorted(sorted_k, q, right=True)
     run = run_hi - run_lo
-    admissible = B - run
-    if check and int(admissible.min()) == 0:
-        raise RuntimeError("every item of the batch shares one query_id: no admissible negative")
+    admissible = n_ok - run
+    if check and int(admissible.min()) <= 0:
+        raise RuntimeError("an item of the batch has no admissible negative (every other item shares its query_id "
+                           "or has an empty positive)")
     u = torch.rand(q.shape, generator=generator, device=q.device, dtype=torch.float64)
     pick = torch.minimum((u * admissible).long(), (admissible - 1).clamp_(min=0))
     pick = torch.where(pick < run_lo, pick, pick + run)
@@ -142,7 +155,8 @@ class TripletDataLoader:
     def create_triplets(self, batch: list) -> Triplet:
         queries = [item["query"] for item in batch]
         positives = [item["positive"] for item in batch]
-        neg_idx = sample_negative_indices([int(item["query_id"]) for item in batch])
+        neg_idx = sample_negative_indices([int(item["query_id"]) for item in batch],
+                                          positive_nonempty=[bool(item["positive"]) for item in batch])
         negatives = [batch[j]["positive"] for j in neg_idx]
         return queries, positives, negatives
 
@@ -226,6 +240,7 @@ class TokenTripletLoader:
         self.rng = random.Random(seed) if seed is not None else random
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed if seed is not None else random.getrandbits(60))
+        p_nonempty = None
         if isinstance(packed, _Rows):
             self.query_ids = [int(x) for x in packed.query_ids]
             self.q_ids, self.q_lens = packed.q_ids.to(self.device, torch.int32), packed.q_lens.to(self.device, torch.int32)
@@ -239,9 +254,13 @@ class TokenTripletLoader:
             n = len(dataset)
             items = [dataset[i] for i in range(n)]
             self.query_ids = [int(it["query_id"]) for it in items]
+            p_nonempty = [bool(it["positive"]) for it in items]  # data.py:126: an empty passage is never a negative
             self.q_ids, self.q_lens = self._tokenize(tokenizer, [it["query"] for it in items], max_length)
             self.p_ids, self.p_lens = self._tokenize(tokenizer, [it["positive"] for it in items], max_length)
         self._qid_t = torch.tensor(self.query_ids, dtype=torch.int64, device=self.device)
+        # per item: may its positive serve as a negative?  (always, unless built from strings with empty passages)
+        self.p_nonempty = None if all(p_nonempty or [True]) else list(p_nonempty)
+        self._ok_t = None if self.p_nonempty is None else torch.tensor(self.p_nonempty, dtype=torch.bool, device=self.device)
         self._padded = None  # (q_ids, p_ids) padded to one common S (pad="max")
 
     def _tokenize(self, tokenizer, texts, max_length):
@@ -288,6 +307,18 @@ class TokenTripletLoader:
         cls.__init__(self, None, None, batch_size, device, packed=_Rows(q_ids, q_lens, p_ids, p_lens, query_ids), **kw)
         return self
 
+    def peek(self):
+        """The first batch an iteration started now would yield, WITHOUT consuming anything: the host and device
+        random streams (`rng`, `gen`) are put back afterwards, so a later epoch shuffles and draws its negatives
+        exactly as if this call had not happened (run_training calibrates on it before epoch 1)."""
+        host_state = self.rng.getstate()
+        dev_state = self.gen.get_state()
+        try:
+            return next(iter(self))
+        finally:
+            self.rng.setstate(host_state)
+            self.gen.set_state(dev_state)
+
     def all_texts(self):
         """(ids [2N, S], lens [2N]) of every query then every positive — the input of the feature cache."""
         S = max(self.q_ids.shape[1], self.p_ids.shape[1])
@@ -312,17 +343,27 @@ class TokenTripletLoader:
         if r == 1 or (B == 1 and n_full):
             raise IndexError("cannot draw an in-batch negative from a batch of one")
         qt = self._qid_t[order_t]
+        okt = None if self._ok_t is None else self._ok_t[order_t]
         full = qt[: n_full * B].view(n_full, B) if n_full else None
         tail = qt[n_full * B:] if r else None
+        ok_full = None if okt is None or not n_full else okt[: n_full * B].view(n_full, B)
+        ok_tail = None if okt is None or not r else okt[n_full * B:]
         bad = torch.zeros((), dtype=torch.bool, device=self.device)
-        if n_full:
-            bad = bad | (full.min(1).values == full.max(1).values).any()
-        if r:
-            bad = bad | (tail.min() == tail.max())
+        if okt is None:
+            if n_full:
+                bad = bad | (full.min(1).values == full.max(1).values).any()
+            if r:
+                bad = bad | (tail.min() == tail.max())
+        else:  # some item must find a non-empty positive of another query: count them exactly
+            for qq, oo in ((full, ok_full), (tail.view(1, -1) if r else None, ok_tail.view(1, -1) if r else None)):
+                if qq is None:
+                    continue
+                same_ok = ((qq.unsqueeze(2) == qq.unsqueeze(1)) & oo.unsqueeze(1)).sum(2)  # O(B^2): only on this rare path
+                bad = bad | ((oo.sum(1, keepdim=True) - same_ok) <= 0).any()
         if bool(bad):  # the reference would spin forever in create_triplets (backend/data.py:124-128)
             raise RuntimeError("every item of a batch shares one query_id: no admissible negative")
-        neg_full = sample_negative_indices_device(full, self.gen, check=False) if n_full else None
-        neg_tail = sample_negative_indices_device(tail, self.gen, check=False) if r else None
+        neg_full = sample_negative_indices_device(full, self.gen, check=False, positive_nonempty=ok_full) if n_full else None
+        neg_tail = sample_negative_indices_device(tail, self.gen, check=False, positive_nonempty=ok_tail) if r else None
         return neg_full, neg_tail
 
     def __iter__(self):
@@ -375,8 +416,10 @@ class TokenTripletLoader:
             if self.sampler == "device":
                 neg_t = neg_full[bi] if bi < n_full else neg_tail
             else:
-                neg_t = torch.tensor(sample_negative_indices([self.query_ids[i] for i in order[s: s + B]], self.rng),
-                                     device=self.device)
+                sel = order[s: s + B]
+                neg_t = torch.tensor(sample_negative_indices(
+                    [self.query_ids[i] for i in sel], self.rng,
+                    None if self.p_nonempty is None else [self.p_nonempty[i] for i in sel]), device=self.device)
             if by_rows:
                 parts = [it, it + n] + ([it[neg_t] + n] if three else [])
                 rows = torch.stack(parts).to(torch.int32)

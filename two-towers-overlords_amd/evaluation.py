@@ -17,14 +17,56 @@ not need the host copies the reference makes.
 """
 from __future__ import annotations
 
+import dataclasses
 import random
-from typing import Union
+from typing import Dict, List, Set, Tuple, Union
 
 import numpy as np
 import torch
 
 from . import ops
 from .model import TwoTowersModel
+
+
+@dataclasses.dataclass
+class QueryGroup:
+    """One evaluation query and the passages the sampled items list for it."""
+
+    query: str
+    relevant: Set[str] = dataclasses.field(default_factory=set)
+
+
+def sample_query_groups(dataset, sample_size: int, min_query_groups: int, rng=random) -> Tuple[List, Dict]:
+    """Draw evaluation queries the way backend/training.py:184-207 does — the draws have to be the reference's
+    (`rng.sample(range(len(dataset)), k)` with k = sample_size, 2*sample_size, ... at most ten times, until
+    `min_query_groups` distinct query ids have been seen), or `tests/golden/eval.npz` would not be reproduced.
+    Returns (the query ids with the most relevant passages first, cut to min_query_groups; {query_id: QueryGroup})."""
+    groups: Dict = {}
+    for attempt in range(1, 11):
+        if len(groups) >= min_query_groups:
+            break
+        for i in rng.sample(range(len(dataset)), min(sample_size * attempt, len(dataset))):
+            item = dataset[i]
+            groups.setdefault(item["query_id"], QueryGroup(item["query"])).relevant.add(item["positive"])
+    ranked = sorted(groups, key=lambda qid: len(groups[qid].relevant), reverse=True)  # stable: ties keep first-seen order
+    return ranked[:min_query_groups], groups
+
+
+def candidate_pools(order: List, groups: Dict, candidate_pool_size: int, rng=random) -> List[List[str]]:
+    """Per query: its relevant passages first, then the other selected queries' passages it does not share, thinned
+    to `candidate_pool_size` by `rng.sample` when there are more (backend/training.py:249-267)."""
+    pools = []
+    for qid in order:
+        relevant = groups[qid].relevant
+        others: Set[str] = set()
+        for other in order:
+            if other != qid:
+                others.update(d for d in groups[other].relevant if d not in relevant)
+        distractors = list(others)
+        if len(distractors) > candidate_pool_size:
+            distractors = rng.sample(distractors, candidate_pool_size)
+        pools.append(list(relevant) + distractors)
+    return pools
 
 
 def evaluate_model(
@@ -41,45 +83,17 @@ def evaluate_model(
     """NDCG@{10,5,1} over sampled query groups.  Mirrors backend/training.py:136-380."""
     print(f"Sampling documents for evaluation (initial sample size: {sample_size})...")
     model.eval()
-
-    # -- group by query_id until enough unique queries (training.py:184-201): identical `random` use
-    query_groups: dict = {}
-    sample_multiplier = 1
-    while len(query_groups) < min_query_groups and sample_multiplier <= 10:
-        sample_size_current = min(sample_size * sample_multiplier, len(dataset))
-        indices = random.sample(range(len(dataset)), sample_size_current)
-        for item in (dataset[i] for i in indices):
-            query_id = item["query_id"]
-            if query_id not in query_groups:
-                query_groups[query_id] = {"query": item["query"], "relevant_docs": set()}
-            query_groups[query_id]["relevant_docs"].add(item["positive"])
-        sample_multiplier += 1
-
-    query_ids = sorted(query_groups.keys(), key=lambda qid: len(query_groups[qid]["relevant_docs"]), reverse=True)[
-        :min_query_groups
-    ]
-    total_relevant_docs = sum(len(query_groups[qid]["relevant_docs"]) for qid in query_ids)
+    query_ids, groups = sample_query_groups(dataset, sample_size, min_query_groups)
+    total_relevant_docs = sum(len(groups[qid].relevant) for qid in query_ids)
     avg_relevant_per_query = total_relevant_docs / len(query_ids)
     print(f"Selected {len(query_ids)} queries for evaluation")
 
-    # -- candidate pools (training.py:230-277) as (unique document list, per-query membership)
+    # candidate pools as (unique document list, per-query membership mask): -1 = every unique passage of the dataset
     if candidate_pool_size == -1:
         docs = list(dataset.get_unique_passages())
         pools = None
     else:
-        pools = []
-        for query_id in query_ids:
-            relevant_docs = query_groups[query_id]["relevant_docs"]
-            irrelevant_docs = set(
-                doc
-                for other_qid in query_ids
-                for doc in query_groups[other_qid]["relevant_docs"]
-                if other_qid != query_id
-                if doc not in relevant_docs
-            )
-            if len(irrelevant_docs) > candidate_pool_size:
-                irrelevant_docs = random.sample(list(irrelevant_docs), candidate_pool_size)
-            pools.append(list(relevant_docs) + list(irrelevant_docs))
+        pools = candidate_pools(query_ids, groups, candidate_pool_size)
         docs = list(dict.fromkeys(d for pool in pools for d in pool))
     doc_index = {d: j for j, d in enumerate(docs)}
     Q, N = len(query_ids), len(docs)
@@ -87,7 +101,7 @@ def evaluate_model(
     relevance = np.zeros((Q, N), dtype=np.float32)
     valid = None if pools is None else np.zeros((Q, N), dtype=np.uint8)
     for i, query_id in enumerate(query_ids):
-        for d in query_groups[query_id]["relevant_docs"]:
+        for d in groups[query_id].relevant:
             j = doc_index.get(d)
             if j is not None:
                 relevance[i, j] = 1.0
@@ -96,7 +110,7 @@ def evaluate_model(
 
     # -- embeddings through the hot path, similarities and NDCG on the device
     with torch.no_grad():
-        query_embeds = model.encode_queries([query_groups[qid]["query"] for qid in query_ids])
+        query_embeds = model.encode_queries([groups[qid].query for qid in query_ids])
         doc_embeds = model.encode_documents_batched(docs, batch_size=batch_size)
         scores = ops.cosine_scores(query_embeds.contiguous(), doc_embeds.contiguous())
         dev = scores.device

@@ -110,6 +110,25 @@ class AveragePoolingTower(nn.Module):
             nn.Linear(projection_dim, projection_dim),
         )
 
+    # -- the encoder mode travels with the weights -------------------------------------
+    # as state_dict METADATA (the per-module dict torch keeps beside `version`), not as a key: the reference loads
+    # these checkpoints with a strict load_state_dict (search.py:229-231) and must not see keys it does not know.
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        meta = getattr(destination, "_metadata", None)
+        if meta is not None and prefix[:-1] in meta:
+            meta[prefix[:-1]]["encoder_mode"] = self.encoder_mode
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        trained = (local_metadata or {}).get("encoder_mode")
+        if trained is None and getattr(self.pretrained_model, "encoder", None) is not None:
+            trained = "bert"  # no record: a reference checkpoint, trained behind the full frozen encoder (model.py:51-52)
+        if trained is not None and trained != self.encoder_mode and any(k.startswith(prefix + "projection.") for k in state_dict):
+            warnings.warn(f"{prefix or 'tower.'}projection weights were trained with encoder_mode='{trained}' but this tower "
+                          f"runs encoder_mode='{self.encoder_mode}': its embeddings will not match the training run's; "
+                          f"construct the model with encoder_mode='{trained}'.", stacklevel=2)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
     # -- the reference entry point ------------------------------------------------
     def forward(self, texts: list[str]) -> Tensor:
         """model.py:40-60: tokenize, move to the model's device, pool, project."""

@@ -246,6 +246,8 @@ class TripletTrainer:
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         # gradients are exchanged between replicas (see _all_reduce); `exchange=True` forces the data-parallel step's
         # code path on a single-rank group too (tests: the exchange is then an identity)
+        if self.world > 1 and exchange is False:
+            raise ValueError("exchange=False with more than one replica: the gradients must be summed over the ranks")
         self._exchange = (self.world > 1) if exchange is None else bool(exchange)
         self._gather_under_exchange = os.environ.get("TT_GATHER_UNDER_EXCHANGE", "1") != "0"  # A/B knob
         self.bucket = torch.empty_like(self.flat) if (self._exchange or self.accumulation_steps > 1) else None
@@ -408,13 +410,22 @@ class TripletTrainer:
                 order = mask.sum(1).argsort()
             else:
                 order = torch.arange(N, device=ids.device)
-            for s in range(0, N, chunk):
-                sel = order[s: s + chunk]
-                cut = ids.shape[1] if mask is None else max(int(mask[sel].sum(1).max()), 1)
-                tokens = {"input_ids": ids[sel][:, :cut].long().contiguous()}
-                if mask is not None:
-                    tokens["attention_mask"] = mask[sel][:, :cut].contiguous()
-                out[sel] = self.model.query_tower.pool_tokens(tokens)
+            # the cache holds the EVAL-mode encoder's outputs (what backend/training.py:26-63, the reference's CPU
+            # loop, sees: from_pretrained leaves the encoder in eval and train_epoch never calls model.train()); a
+            # caller that has switched the model to train() would otherwise bake one sample of dropout noise into it
+            pm = self.model.query_tower.pretrained_model
+            was_training = pm.training
+            pm.eval()
+            try:
+                for s in range(0, N, chunk):
+                    sel = order[s: s + chunk]
+                    cut = ids.shape[1] if mask is None else max(int(mask[sel].sum(1).max()), 1)
+                    tokens = {"input_ids": ids[sel][:, :cut].long().contiguous()}
+                    if mask is not None:
+                        tokens["attention_mask"] = mask[sel][:, :cut].contiguous()
+                    out[sel] = self.model.query_tower.pool_tokens(tokens)
+            finally:
+                pm.train(was_training)
         else:
             for s in range(0, N, chunk):
                 e = min(N, s + chunk)
@@ -462,6 +473,10 @@ class TripletTrainer:
         self._micro += 1
         do_step = self._micro % k == 0
         if self.bucket is None:  # single replica, no accumulation: Adam folds the slab sum
+            if local_B == 0:  # nothing was computed: the slabs still hold the previous batch's gradients
+                if issue_next is not None:
+                    issue_next()
+                return
             self.step_count += 1
             if self._auto_step:  # step counter on the device: the same call sequence is graph-replayable
                 self.engine.adam_auto(self.lr, None, self.betas[0], self.betas[1], self.eps)
@@ -846,7 +861,7 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
                  run_comprehensive_test: bool = True, *, train_dataset=None, val_dataset=None, test_dataset=None,
                  tokenizer=None, pretrained_model=None, model_name: Optional[str] = None,
                  seed: Optional[int] = None, feature_cache: bool = True, sampler: str = "device",
-                 encoder_mode: str = "embed", calibrate: bool = True, three_encodes: bool = False) -> TwoTowersModel:
+                 encoder_mode: Optional[str] = None, calibrate: bool = True, three_encodes: bool = False) -> TwoTowersModel:
     """Same keyword surface and defaults as backend/training.py:383-397; builds the
     model / criterion / Adam exactly like :433-436 and runs `num_epochs` epochs on
     the fused engine.  Differences, all outside the hot path: the dataset is passed
@@ -855,7 +870,10 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
     harness (training.py:136-380) are not reproduced, `use_mixed_precision` /
     `num_workers` / `run_comprehensive_test` are accepted for signature parity and
     ignored (fp32 is the parity path; tokenisation happens once, up front).
-    `encoder_mode` is explicit here.  "embed": word-embedding rows pooled directly (the HIP gather).  "bert": the
+    `encoder_mode` None = the model's own default (`TwoTowersModel`: "bert" for a pretrained model with encoder layers —
+    what the reference executes — else "embed"), so a default `run_training` and a default-constructed model that later
+    loads its weights agree; the mode travels with the checkpoint (state_dict metadata) and a mismatch at load time
+    warns.  "embed": word-embedding rows pooled directly (the HIP gather).  "bert": the
     reference's executed behaviour (frozen encoder between gather and pool, backend/model.py:51-52) — the encoder
     runs ONCE per text into the frozen-feature cache (it is frozen: its outputs never change), every epoch is then
     the fused cache-fed step, where the reference re-runs the encoder three times per step (99 % of its step
@@ -881,6 +899,7 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
     model = TwoTowersModel(projection_dim=projection_dim, tokenizer=tokenizer, pretrained_model=pretrained_model,
                            encoder_mode=encoder_mode, **kw)
     model = model.to(device)
+    encoder_mode = model.query_tower.encoder_mode
     if max_samples and max_samples > 0 and len(train_dataset) > max_samples:
         train_dataset = torch.utils.data.Subset(train_dataset, range(max_samples))
     loader = TokenTripletLoader(train_dataset, model.query_tower.tokenizer, batch_size, device, seed=seed,
@@ -905,7 +924,7 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
         trainer.set_token_store(*loader.all_texts())
     sizes = loader.global_batch_sizes() if world > 1 else None  # the loader yields this rank's shard of every batch
     if calibrate and len(loader) > 0:
-        trainer.calibrate(next(iter(loader)))
+        trainer.calibrate(loader.peek())  # a first batch drawn WITHOUT advancing the loader's random streams
     if rank == 0:
         print(f"Starting training for {num_epochs} epochs...")
     for epoch in range(num_epochs):

@@ -300,7 +300,8 @@ def secondary_c4(args, world, rank, device) -> dict:
     step rate, K1 in the loop and K1 alone.  `traffic` is null: PMC counters are not collected in a timed run."""
     a = copy.copy(args)
     a.config, a.steps, a.warmup, a.no_cpu_baseline = "c4", 12, 3, True
-    a.n_distinct, a.calibrate_steps, a.calibrate_rounds, a.iso_launches = 2, 8, 1, 8
+    a.n_distinct, a.calibrate_steps, a.calibrate_rounds, a.iso_launches = 2, 12, 1, 8
+    a.no_traffic_file = True  # `traffic` stays null here: nothing is read back from committed profiles
     torch.cuda.empty_cache()
     r = run_config(a, world, rank, device)
     torch.cuda.empty_cache()
@@ -426,8 +427,8 @@ def run_config(args, world, rank, device) -> dict:
                 trainer.gather(next_batch())
             else:
                 trainer.advance(next_batch(), B * world)
-            if timed and trace_ev and k % 10 == 0 and k // 10 <= len(trace_ev):
-                trace_ev[k // 10 - 1].record()
+            if timed and trace_ev and k % trace_every == 0 and len(trace_host) < len(trace_ev):
+                trace_ev[len(trace_host)].record()
                 trace_host.append(time.perf_counter())
         trainer.k1_events = None
 
@@ -438,7 +439,8 @@ def run_config(args, world, rank, device) -> dict:
             else:
                 trainer.advance(None, B * world)
 
-    trace_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // 10)] if os.environ.get("TT_TRACE") else []
+    trace_every = 1 if os.environ.get("TT_TRACE") == "step" else 10  # TT_TRACE=step: one event per step
+    trace_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // trace_every)] if os.environ.get("TT_TRACE") else []
     trace_host = []
 
     if os.environ.get("TT_GC_FREEZE", "1") == "1":  # (0: A/B of this very effect)
@@ -475,6 +477,7 @@ def run_config(args, world, rank, device) -> dict:
         if not args.no_calibrate:  # set-up, like calibrate(): run the event-timed code path once before anything is timed
             run(4, timed=True)
             k1_ev.clear()
+            trace_host.clear()
             set_up_steps += 4
         run(args.warmup, timed=False)
         barrier()
@@ -510,7 +513,7 @@ def run_config(args, world, rank, device) -> dict:
     traffic = traffic_source = None  # fabric-side bytes per K1 launch: from the committed PMC passes of this same workload, if any
     import glob
     tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_k1_traffic_{args.config}.json")))
-    if tpaths and not args.zipf:  # the newest round's PMC passes
+    if tpaths and not args.zipf and not getattr(args, "no_traffic_file", False):  # the newest round's PMC passes
         tj = json.load(open(tpaths[-1]))
         if int(tj.get("algorithmic_bytes_per_launch", -1)) == alg and args.inputs == "ids3":
             traffic = tj["traffic_bytes_per_launch"]
@@ -519,8 +522,12 @@ def run_config(args, world, rank, device) -> dict:
     achieved = alg / (k1_ms * 1e-3) / 1e9
     from two_towers_overlords_amd import _lib as _ttlib
     sliced = bool(_ttlib.load().tt_k1_prefers_sliced(V, D, roles * B, S))
+    streaming = (trainer.side is not None and trainer.engine_k1_cap < 0
+                 and bool(_ttlib.load().tt_k1_prefers_stream(V, D, roles * B, S)))
     k1_label = ("pool_sliced_kernel + pool_combine_kernel (K1, XCD-sliced form: gather + masked mean-pool + L2 normalise; "
                 "both launches lie inside the timed events)" if sliced
+                else "pool_norm_stream_kernel (K1, streaming form: persistent workgroups, two per compute unit, pulling texts "
+                     "from a queue; gather + masked mean-pool + L2 normalise)" if streaming
                 else "pool_norm_kernel (K1 gather + masked mean-pool + L2 normalise)")
     metric = (("triplets/sec (q,pos,neg @ seq128/d384), full training step" if args.config == "c2"
                else "triplets/sec, full training step") if args.inputs == "ids3"
@@ -584,10 +591,13 @@ def run_config(args, world, rank, device) -> dict:
     if trace_ev and len(trace_host) > 1:
         gaps = [round(trace_ev[i].elapsed_time(trace_ev[i + 1]), 2) for i in range(len(trace_host) - 1)]
         hgaps = [round((trace_host[i + 1] - trace_host[i]) * 1e3, 2) for i in range(len(trace_host) - 1)]
-        print("TRACE gpu ms per 10 steps:", gaps, file=sys.stderr)
-        print("TRACE host ms per 10 steps:", hgaps, file=sys.stderr)
+        print(f"TRACE gpu ms per {trace_every} step(s):", gaps, file=sys.stderr)
+        print(f"TRACE host ms per {trace_every} step(s):", hgaps, file=sys.stderr)
         print("TRACE K1 in-loop ms (every %d-th launch):" % trainer.k1_event_every,
               [round(a.elapsed_time(b), 3) for a, b in k1_ev], file=sys.stderr)
+    if os.environ.get("TT_TRACE") and hasattr(trainer.engine, "k1_census"):
+        print("TRACE streaming-K1 census per slot (admitted workgroups, CUs used, max registered on one CU):",
+              [trainer.engine.k1_census(s) for s in range(trainer.SLOTS)], file=sys.stderr)
     trainer.engine.close()  # the workspace goes back to the allocator before a `secondary` configuration is set up
     return result
 

@@ -104,6 +104,30 @@ int tt_gather_pool_norm_sliced_f32(const float* table, const void* ids, int ids_
                                    tt_stream_t stream);
 
 /*
+ * Streaming form of tt_gather_pool_norm_f32 for tables that really come from HBM (several times the 256 MiB
+ * Infinity Cache; BASELINE.json configs[3]), built to share the chip with MFMA kernels of another stream:
+ * persistent workgroups pull texts from a queue and at most `workgroups_per_cu` of them stay on any compute
+ * unit (a workgroup that finds its CU full leaves at once), so the gather keeps a fixed number of row loads
+ * in flight per CU and the rest of every CU stays free.  Same arguments and bitwise the same result as
+ * tt_gather_pool_norm_f32.  `workspace`: tt_gather_pool_stream_workspace_bytes() bytes, 16-byte aligned,
+ * private to one launch at a time (it holds the queue head and the per-CU registry; cleared by the call).
+ * Requires D % 4 == 0, D <= 1024.  Replaces the same reference lines (backend/model.py:51-56, 63-72).
+ */
+size_t tt_gather_pool_stream_workspace_bytes(void);
+int tt_k1_stream_supported(int D, const float* table, const float* out);
+/* 1 if the streaming form is the one to use for this shape on MI355X (tt_engine_pool applies it by itself) */
+int tt_k1_prefers_stream(int64_t V, int D, int64_t N, int S);
+int tt_gather_pool_norm_stream_f32(const float* table, const void* ids, int ids_dtype,
+                                   const void* mask, int mask_dtype, const int32_t* lens,
+                                   float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                                   void* workspace, size_t workspace_bytes, int workgroups_per_cu,
+                                   tt_stream_t stream);
+/* Diagnostic (synchronises `stream`): workgroups the last streaming launch on `workspace` admitted, compute
+ * units that hosted one, and the largest number of workgroups that registered on one CU. */
+int tt_gather_pool_stream_census(const void* workspace, int32_t* admitted, int32_t* cus_used,
+                                 int32_t* max_registered, tt_stream_t stream);
+
+/*
  * Same pooling + normalisation over dense hidden states [N,S,D] (the `bert`
  * encoder mode: the frozen encoder of backend/model.py:51-52 is run by stock
  * PyTorch-ROCm, its last_hidden_state is pooled here).  Replaces
@@ -387,8 +411,28 @@ int tt_engine_backward(tt_engine* e, int slot, int32_t B, int32_t roles, tt_stre
 float* tt_engine_dout(const tt_engine* e);                     /* [roles*B, P] */
 int tt_engine_add_loss(tt_engine* e, const float* loss_value, tt_stream_t stream);
 
+/* Diagnostic (synchronises `stream`): tt_gather_pool_stream_census of the streaming gather last launched into pooled
+ * slot `slot` by tt_engine_pool* (all zeros when the engine does not use the streaming form for its table). */
+int tt_engine_k1_census(tt_engine* e, int slot, int32_t* admitted, int32_t* cus_used, int32_t* max_registered,
+                        tt_stream_t stream);
+
 /* grad_out[param_count] (+)= sum of slabs — the flat bucket handed to the RCCL all-reduce. */
 int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumulate, tt_stream_t stream);
+/*
+ * The same over the parameters [offset, offset + count) only (grad_out is still the whole flat bucket):
+ * lets the data-parallel step reduce and exchange the second-layer gradients (dW2 / db2, complete before
+ * the dH -> dW1 chain starts) while the first-layer gradients are still being computed.
+ */
+int tt_engine_reduce_grads_range(tt_engine* e, float* grad_out, int64_t offset, int64_t count, int accumulate,
+                                 tt_stream_t stream);
+/*
+ * Optional hand-off point inside tt_engine_fwd_bwd / tt_engine_backward: `event` (a hipEvent_t, NULL = none)
+ * is recorded right after the launch that completes the dW2 / db2 slabs of both towers — on the caller's
+ * stream (fused backward) or on the engine's second stream (fork backward).  A stream that waits for it may
+ * read those slabs while dH -> dW1 / db1 are still running.
+ */
+typedef void* tt_event_t; /* hipEvent_t */
+int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event);
 
 /*
  * Phase C: Adam over the bound flat buffers.  grads == NULL: consume the

@@ -69,6 +69,12 @@ class OracleEngine:
         else:
             out.copy_(self.grad)
 
+    def reduce_grads_range(self, out, offset, count, accumulate=False):
+        if accumulate:
+            out[offset: offset + count] += self.grad[offset: offset + count]
+        else:
+            out[offset: offset + count].copy_(self.grad[offset: offset + count])
+
     def adam(self, step, lr, grads=None, beta1=0.9, beta2=0.999, eps=1e-8):
         g = self.grad if grads is None else grads
         st = orc.AdamState(lr=lr, beta1=beta1, beta2=beta2, eps=eps, step=step - 1, m={"p": self.m}, v={"p": self.v})

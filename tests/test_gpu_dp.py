@@ -240,10 +240,10 @@ def _rccl_one_rank_worker(port, q):
         table, params, _, gb = _setup()
         dev_batches = [tuple(None if t is None else t.cuda() for t in b) for b in gb]
         out = []
-        for exchange in (False, True):
+        for exchange, split in ((False, False), (True, False), (True, True)):
             tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B,
-                                max_seq_len=S, margin=0.3, lr=1e-3, exchange=exchange)
-            assert (tr.bucket is not None) == exchange
+                                max_seq_len=S, margin=0.3, lr=1e-3, exchange=exchange, split_exchange=split)
+            assert (tr.bucket is not None) == exchange and tr._split == split
             losses = [tr.train_epoch(dev_batches) for _ in range(3)]
             out.append((losses, tr.flat.cpu().numpy().copy()))
         q.put(("ok", out, None))
@@ -267,6 +267,76 @@ def test_data_parallel_step_over_rccl_single_rank_is_the_single_replica_step():
     out = q.get()
     p.join(180)
     assert out[0] == "ok", out[1]
-    (l0, f0), (l1, f1) = out[1]
-    assert l0 == l1
+    (l0, f0), (l1, f1), (l2, f2) = out[1]
+    assert l0 == l1 == l2
     assert np.array_equal(f0, f1)
+    assert np.array_equal(f0, f2)  # the two-part exchange (TT_DP_SPLIT): coalesced RCCL groups on a second stream
+
+
+# --------------------------------------------------------------------------- two-part exchange, two ranks
+def _split_worker(rank, world, port, backend, q):
+    try:
+        from two_towers_overlords_amd.training import TripletTrainer, shard_batch
+
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dev = rank if backend == "nccl" else 0
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        table, params, _, gb = _setup()
+        res = {}
+        for split in (False, True):
+            tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B,
+                                max_seq_len=S, margin=0.3, lr=1e-3, split_exchange=split)
+            shards, sizes = zip(*(shard_batch(tuple(None if t is None else t.cuda() for t in b), rank, world) for b in gb))
+            losses = [tr.train_epoch(list(shards), global_batch_sizes=list(sizes)) for _ in range(2)]
+            res[split] = (losses, tr.flat.cpu().numpy().copy(), tr.replica_divergence())
+        if rank == 0:
+            q.put(("ok", res, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put(("error", f"rank {rank}: {e}\n{traceback.format_exc()}", None))
+        raise
+
+
+def _run_split(backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29300 + os.getpid() % 500 + (17 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get()
+    for p in procs:
+        p.join(240)
+    assert out[0] == "ok", out[1]
+    assert all(p.exitcode == 0 for p in procs)
+    return out[1]
+
+
+def _check_split(res):
+    (l0, f0, d0), (l1, f1, d1) = res[False], res[True]
+    assert d0 == 0.0 and d1 == 0.0          # replicas in step
+    assert l0 == l1 and np.array_equal(f0, f1)  # two replicas: a + b either way, bit for bit
+    table, params, batches, _ = _setup()
+    st = orc.AdamState(lr=1e-3)
+    for _ in range(2):
+        ref_avg, _ = orc.train_epoch(table, batches, params, st, 0.3)
+    assert abs(l1[-1] - ref_avg) <= 1e-5
+
+
+def test_split_exchange_two_ranks_is_bitwise_the_one_bucket_exchange():
+    """TT_DP_SPLIT's two-part exchange with the real HIP engine (dW2 / db2 reduced and exchanged on a second stream
+    behind the engine's `dw2` event while dH -> dW1 still run), two ranks sharing the box's GPU over gloo."""
+    _check_split(_run_split("gloo"))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per GPU")
+def test_two_ranks_over_rccl_both_exchange_forms():
+    """The same over RCCL (nccl backend), one rank per GPU — runs wherever two GPUs are visible."""
+    _check_split(_run_split("nccl"))

@@ -254,6 +254,19 @@ def test_run_training_end_to_end_with_cache_and_eval():
         out[cache] = torch.cat([p.detach().reshape(-1).cpu() for p in m.trainable_parameters()])
     assert (out[True] - out[False]).abs().max() <= 2e-5  # 3 epochs x 4 steps of Adam at lr 1e-2
 
+    # calibrate() runs on loader.peek(): it must not advance the loader's shuffle / negative draws, so a run with it
+    # and a run without it train on the same batches and end with the same parameters, bit for bit
+    for sampler in ("device", "reference"):
+        res = []
+        for calibrate in (True, False):
+            torch.manual_seed(0)
+            m = run_training(num_epochs=2, batch_size=32, learning_rate=1e-2, max_samples=10 ** 6, projection_dim=32,
+                             margin=0.3, use_wandb=False, accumulation_steps=1, train_dataset=DS(), tokenizer=IntTokenizer(),
+                             pretrained_model=EmbeddingOnlyEncoder(table), seed=5, feature_cache=False, sampler=sampler,
+                             calibrate=calibrate)
+            res.append(torch.cat([p.detach().reshape(-1).cpu() for p in m.trainable_parameters()]))
+        assert torch.equal(res[0], res[1]), sampler
+
 
 @pytest.mark.parametrize("overlap", [False, True])
 def test_training_is_bitwise_reproducible(overlap):

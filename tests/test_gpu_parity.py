@@ -384,17 +384,21 @@ def test_engine_vs_oracle_metric_shape(tt):
 
 
 # --------------------------------------------------------------------------- f1: negatives by index, feature cache
-def test_engine_neg_index_equals_three_encodes(tt):
+@pytest.mark.parametrize("V,D,P,B,S", [
+    (3000, 384, 64, 200, 40),
+    (2000, 32, 16, 4500, 6),   # B > 4096: the gradient scatter goes through the sort-by-destination (CSR) path
+])
+def test_engine_neg_index_equals_three_encodes(tt, V, D, P, B, S):
     """In-batch negatives by index (2 gathers, document tower on B rows, scatter-added gradient)
     == the reference's three-encode form with negatives = positives[neg_index]."""
     _, engine = tt
-    V, D, P, B, S = 3000, 384, 64, 200, 40
     table = orc.synthetic_table(V, D, seed=7) * 30
     params = orc.init_params(D, P, seed=8)
     gen = torch.Generator().manual_seed(9)
     q_b, p_b, _ = orc.synthetic_batch(B, S, V, seed=33, ragged=True)
     neg = torch.randint(0, B, (B,), generator=gen)
     neg[:10] = 3  # one positive drawn as the negative of many triplets
+    neg[50:130] = 7  # ... and one by more than a wave's worth of them (the CSR bucket is walked in chunks of 64)
     batch3 = (q_b, p_b, (p_b[0][neg], p_b[1][neg]))
     loss, grads, embs = orc.loss_and_grads(table, batch3, params, 0.3)
 
@@ -558,12 +562,13 @@ def test_inbatch_triplet_vs_oracle(tt, Bq, Bd, P, ids):
 
 # --------------------------------------------------------------------------- BASELINE size: properties
 @pytest.mark.parametrize("V,D,P,B,S", [
+    pytest.param(30522, 384, 64, 256, 128, id="configs0_b256_p64"),  # the reference README's own CPU run (README.md:64-75)
     pytest.param(30522, 384, 384, 2048, 128, id="configs1_b2048_p384"),
     pytest.param(30522, 384, 512, 1024, 128, id="configs2_one_gpu_share_b1024_p512"),
     pytest.param(250000, 768, 768, 16384, 256, id="configs3_v250k_d768_b16384_s256"),
 ])
 def test_metric_size_properties(tt, V, D, P, B, S):
-    """BASELINE.json configs[1], [2] (one GPU's share) and [3] at their full sizes, where the oracle would
+    """BASELINE.json configs[0], [1], [2] (one GPU's share) and [3] at their full sizes, where the oracle would
     take minutes to hours: size-independent properties + the oracle on a row subsample (the forward is
     row-independent, so any subset of rows must agree with the oracle run on just those rows)."""
     ops, engine = tt
@@ -722,6 +727,84 @@ def test_pool_forms_fuzz(tt):
         close(a, ref, atol=2e-6)
         close(b, ref, atol=2e-6)
         assert (a - b).abs().max().item() <= 1e-6, (case, D, S, V, N, kind)
+
+
+# --------------------------------------------------------------------------- streaming K1 (tables that come from HBM)
+def test_pool_stream_form_is_bitwise_the_per_text_form(tt):
+    """tt_gather_pool_norm_stream_f32 (persistent workgroups pulling texts from a queue, at most n per compute
+    unit): every text pooled exactly once, with pool_norm_kernel's arithmetic — bitwise the per-text result and
+    within 2e-6 of the oracle — for every mask kind / index width, out-of-range ids, more and fewer texts than
+    workgroups; the per-CU registry never admits more than n workgroups on one compute unit."""
+    import ctypes as C
+
+    from two_towers_overlords_amd import _lib
+
+    ops, _ = tt
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(77)
+    for case in range(24):
+        D = (4, 64, 256, 384, 768, 1024, 100)[case % 7]
+        S = int(torch.randint(1, 300, (1,), generator=gen))
+        V = int(torch.randint(1, 5000, (1,), generator=gen))
+        N = (1, 3, 40, 700, 2600)[case % 5]
+        per_cu = (1, 2, 3)[case % 3]
+        table = torch.randn(V, D, generator=gen)
+        ids = torch.randint(0, V, (N, S), generator=gen)
+        kind = case % 4
+        mask = lens = None
+        if kind == 0:
+            lens = torch.randint(0, S + 1, (N,), generator=gen)
+            eff = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+        elif kind == 1:
+            mask = (torch.rand(N, S, generator=gen) < 0.7).long()
+            eff = mask
+        elif kind == 2:
+            mask = torch.randint(0, 4, (N, S), generator=gen)
+            eff = mask
+        else:
+            eff = torch.ones(N, S, dtype=torch.long)
+        if case % 5 == 0:
+            ids[0, 0] = V + 7
+            ids[-1, -1] = -3
+        idt = torch.int32 if case % 2 else torch.int64
+        mt = torch.int32 if case % 3 else torch.int64
+        kw = dict(attention_mask=None if mask is None else mask.to(mt).cuda(), lens=None if lens is None else lens.int().cuda())
+        a = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=False, **kw)
+        b = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), stream_form=per_cu, **kw)
+        assert torch.equal(a, b), (case, D, S, V, N, kind, per_cu)
+        if N <= 700:
+            close(b, orc.gather_pool_normalize(table, ids.clamp(0, V - 1), eff), atol=2e-6)
+        ws = ops._scratch(torch.device("cuda", torch.cuda.current_device()), int(lib.tt_gather_pool_stream_workspace_bytes()))
+        adm, cus, mx = C.c_int32(), C.c_int32(), C.c_int32()
+        assert lib.tt_gather_pool_stream_census(ws.data_ptr(), C.byref(adm), C.byref(cus), C.byref(mx),
+                                                torch.cuda.current_stream().cuda_stream) == 0
+        n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+        assert 1 <= adm.value <= min(N, per_cu * n_cu) and 1 <= cus.value <= n_cu, (adm.value, cus.value, mx.value)
+        assert adm.value <= per_cu * cus.value
+
+
+def test_pool_stream_registry_keys_are_compute_units(tt):
+    """The registry key (XCC id + SE / SH / CU bits of HW_ID) names a physical compute unit: a launch of far more
+    workgroups than the chip holds registers on exactly `multi_processor_count` distinct keys and admits exactly
+    one workgroup on each of them with workgroups_per_cu = 1."""
+    import ctypes as C
+
+    from two_towers_overlords_amd import _lib
+
+    ops, _ = tt
+    lib = _lib.load()
+    V, D, S, N = 4000, 768, 256, 40000
+    gen = torch.Generator().manual_seed(5)
+    table = torch.randn(V, D, generator=gen).cuda()
+    ids = torch.randint(0, V, (N, S), generator=gen, dtype=torch.int32).cuda()
+    out = ops.gather_pool_norm(table, ids, stream_form=1)
+    ws = ops._scratch(torch.device("cuda", torch.cuda.current_device()), int(lib.tt_gather_pool_stream_workspace_bytes()))
+    adm, cus, mx = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.tt_gather_pool_stream_census(ws.data_ptr(), C.byref(adm), C.byref(cus), C.byref(mx),
+                                            torch.cuda.current_stream().cuda_stream) == 0
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert cus.value == n_cu and adm.value == n_cu, (adm.value, cus.value, mx.value, n_cu)
+    assert torch.equal(out, ops.gather_pool_norm(table, ids, sliced=False))
 
 
 # --------------------------------------------------------------------------- K1 through a token store (f3)

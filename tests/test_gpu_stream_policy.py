@@ -1,0 +1,29 @@
+"""Kernel variants that a policy picks inside the engine, forced here for every shape of the parity suite.
+The kernels the engine pairs with the streaming gather (BASELINE.json configs[3]): 128x128 projection tiles with
+K-step 16 (NT / NN / split-K TN) in the XCD-aware workgroup order.  They are selected by policy inside the engine;
+here the A/B environment knobs force them for EVERY shape the parity suite knows (the knobs are read once per
+process, hence the child process), so odd shapes, edge tiles and the scalar path go through them as well."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env", [
+    {"TT_TILE": "22", "TT_BK": "16", "TT_TN_TILE": "22", "TT_XCD": "1"},
+    {"TT_XCD": "1"},                      # the XCD-aware order over the default tiles (64x64, 128x64, 128x128 K-step 32)
+    {"TT_TILE": "21", "TT_XCD": "1"},
+    {"TT_G16": "1"},                      # 96x96 tiles on the 16x16x4 MFMA (gemm16.hip) for every forward / dH product
+])
+def test_parity_suite_under_the_stream_policy_kernels(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "projection or engine_matches_reference_golden or engine_vs_oracle or awkward or neg_index or "
+                              "feature_cache or metric_size"],
+                       capture_output=True, text=True, env=e, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

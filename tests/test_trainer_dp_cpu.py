@@ -236,3 +236,45 @@ def test_trainer_state_dict_resumes_exactly(accum):
     lb.append(c.train_epoch(gbs))
     assert la == lb and a.step_count == c.step_count and a._micro == c._micro
     assert torch.equal(a.flat, c.flat) and torch.equal(a.exp_avg, c.exp_avg) and torch.equal(a.exp_avg_sq, c.exp_avg_sq)
+
+
+def _worker_split(rank, world, port, accum, q):
+    """One epoch with the exchange in one bucket, then the same epoch from the same start with TT_DP_SPLIT's two-part
+    exchange (second-layer gradients first, first-layer gradients after): same per-element sums, so with two replicas
+    the parameters must be bitwise equal.  The last global batch holds one triplet: rank 1's shard is empty."""
+    try:
+        from oracle_engine import OracleEngine
+        from two_towers_overlords_amd.training import TripletTrainer, shard_batch
+
+        torch.set_num_threads(1)
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        table, params, batches = _setup()
+        gbs = _global_batches(batches)
+        gbs.append(tuple(None if t is None else t[:, :1].contiguous() for t in gbs[0]))
+        gbs.append(gbs[1])
+        out = {}
+        for split in (False, True):
+            tr = TripletTrainer(table=table, params={k: v.clone() for k, v in params.items()}, max_batch=B, max_seq_len=S,
+                                margin=0.3, lr=1e-3, accumulation_steps=accum, engine=OracleEngine(table, P, B, S),
+                                split_exchange=split)
+            assert tr._split == split
+            shards, sizes = zip(*(shard_batch(gb, rank, world) for gb in gbs))
+            avg = tr.train_epoch(list(shards), global_batch_sizes=list(sizes))
+            out[split] = (avg, tr.flat.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.step_count)
+        same = all(torch.equal(a, b) for a, b in zip(out[False][1:4], out[True][1:4]))
+        if rank == 0:
+            q.put((same, (out[False][0], out[True][0]), (out[False][4], out[True][4])))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+
+        q.put(("error", f"rank {rank}: {e}\n{traceback.format_exc()}", None))
+        raise
+
+
+@pytest.mark.parametrize("accum", [1, 2])
+def test_split_exchange_is_bitwise_the_one_bucket_exchange(accum):
+    same, avgs, steps = _run(2, accum, worker=_worker_split)
+    assert same and avgs[0] == avgs[1] and steps[0] == steps[1] == 6 // accum

@@ -6,7 +6,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-short = lambda n: ("K1 gather" if "pool_sliced" in n else "K1 combine" if "pool_combine" in n else "K1 per-text" if "pool_norm" in n else
+short = lambda n: ("K1 gather" if "pool_sliced" in n else "K1 combine" if "pool_combine" in n else "K1 stream" if "pool_norm_stream" in n else "K1 per-text" if "pool_norm" in n else
                    "dW2+dH (TN+NN)" if "gemm_tn_nn" in n else "adam" if "adam_kernel" in n else "triplet+mean" if "triplet_kernel" in n and "true" in n else
                    "triplet" if "triplet_kernel" in n else "loss mean" if "loss_mean" in n else
                    ("gemm TN" if "<2," in n.split("gemm_f32_kernel")[-1][:4] else "gemm NN" if "<1," in n.split("gemm_f32_kernel")[-1][:4] else "gemm NT") if "gemm_f32_kernel" in n else n[:30])

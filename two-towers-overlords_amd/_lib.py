@@ -55,6 +55,11 @@ SIGNATURES = {
     "tt_gather_pool_sliced_workspace_bytes": (_sz, [_i64, _i]),
     "tt_k1_prefers_sliced": (_i, [_i64, _i, _i64, _i]),
     "tt_gather_pool_norm_sliced_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _vp]),
+    "tt_gather_pool_stream_workspace_bytes": (_sz, []),
+    "tt_k1_stream_supported": (_i, [_i, _vp, _vp]),
+    "tt_k1_prefers_stream": (_i, [_i64, _i, _i64, _i]),
+    "tt_gather_pool_norm_stream_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _i, _vp]),
+    "tt_gather_pool_stream_census": (_i, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "tt_pool_norm_dense_f32": (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _i, _vp]),
     "tt_embed_gather_f32": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _vp]),
     "tt_proj_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
@@ -85,6 +90,9 @@ SIGNATURES = {
     "tt_engine_dout": (_vp, [_vp]),
     "tt_engine_add_loss": (_i, [_vp, _vp, _vp]),
     "tt_engine_reduce_grads": (_i, [_vp, _vp, _i, _vp]),
+    "tt_engine_k1_census": (_i, [_vp, _i, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
+    "tt_engine_reduce_grads_range": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
+    "tt_engine_set_dw2_event": (_i, [_vp, _vp]),
     "tt_engine_adam": (_i, [_vp, _vp, _d, _d, _d, _d, _i64, _vp]),
     "tt_engine_adam_auto": (_i, [_vp, _vp, _d, _d, _d, _d, _vp]),
     "tt_engine_set_step": (_i, [_vp, _i64, _vp]),

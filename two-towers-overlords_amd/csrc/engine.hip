@@ -20,6 +20,10 @@ int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, cons
                         void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st,
                         const int32_t* text_rows, int64_t n_store);
 int tt_k1_sliced_supported(int S, int D, const float* table, const float* out);
+int tt_k1_stream_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                        const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                        void* workspace, size_t workspace_bytes, int per_cu, unsigned lds_total, hipStream_t st,
+                        const int32_t* text_rows, int64_t n_store);
 int tt_launch_adam_auto(float* params, const float* grads, int nslabs, long long slab_stride, float* exp_avg,
                         float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
                         long long* dev_step, float* dev_scal, hipStream_t st);
@@ -30,7 +34,8 @@ int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float
                            long long B, int P, float* pos_dist, float* neg_dist, float* hinge_rows,
                            float* dq, float* dp, float* dn, const int* neg_index, hipStream_t st,
                            float* mean_partials = nullptr, unsigned* mean_ticket = nullptr, float mean_denom = 1.f,
-                           float* mean_loss = nullptr, double* acc_sum = nullptr, long long* acc_count = nullptr);
+                           float* mean_loss = nullptr, double* acc_sum = nullptr, long long* acc_count = nullptr,
+                           int* csr_ws = nullptr);
 
 struct tt_engine {
   uint32_t magic;
@@ -49,6 +54,10 @@ struct tt_engine {
   float* pooled[TT_ENGINE_SLOTS];
   float* k1_partial[TT_ENGINE_SLOTS];  // XCD-sliced K1: per-slice partial sums + mask sums of one batch
   size_t k1_partial_bytes;
+  void* k1_stream_ctl[TT_ENGINE_SLOTS];  // streaming K1 (HBM-resident tables): queue head + per-CU registry of one launch
+  bool k1_stream;                        // cfg says the streaming form applies (table far beyond the Infinity Cache)
+  int k1_stream_wgs;                     // gather workgroups kept per compute unit
+  unsigned k1_stream_lds;                // LDS a streaming gather workgroup occupies (0: its own 12 KB)
   // sharing with the gathers (cfg.k1_blocks_per_cu != 0), see gather_pool.hip "Sharing the chip"
   bool shared;           // gathers run beside phase B on another stream
   bool tile_above;       // sliced K1 reserved just above the 64x64 projection tile's LDS (else: capped K1, 128x64 tiles)
@@ -67,6 +76,7 @@ struct tt_engine {
   int32_t* oob;
   float* mean_partials;  // per-workgroup hinge sums of the triplet kernel (in-launch loss mean)
   unsigned* mean_ticket;
+  int* neg_csr;         // 4 * max_B + 1 ints: sources of every negative-by-index destination row (large batches)
   long long* dev_step;  // optimizer steps taken, device copy (tt_engine_adam_auto)
   float* dev_scal;      // {step_size, bc2_sqrt} of the current device step
   // second stream: dW2/db2 run there, under the dH -> dW1/db1 chain (see backward_chain)
@@ -74,6 +84,7 @@ struct tt_engine {
   hipEvent_t ev_fork, ev_join;
   bool gathers_share_chip;  // tt_engine_set_sharing: token-id gathers are running beside phase B
   int bwd_mode;             // tt_engine_set_backward: TT_BWD_AUTO / TT_BWD_FORK / TT_BWD_FUSED
+  hipEvent_t ev_dw2;        // tt_engine_set_dw2_event: recorded once the dW2 / db2 slabs are complete (may be null)
   int env_bwd;              // TT_BWD read once at creation: -1 unset, 0 "fused", 1 "fork" (A/B runs)
 };
 
@@ -102,6 +113,9 @@ void carve(tt_engine* e, char* base, size_t* total) {
                             ? tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D) : 0;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i)
     e->k1_partial[i] = e->k1_partial_bytes ? c.take<float>(e->k1_partial_bytes / sizeof(float)) : nullptr;
+  e->k1_stream = tt_k1_prefers_stream(e->cfg.V, e->cfg.D, (int64_t)1 << 40, 512) != 0;
+  for (int i = 0; i < TT_ENGINE_SLOTS; ++i)
+    e->k1_stream_ctl[i] = e->k1_stream ? c.take<char>(tt_gather_pool_stream_workspace_bytes()) : nullptr;
   e->H = c.take<float>(rows * e->cfg.P);
   e->emb = c.take<float>(rows * e->cfg.P);
   e->dOut = c.take<float>(rows * e->cfg.P);
@@ -116,6 +130,7 @@ void carve(tt_engine* e, char* base, size_t* total) {
   e->oob = c.take<int32_t>(4);
   e->mean_partials = c.take<float>((size_t)e->cfg.max_B / 4 + 4);
   e->mean_ticket = c.take<unsigned>(4);
+  e->neg_csr = c.take<int>(4 * (size_t)e->cfg.max_B + 1);
   e->dev_step = c.take<long long>(2);
   e->dev_scal = c.take<float>(4);
   *total = c.off;
@@ -177,6 +192,10 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
   e->env_bwd = -1;
   if (const char* v = getenv("TT_BWD"))  // "fork" / "fused" force a schedule (A/B runs); anything else: automatic
     if (v[0] == 'f') e->env_bwd = (v[1] == 'o') ? 1 : 0;
+  e->k1_stream_wgs = 2;  // two 4-wave workgroups x 6 rows x C KiB in flight per CU; leaves room for two 128x128 K-step-16 tiles
+  if (const char* v = getenv("TT_K1_STREAM_WGS")) e->k1_stream_wgs = atoi(v) >= 1 && atoi(v) <= 8 ? atoi(v) : 2;  // A/B
+  e->k1_stream_lds = 0;
+  if (const char* v = getenv("TT_K1_STREAM_LDS_KB")) e->k1_stream_lds = (unsigned)(atoi(v) > 0 && atoi(v) <= 160 ? atoi(v) : 0) * 1024u;
   e->shared = cfg->k1_blocks_per_cu != 0;
   e->tile_above = cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO && e->k1_partial_bytes != 0 &&
                   tt_k1_prefers_sliced(cfg->V, cfg->D, 3 * (int64_t)cfg->max_B, cfg->max_S);
@@ -245,6 +264,13 @@ static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, con
   if (e->shared)
     lds_total = e->tile_above ? (unsigned)ttp::chain_lds_bytes(3 * (long long)e->cfg.max_B, e->cfg.P, ttp::kTileSmall) + 3072u
                               : tt_k1_lds_for_cap(e->cap);
+  // streaming form beside the projection chain when the table really comes from HBM (gather_pool.hip)
+  if (e->k1_stream && e->shared && e->cfg.k1_blocks_per_cu == TT_K1_SHARE_AUTO &&
+      tt_k1_prefers_stream(e->cfg.V, e->cfg.D, roles * (int64_t)B, S) &&
+      tt_k1_stream_supported(e->cfg.D, e->table, e->pooled[slot]))
+    return tt_k1_stream_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B, S,
+                               e->cfg.D, e->cfg.V, e->oob, e->k1_stream_ctl[slot], tt_gather_pool_stream_workspace_bytes(),
+                               e->k1_stream_wgs, e->k1_stream_lds, static_cast<hipStream_t>(stream), text_rows, n_store);
   // XCD-sliced form where it is the faster one (table several times an XCD's L2, see tt_k1_prefers_sliced)
   if (e->k1_partial_bytes && tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, roles * (int64_t)B, S) &&
       tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot])) {
@@ -320,6 +346,7 @@ static void fill_towers(tt_engine* e, int slot, int32_t B, int32_t doc_rows, ttp
 //          mean also loses (its ticket round trip queues behind the gather's loads).
 // projection tiles that pair with how the gathers are reserved (gather_pool.hip "Sharing the chip")
 static int tile_policy(const tt_engine* e) {
+  if (e->shared && e->k1_stream && e->cfg.k1_blocks_per_cu == TT_K1_SHARE_AUTO) return ttp::kTileStream;
   return !e->shared ? ttp::kTileAuto : (e->tile_above ? ttp::kTileSmall : ttp::kTileLowTraffic);
 }
 
@@ -342,7 +369,8 @@ static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_r
     }
     rc = ttp::backward_dw2_dh(t, 2, D, P, e->nslabs, e->slab_stride, st, shared);
     if (rc != TT_OK) return rc;
-    return ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
+    if (e->ev_dw2) TT_HIP(hipEventRecord(e->ev_dw2, st));
+    return ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st, shared);
   }
   TT_HIP(hipEventRecord(e->ev_fork, st));
   TT_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
@@ -350,12 +378,13 @@ static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_r
     rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, e->aux);
     if (rc != TT_OK) return rc;
   }
-  rc = ttp::backward_dw2(t, 2, D, P, e->nslabs, e->slab_stride, e->aux);
+  rc = ttp::backward_dw2(t, 2, D, P, e->nslabs, e->slab_stride, e->aux, shared);
   if (rc != TT_OK) return rc;
+  if (e->ev_dw2) TT_HIP(hipEventRecord(e->ev_dw2, e->aux));
   TT_HIP(hipEventRecord(e->ev_join, e->aux));
   rc = ttp::backward_dh(t, 2, D, P, st, shared);
   if (rc != TT_OK) return rc;
-  rc = ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st);
+  rc = ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st, shared);
   if (rc != TT_OK) return rc;
   TT_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
   return TT_OK;
@@ -379,14 +408,15 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
   const float* n = neg_index ? p : e->emb + 2 * (int64_t)B * P;
   if (use_fork(e)) {  // loss mean as its own launch on the second stream
     rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
-                                e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st);
+                                e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st, nullptr, nullptr, 1.f,
+                                nullptr, nullptr, nullptr, e->neg_csr);
     if (rc != TT_OK) return rc;
     return backward_chain(e, t, B, loss_denominator, st);
   }
   // the batch loss is reduced inside the triplet launch (last workgroup), not by a launch of its own
   rc = tt_launch_triplet_rows(q, p, n, margin, grad_scale, B, P, e->pos_dist, e->neg_dist, e->hinge, e->dOut,
                               e->dOut + (int64_t)B * P, e->dOut + 2 * (int64_t)B * P, neg_index, st,
-                              e->mean_partials, e->mean_ticket, loss_denominator, e->loss, e->loss_sum, e->loss_cnt);
+                              e->mean_partials, e->mean_ticket, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, e->neg_csr);
   if (rc != TT_OK) return rc;
   return backward_chain(e, t, 0, 1.f, st);
 }
@@ -433,6 +463,33 @@ extern "C" int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumul
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(grad_out, TT_ERR_NULL_POINTER);
   return tt_reduce_slabs_f32(e->slabs, e->nslabs, e->slab_stride, grad_out, e->nparam, accumulate, stream);
+}
+
+extern "C" int tt_engine_reduce_grads_range(tt_engine* e, float* grad_out, int64_t offset, int64_t count,
+                                            int accumulate, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(grad_out, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(offset >= 0 && count >= 0 && offset + count <= e->nparam, TT_ERR_BAD_SHAPE);
+  return tt_reduce_slabs_f32(e->slabs + offset, e->nslabs, e->slab_stride, grad_out + offset, count, accumulate, stream);
+}
+
+extern "C" int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  e->ev_dw2 = static_cast<hipEvent_t>(event);
+  return TT_OK;
+}
+
+extern "C" int tt_engine_k1_census(tt_engine* e, int slot, int32_t* admitted, int32_t* cus_used, int32_t* max_registered,
+                                   tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
+  if (!e->k1_stream_ctl[slot]) {  // the streaming form is not in use for this table
+    if (admitted) *admitted = 0;
+    if (cus_used) *cus_used = 0;
+    if (max_registered) *max_registered = 0;
+    return TT_OK;
+  }
+  return tt_gather_pool_stream_census(e->k1_stream_ctl[slot], admitted, cus_used, max_registered, stream);
 }
 
 extern "C" int tt_engine_adam(tt_engine* e, const float* grads, double lr, double beta1, double beta2,

@@ -116,18 +116,15 @@ __device__ __forceinline__ void pool_group_lds(unsigned long long& mine, const f
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is overwritten by the next group's DMA
 }
 
+// One text by one 4-wave workgroup (see the file header).  `part` / `red` / `stage` are the workgroup's LDS.
 // C = float4 chunks per lane = ceil(D/4/64); U = rows in flight per wave.
 // LDS_STAGE: the A/B variant above (token-id gathers only).
-template <typename IdT, typename MaskT, int C, int U, bool DENSE, bool LDS_STAGE = false>
-__global__ __launch_bounds__(kThreads) void pool_norm_kernel(
+template <typename IdT, typename MaskT, int C, int U, bool DENSE, bool LDS_STAGE>
+__device__ __forceinline__ void pool_one_text(
+    long long text, float4 (*part)[C * TT_WAVE], float* red, float* stage,
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, int S, int D, long long V,
     int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
-  __shared__ float4 part[kWavesPerText][C * TT_WAVE];
-  __shared__ float red[kWavesPerText];
-  __shared__ __attribute__((aligned(16))) float stage[LDS_STAGE ? kWavesPerText * U * C * 256 : 4];
-
-  const long long text = blockIdx.x;
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int nchunk = D >> 2;
@@ -177,6 +174,11 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
       pool_group<U, C, DENSE>(mine, src, id, w, drow0, D, lane, last_ok, acc);
       cnt -= U;
     }
+    // the rest (< U positions) in groups of 8 / 4 / 2 / 1: any U works, positions stay in ascending order
+    if (U > 8 && cnt >= 8) {
+      pool_group<8, C, DENSE>(mine, src, id, w, drow0, D, lane, last_ok, acc);
+      cnt -= 8;
+    }
     if (U > 4 && cnt >= 4) {
       pool_group<4, C, DENSE>(mine, src, id, w, drow0, D, lane, last_ok, acc);
       cnt -= 4;
@@ -222,6 +224,78 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
     o.z = m.z / dn;
     o.w = m.w / dn;
     reinterpret_cast<float4*>(out + text * (long long)D)[t] = o;
+  }
+}
+
+template <typename IdT, typename MaskT, int C, int U, bool DENSE, bool LDS_STAGE = false>
+__global__ __launch_bounds__(kThreads) void pool_norm_kernel(
+    const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
+    const int* __restrict__ lens, float* __restrict__ out, int S, int D, long long V,
+    int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
+  __shared__ float4 part[kWavesPerText][C * TT_WAVE];
+  __shared__ float red[kWavesPerText];
+  __shared__ __attribute__((aligned(16))) float stage[LDS_STAGE ? kWavesPerText * U * C * 256 : 4];
+  pool_one_text<IdT, MaskT, C, U, DENSE, LDS_STAGE>(blockIdx.x, part, red, stage, src, ids, mask, lens, out, S, D, V,
+                                                    oob_flag, text_rows, n_store);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming K1 for tables that really come from HBM (far beyond the 256 MiB Infinity Cache), built to run BESIDE
+// the projection chain of another stream.  There the gather is bandwidth-bound and wants a fixed amount of loads
+// in flight on every CU for its whole duration (two 4-wave workgroups = 96 KB at D = 768), and the MFMA kernels
+// want the rest of the CU.  A grid of one workgroup per text cannot hold that balance: which stream's workgroup
+// takes the registers / LDS a finished one leaves is the dispatcher's choice, and measured at
+// BASELINE.json configs[3] either the gathers crowd the GEMM tiles out (chain 3.5 -> 7.8 ms) or an LDS reservation
+// keeps them to a CU they then share one-for-one with a tile (K1 5.2 -> 6.8 ms) — 7.5 ms per step both ways.
+// Here residency is explicit instead:
+//   * persistent workgroups pull texts from a queue head (one relaxed atomic per 0.8 MB of rows);
+//   * a workgroup first registers on ITS compute unit (XCC id + SE/SH/CU bits of HW_ID -> a counter per CU); when
+//     `per_cu` workgroups are already registered there it leaves at once, so no CU ever hosts more gather waves
+//     than planned, whatever the dispatcher does, and the MFMA kernels keep the rest.
+// Placement decides speed only: every text is pooled by exactly one workgroup, with the arithmetic of
+// pool_norm_kernel (same order => bitwise the same output).  No wave ever waits for another workgroup.
+constexpr int kCuSlots = 4096;  // 4 bits of XCC id x 8 bits of SE / SH / CU id
+struct StreamCtl {
+  int head;            // next text to hand out
+  int admitted;        // workgroups that registered successfully (diagnostic)
+  int pad[2];
+  int cu[kCuSlots];    // registered workgroups per compute unit
+};
+
+__device__ __forceinline__ unsigned tt_cu_key() {
+  // s_getreg_b32 simm16 = (size - 1) << 11 | offset << 6 | id;  HW_REG_HW_ID = 4, HW_REG_XCC_ID = 20
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID[3:0]
+  return ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);                  // CU_ID[11:8], SH_ID[12], SE_ID[15:13]
+}
+
+template <typename IdT, typename MaskT, int C, int U>
+__global__ __launch_bounds__(kThreads) void pool_norm_stream_kernel(
+    const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
+    const int* __restrict__ lens, float* __restrict__ out, long long N, int S, int D, long long V,
+    int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store, StreamCtl* __restrict__ ctl,
+    int per_cu) {
+  __shared__ float4 part[kWavesPerText][C * TT_WAVE];
+  __shared__ float red[kWavesPerText];
+  __shared__ int s_next;
+  if (threadIdx.x == 0) {
+    int next = -1;
+    if (atomicAdd(&ctl->cu[tt_cu_key()], 1) < per_cu) {
+      atomicAdd(&ctl->admitted, 1);
+      next = atomicAdd(&ctl->head, 1);
+    }
+    s_next = next;
+  }
+  __syncthreads();
+  long long text = s_next;
+  while (text >= 0 && text < N) {
+    // the next text's number travels through LDS; thread 0 asks for it now, everyone reads it after the two
+    // barriers inside pool_one_text (so the write below cannot overtake this iteration's read above)
+    pool_one_text<IdT, MaskT, C, U, false, false>(text, part, red, nullptr, src, ids, mask, lens, out, S, D, V, oob_flag,
+                                                  text_rows, n_store);
+    if (threadIdx.x == 0) s_next = atomicAdd(&ctl->head, 1);
+    __syncthreads();
+    text = s_next;
   }
 }
 
@@ -628,6 +702,41 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   return TT_OK;
 }
 
+template <typename IdT, typename MaskT>
+int launch_stream(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
+                  int S, int D, int64_t V, int32_t* oob, void* ctl_ws, int per_cu, unsigned lds_total, hipStream_t st,
+                  const int32_t* text_rows, int64_t n_store) {
+  const IdT* ids_t = static_cast<const IdT*>(ids);
+  const MaskT* mask_t = static_cast<const MaskT*>(mask);
+  StreamCtl* ctl = static_cast<StreamCtl*>(ctl_ws);
+  TT_HIP(hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
+  // twice the workgroups the chip may keep: those that find their CU full leave at once
+  long long wgs = 2LL * per_cu * cu_count();
+  if (wgs > N) wgs = N;
+  const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
+  // rows in flight per wave: TT_K1_STREAM_U (A/B) or 96 KB per workgroup (4 waves x U rows x C KiB)
+  static const int env_u = getenv("TT_K1_STREAM_U") ? atoi(getenv("TT_K1_STREAM_U")) : 0;
+#define TT_STREAM_CASE(CC, UU)                                                                               \
+  hipLaunchKernelGGL((pool_norm_stream_kernel<IdT, MaskT, CC, UU>), dim3((unsigned)wgs), dim3(kThreads),     \
+                     k1_dynamic_lds(lds_total, CC * 4096u + 32u), st, table, ids_t, mask_t, lens, out,       \
+                     (long long)N, S, D, (long long)V, oob, text_rows, (long long)n_store, ctl, per_cu)
+  switch (C) {
+    case 1: if (env_u == 8) TT_STREAM_CASE(1, 8); else TT_STREAM_CASE(1, 16); break;
+    case 2: if (env_u == 8) TT_STREAM_CASE(2, 8); else TT_STREAM_CASE(2, 12); break;
+    case 3:  // D in (512, 768]: U rows x 3 KiB in flight per wave
+      if (env_u == 4) TT_STREAM_CASE(3, 4);
+      else if (env_u == 5) TT_STREAM_CASE(3, 5);
+      else if (env_u == 7) TT_STREAM_CASE(3, 7);
+      else if (env_u == 8) TT_STREAM_CASE(3, 8);
+      else TT_STREAM_CASE(3, 6);
+      break;
+    default: if (env_u == 4) TT_STREAM_CASE(4, 4); else TT_STREAM_CASE(4, 5); break;
+  }
+#undef TT_STREAM_CASE
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
 }  // namespace
 
 // internal (engine.hip): K1 with an LDS reservation (0 = none)
@@ -736,4 +845,66 @@ extern "C" int tt_gather_pool_norm_sliced_f32(const float* table, const void* id
                                               tt_stream_t stream) {
   return tt_k1_sliced_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, workspace,
                              workspace_bytes, 0, static_cast<hipStream_t>(stream), nullptr, 0);
+}
+
+extern "C" size_t tt_gather_pool_stream_workspace_bytes(void) { return sizeof(StreamCtl); }
+
+extern "C" int tt_k1_stream_supported(int D, const float* table, const float* out) {
+  return (D % 4 == 0) && D <= 1024 && tt_aligned16(table) && tt_aligned16(out);
+}
+
+// The streaming form pays where the gather is HBM-bound: a table several times the 256 MiB Infinity Cache.
+extern "C" int tt_k1_prefers_stream(int64_t V, int D, int64_t N, int S) {
+  if (D < 4 || (D % 4) != 0 || D > 1024 || S < 1 || V < 1 || N < 1) return 0;
+  if (const char* v = getenv("TT_K1_STREAM"))  // A/B override
+    if (*v) return *v != '0';
+  return (double)V * D * 4.0 >= 400e6 && (double)N * S >= 1048576.0;
+}
+
+// internal (engine.hip) + public: the streaming form.  Same contract as tt_gather_pool_norm_f32.
+int tt_k1_stream_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                        const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                        void* workspace, size_t workspace_bytes, int per_cu, unsigned lds_total, hipStream_t st,
+                        const int32_t* text_rows, int64_t n_store) {
+  TT_REQUIRE(table && ids && out && workspace, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(!text_rows || n_store >= 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x3fffffffLL, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(per_cu >= 1 && per_cu <= 8, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  TT_REQUIRE(tt_k1_stream_supported(D, table, out) && tt_aligned16(workspace), TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(workspace_bytes >= sizeof(StreamCtl), TT_ERR_WORKSPACE);
+  if (N == 0) return TT_OK;
+  const int md = mask ? mask_dtype : TT_I32;
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_stream<int32_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, lds_total, st, text_rows, n_store);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_stream<int32_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, lds_total, st, text_rows, n_store);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_stream<int64_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, lds_total, st, text_rows, n_store);
+  return launch_stream<int64_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, lds_total, st, text_rows, n_store);
+}
+
+extern "C" int tt_gather_pool_norm_stream_f32(const float* table, const void* ids, int ids_dtype, const void* mask,
+                                              int mask_dtype, const int32_t* lens, float* out, int64_t N, int S, int D,
+                                              int64_t V, int32_t* oob_flag, void* workspace, size_t workspace_bytes,
+                                              int workgroups_per_cu, tt_stream_t stream) {
+  return tt_k1_stream_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, workspace,
+                             workspace_bytes, workgroups_per_cu, 0, static_cast<hipStream_t>(stream), nullptr, 0);
+}
+
+// Diagnostic: what the last streaming launch that used `workspace` did — workgroups admitted, compute units that
+// hosted at least one, the largest count registered on one CU (admitted + turned away).  Synchronises `stream`.
+extern "C" int tt_gather_pool_stream_census(const void* workspace, int32_t* admitted, int32_t* cus_used,
+                                            int32_t* max_registered, tt_stream_t stream) {
+  TT_REQUIRE(workspace, TT_ERR_NULL_POINTER);
+  static StreamCtl host;  // 16 KB: not on the stack
+  TT_HIP(hipMemcpyAsync(&host, workspace, sizeof(StreamCtl), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+  TT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  int used = 0, mx = 0;
+  for (int i = 0; i < kCuSlots; ++i) {
+    used += host.cu[i] > 0;
+    mx = host.cu[i] > mx ? host.cu[i] : mx;
+  }
+  if (admitted) *admitted = host.admitted;
+  if (cus_used) *cus_used = used;
+  if (max_registered) *max_registered = mx;
+  return TT_OK;
 }

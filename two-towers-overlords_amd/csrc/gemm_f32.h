@@ -15,7 +15,22 @@ enum Epilogue : int {
   kStore = 0,     // C = acc
   kBias = 1,      // C = acc + bias[n]
   kBiasRelu = 2,  // C = max(acc + bias[n], 0)
-  kReluMask = 3   // C = aux[m,n] > 0 ? acc : 0
+  kReluMask = 3,  // C = aux[m,n] > 0 ? acc : 0
+  kHinge = 4      // in-batch-negatives loss (inbatch.hip): acc = S[m,n] = cos(q_m, d_n); C = dL/dS[m,n], see HingeEpi
+};
+
+// kHinge: C[m,n] = g where n is a valid negative of query m and S[m,n] - s_pos[m] + margin > 0, else 0; every
+// workgroup also leaves its rows' hinge sums and active counts in part_loss / part_cnt [M, n_tiles] (column-tile
+// major per row), which a finishing pass adds up in tile order (fixed order: bitwise reproducible).
+struct HingeEpi {
+  const int* pos_index;        // [M] column of the positive (null: the diagonal)
+  const long long* qid_q;      // [M] query ids (null: none)
+  const long long* qid_d;      // [N]
+  const float* s_pos;          // [M] S[m, pos_m]
+  float margin, g;
+  float* part_loss;
+  float* part_cnt;
+  int n_tiles;                 // column tiles of the launch (row stride of the partials)
 };
 
 struct Problem {
@@ -37,16 +52,31 @@ struct Batch {
   int count;            // problems in this launch (blockIdx.z / nsplit selects)
   int nsplit;           // split-K factor (kTN, else 1); split z writes C + z*slab_stride
   long long slab_stride;  // floats between consecutive split slabs of C / colsum
+  // XCD-aware workgroup order (1-D grid; workgroups with equal index % 8 share an XCD — a placement label, speed
+  // only): tiles that re-read the same operand block run on ONE XCD, back to back, so the block crosses the fabric
+  // once instead of once per tile.  kNT / kNN: the n-tiles of a row panel; kTN: all tiles of one split-K slab.
+  // Worth it where the fabric is the shared bottleneck (beside the streaming gather); 0 = plain 3-D grid.
+  HingeEpi hinge;  // kHinge only
+  int xcd_order;
+  int gx, gy, gz;         // tile grid (filled by the launcher when xcd_order is set)
 };
 
 // Static LDS of one workgroup of the (layout, wm, wn) kernel, in bytes.
-size_t tile_lds_bytes(Layout layout, int wm, int wn);
+size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk = 32);
 
 // Launches one grouped GEMM.  wm/wn pick the block tile: (64*wm) x (64*wn).
-int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st);
+// bk: K-step, 32 or 16 (16 only changes the 128x128 kNT / kNN tiles: 40 KB of LDS instead of 72).
+int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st, int bk = 32);
 
 // One launch for an independent (kTN split-K, kStore) + (kNN, kReluMask) pair; falls back to two
 // launches for shapes the vector path does not cover.
 int launch_tn_nn_pair(const Batch& tn, const Batch& nn, int wm, int wn, hipStream_t st);
+
+// 96x96 tiles on v_mfma_f32_16x16x4_f32 (gemm16.hip): kNT with kBias / kBiasRelu and kNN with kReluMask, no split-K.
+// For output shapes that 64x64 tiles cut badly — [6144 x 384] is 576 tiles of 64x64 (2.25 per CU) but exactly 256
+// of 96x96.  Same numerics (k-ordered fp32 fmaf chains).
+bool gemm16_supported(Layout layout, Epilogue epi, const Batch& b);
+size_t gemm16_lds_bytes();
+int launch16(Layout layout, Epilogue epi, const Batch& b, hipStream_t st);
 
 }  // namespace ttg

@@ -27,9 +27,11 @@
 namespace ttg {
 namespace {
 
-constexpr int BK = 32;
-constexpr int BKP = BK + 4;
 constexpr int kThreads = 256;
+// K-step: 32 by default; 16 for the 128x128 tiles that share a CU with the streaming gather (half the operand
+// LDS — 40 KB instead of 72 — and 32 staging registers fewer, so two tiles AND the gather's waves stay resident).
+// A K-contiguous operand's LDS row is BK + 4 floats: 36 or 20 words = 9 or 5 sixteen-byte slots, both coprime
+// with the 16 slots of a bank row, so the 16-lane groups of ds_read_b128 stay conflict-free.
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -40,13 +42,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // under the MFMAs of tile t.  The scalar path (any shape) is correct, not fast.
 //
 // K-contiguous operand: tile [R rows][BK], element (row, k) at P[(r0+row)*ld + k0+k].
-template <int R, bool VEC, bool FULL>
+template <int R, int BK, bool VEC, bool FULL>
 __device__ __forceinline__ void gload_kc(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
                                          int ld, int r0, int rmax, int k0, int kend, int tid) {
 #pragma unroll
   for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
     const int f = tid + i * kThreads;
-    const int row = f >> 3, kq = f & 7;
+    const int row = f / (BK / 4), kq = f % (BK / 4);
     const int gr = r0 + row, gk = k0 + kq * 4;
     if (FULL) {  // interior tile: nothing to guard, so the load stays unconditional and countable
       v[i] = *reinterpret_cast<const float4*>(P + (long long)gr * ld + gk);
@@ -68,18 +70,18 @@ __device__ __forceinline__ void gload_kc(float4 (&v)[R * BK / 4 / kThreads], con
     }
   }
 }
-template <int R>
+template <int R, int BK>
 __device__ __forceinline__ void sstore_kc(const float4 (&v)[R * BK / 4 / kThreads], float* __restrict__ T, int tid) {
 #pragma unroll
   for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
     const int f = tid + i * kThreads;
-    const int row = f >> 3, kq = f & 7;
-    *reinterpret_cast<float4*>(T + row * BKP + kq * 4) = v[i];
+    const int row = f / (BK / 4), kq = f % (BK / 4);
+    *reinterpret_cast<float4*>(T + row * (BK + 4) + kq * 4) = v[i];
   }
 }
 // K-strided operand: tile [BK][R cols], element (k, col) at P[(k0+k)*ld + r0+col].
 // VEC additionally needs rmax % 4 == 0 (a 4-column chunk is all in or all out).
-template <int R, bool VEC, bool FULL>
+template <int R, int BK, bool VEC, bool FULL>
 __device__ __forceinline__ void gload_ks(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
                                          int ld, int r0, int rmax, int k0, int kend, int tid) {
   constexpr int RQ = R / 4;
@@ -108,7 +110,7 @@ __device__ __forceinline__ void gload_ks(float4 (&v)[R * BK / 4 / kThreads], con
     }
   }
 }
-template <int R>
+template <int R, int BK>
 __device__ __forceinline__ void sstore_ks(const float4 (&v)[R * BK / 4 / kThreads], float* __restrict__ T, int tid) {
   constexpr int RQ = R / 4;
 #pragma unroll
@@ -120,8 +122,9 @@ __device__ __forceinline__ void sstore_ks(const float4 (&v)[R * BK / 4 / kThread
 }
 
 // ---- LDS -> MFMA fragments: 4 values for k = 8j + 4h + {0,1,2,3} ------------------
+template <int BK>
 __device__ __forceinline__ float4 frag_kc(const float* __restrict__ T, int row, int j, int h) {
-  return *reinterpret_cast<const float4*>(T + row * BKP + 8 * j + 4 * h);
+  return *reinterpret_cast<const float4*>(T + row * (BK + 4) + 8 * j + 4 * h);
 }
 template <int R>
 __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, int j, int h) {
@@ -129,28 +132,34 @@ __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, 
   return make_float4(p[0], p[R], p[2 * R], p[3 * R]);
 }
 
-template <int LAYOUT, int WM, int WN>
+template <int LAYOUT, int WM, int WN, int BK = 32>
 struct TileCfg {
-  static constexpr int BM = 64 * WM, BN = 64 * WN;
+  static constexpr int BM = 64 * WM, BN = 64 * WN, BKP = BK + 4;
   static constexpr bool A_KC = (LAYOUT != kTN);
   static constexpr bool B_KC = (LAYOUT == kNT);
   static constexpr int A_TILE = A_KC ? BM * BKP : BK * BM;
   static constexpr int B_TILE = B_KC ? BN * BKP : BK * BN;
   static constexpr int CP = BN + 4;  // padded row of the epilogue's C tile
-  static constexpr int LDS_FLOATS = (2 * (A_TILE + B_TILE) > BM * CP) ? 2 * (A_TILE + B_TILE) : BM * CP;
+  // the C tile leaves through LDS in EP passes of BM / EP rows (one pass per wave row), so that it needs no more
+  // LDS than the operand buffers do when those are small (BK = 16)
+  static constexpr int EP = (2 * (A_TILE + B_TILE) >= BM * CP) ? 1 : WM;
+  static constexpr int EP_ROWS = BM / EP;
+  static constexpr int LDS_FLOATS = (2 * (A_TILE + B_TILE) > EP_ROWS * CP) ? 2 * (A_TILE + B_TILE) : EP_ROWS * CP;
 };
 
 // One workgroup's tile: (bx, by) tile coordinates, bz = group * nsplit + split.
-template <int LAYOUT, int EPI, int WM, int WN, bool VEC>
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32>
 __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ lds, int bx, int by, int bz) {
+  using Cfg = TileCfg<LAYOUT, WM, WN, BK>;
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr bool A_KC = (LAYOUT != kTN);
   constexpr bool B_KC = (LAYOUT == kNT);
-  constexpr int A_TILE = A_KC ? BM * BKP : BK * BM;
-  constexpr int B_TILE = B_KC ? BN * BKP : BK * BN;
+  constexpr int A_TILE = Cfg::A_TILE;
+  constexpr int B_TILE = Cfg::B_TILE;
   constexpr int NVA = BM * BK / 4 / kThreads, NVB = BN * BK / 4 / kThreads;
+  static_assert(NVA >= 1 && NVB >= 1, "a K-step of the tile is at least one 16-byte chunk per thread");
 
-  constexpr int CP = BN + 4;  // padded row of the epilogue's C tile
+  constexpr int CP = Cfg::CP;  // padded row of the epilogue's C tile
 
   const int grp = bz / b.nsplit;
   const int split = bz - grp * b.nsplit;
@@ -170,8 +179,9 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   const int m0 = by * BM, n0 = bx * BN;
   if (m0 >= M || n0 >= N) return;  // grouped launch: grid is sized for the largest problem
 
-  const int kbeg = (LAYOUT == kTN) ? min(K, split * kps) : 0;
-  const int kend = (LAYOUT == kTN) ? min(K, kbeg + kps) : K;
+  const bool ksplit = (LAYOUT == kTN) || b.nsplit > 1;  // split z covers k in [z * kps, (z + 1) * kps)
+  const int kbeg = ksplit ? min(K, split * kps) : 0;
+  const int kend = ksplit ? min(K, kbeg + kps) : K;
   const long long slab = (long long)split * b.slab_stride;
 
   const int tid = threadIdx.x;
@@ -199,16 +209,16 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   const bool full = VEC && (m0 + BM <= M) && (n0 + BN <= N) && ((kend - kbeg) % BK == 0);
   auto gload = [&](float4 (&ra)[NVA], float4 (&rb)[NVB], int k0, auto full_tag) {
     constexpr bool F = decltype(full_tag)::value;
-    if (A_KC) gload_kc<BM, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
-    else      gload_ks<BM, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
-    if (B_KC) gload_kc<BN, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
-    else      gload_ks<BN, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    if (A_KC) gload_kc<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+    else      gload_ks<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+    if (B_KC) gload_kc<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    else      gload_ks<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
   };
   auto sstore = [&](const float4 (&ra)[NVA], const float4 (&rb)[NVB], int buf) {
     float* As = lds + buf * (A_TILE + B_TILE);
     float* Bs = As + A_TILE;
-    if (A_KC) sstore_kc<BM>(ra, As, tid); else sstore_ks<BM>(ra, As, tid);
-    if (B_KC) sstore_kc<BN>(rb, Bs, tid); else sstore_ks<BN>(rb, Bs, tid);
+    if (A_KC) sstore_kc<BM, BK>(ra, As, tid); else sstore_ks<BM, BK>(ra, As, tid);
+    if (B_KC) sstore_kc<BN, BK>(rb, Bs, tid); else sstore_ks<BN, BK>(rb, Bs, tid);
   };
   auto compute = [&](int buf) {
     const float* __restrict__ As = lds + buf * (A_TILE + B_TILE);
@@ -219,12 +229,12 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const int row = (wrow * WM + i) * 32 + r;
-        fa[i] = A_KC ? frag_kc(As, row, j, h) : frag_ks<BM>(As, row, j, h);
+        fa[i] = A_KC ? frag_kc<BK>(As, row, j, h) : frag_ks<BM>(As, row, j, h);
       }
 #pragma unroll
       for (int i = 0; i < WN; ++i) {
         const int col = (wcol * WN + i) * 32 + r;
-        fb[i] = B_KC ? frag_kc(Bs, col, j, h) : frag_ks<BN>(Bs, col, j, h);
+        fb[i] = B_KC ? frag_kc<BK>(Bs, col, j, h) : frag_ks<BN>(Bs, col, j, h);
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
@@ -289,91 +299,189 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   // The tile goes through LDS (free after the K loop's last barrier) so that global
   // stores are whole 16-byte chunks of contiguous rows (4 per thread instead of 16
   // dword stores whose address registers the compiler serialises with vmcnt(0)).
+  // With EP > 1 (small operand buffers, BK = 16) it leaves in EP passes of EP_ROWS rows: pass `ep` is the rows of
+  // the waves with wrow == ep.
   float* __restrict__ Cs = lds;
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int jj = 0; jj < WN; ++jj) {
-      const int col = (wcol * WN + jj) * 32 + r;
-      const int rbase = (wrow * WM + i) * 32 + 4 * h;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) Cs[(rbase + (e & 3) + 8 * (e >> 2)) * CP + col] = acc[i][jj][e];
-    }
-  __syncthreads();
+  constexpr int EP = Cfg::EP, EP_ROWS = Cfg::EP_ROWS;
+  static_assert(EP == 1 || EP == WM, "one pass per wave row");
   const bool vecC = VEC && ((ldc & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(gC) & 15) == 0) &&
                     ((b.slab_stride & 3) == 0) &&
                     (EPI != kReluMask || (((ldaux & 3) == 0) && ((reinterpret_cast<uintptr_t>(gaux) & 15) == 0)));
-  constexpr int NI = BM * BN / 4 / kThreads;  // 16-byte chunks of the C tile per thread
+  constexpr int NI = EP_ROWS * BN / 4 / kThreads;  // 16-byte chunks of one pass per thread
   static_assert(kThreads % (BN / 4) == 0, "every chunk of a thread lies in the same 4 columns");
   const int c4 = (tid % (BN / 4)) * 4, n = n0 + c4;
   const int row_first = tid / (BN / 4);
   constexpr int ROW_STEP = kThreads / (BN / 4);
-  if (vecC && full) {
-    // Interior tile: no guards, so nothing splits the stores into exec-masked branches
-    // (each of which the compiler fences with vmcnt(0)).  All loads first (tile chunks from
-    // LDS, bias once, ReLU-mask rows), then NI stores back to back.
-    float4 v[NI], am[NI];
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI == kBias || EPI == kBiasRelu) bv = *reinterpret_cast<const float4*>(gbias + n);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int row = row_first + i * ROW_STEP;
-      v[i] = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
-      if (EPI == kReluMask) am[i] = *reinterpret_cast<const float4*>(gaux + (long long)(m0 + row) * ldaux + n);
+  for (int ep = 0; ep < EP; ++ep) {
+    if (ep > 0) __syncthreads();  // the previous pass has been read out
+    if (EP == 1 || wrow == ep) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < WN; ++jj) {
+          const int col = (wcol * WN + jj) * 32 + r;
+          const int rbase = ((EP == 1 ? wrow * WM : 0) + i) * 32 + 4 * h;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Cs[(rbase + (e & 3) + 8 * (e >> 2)) * CP + col] = acc[i][jj][e];
+        }
     }
-    float* __restrict__ cbase = gC + slab + (long long)(m0 + row_first) * ldc + n;
+    __syncthreads();
+    const int mrow0 = m0 + ep * EP_ROWS;  // first output row of this pass
+    if (EPI == kHinge) {
+      // S tile -> dL/dS tile; per row: hinge sum and active count of this tile's columns (reduced over the BN / 4
+      // threads that hold the row: consecutive lanes of one wave) -> partials[row][column tile]
+      constexpr int RT = BN / 4;  // threads per row: 16 or 32 consecutive lanes
+      const HingeEpi& hp = b.hinge;
+      for (int i = 0; i < NI; ++i) {
+        const int row = row_first + i * ROW_STEP;
+        const int m = mrow0 + row;
+        const float4 x = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
+        const float xe[4] = {x.x, x.y, x.z, x.w};
+        float ge[4] = {0.f, 0.f, 0.f, 0.f};
+        float l = 0.f, c = 0.f;
+        const bool row_ok = m < M;
+        if (row_ok && n < N) {
+          const int pi = hp.pos_index ? hp.pos_index[m] : m;
+          const float sp = hp.s_pos[m];
+          const long long myq = hp.qid_q ? hp.qid_q[m] : 0;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float4 x = v[i];
-      if (EPI == kBias || EPI == kBiasRelu) { x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w; }
-      if (EPI == kBiasRelu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-      if (EPI == kReluMask) {
-        x.x = am[i].x > 0.f ? x.x : 0.f; x.y = am[i].y > 0.f ? x.y : 0.f;
-        x.z = am[i].z > 0.f ? x.z : 0.f; x.w = am[i].w > 0.f ? x.w : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            const int j = n + e;
+            if (j < N) {
+              const bool valid = j != pi && !(hp.qid_q && hp.qid_d[j] == myq);
+              const float h = xe[e] - sp + hp.margin;  // = (1 - s_pos) - (1 - s[j]) + margin
+              if (valid && h > 0.f) {
+                l += h;
+                c += 1.f;
+                ge[e] = hp.g;
+              }
+            }
+          }
+          float* __restrict__ dst = gC + (long long)m * ldc + n;
+          if (vecC && n + 3 < N) {
+            *reinterpret_cast<float4*>(dst) = make_float4(ge[0], ge[1], ge[2], ge[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < N) dst[e] = ge[e];
+          }
+        }
+#pragma unroll
+        for (int off = RT / 2; off > 0; off >>= 1) {
+          l += __shfl_xor(l, off, TT_WAVE);
+          c += __shfl_xor(c, off, TT_WAVE);
+        }
+        if ((tid % RT) == 0 && row_ok) {
+          hp.part_loss[(long long)m * hp.n_tiles + bx] = l;
+          hp.part_cnt[(long long)m * hp.n_tiles + bx] = c;
+        }
       }
-      *reinterpret_cast<float4*>(cbase + (long long)i * ROW_STEP * ldc) = x;
+      continue;
     }
-  } else if (vecC) {
-    const bool col_ok = n < N;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((EPI == kBias || EPI == kBiasRelu) && col_ok) bv = *reinterpret_cast<const float4*>(gbias + n);
-    for (int i = 0; i < NI; ++i) {
-      const int row = row_first + i * ROW_STEP;
-      const int m = m0 + row;
-      if (m >= M || !col_ok) continue;
-      float4 x = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
-      if (EPI == kBias || EPI == kBiasRelu) { x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w; }
-      if (EPI == kBiasRelu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-      if (EPI == kReluMask) {
-        const float4 a = *reinterpret_cast<const float4*>(gaux + (long long)m * ldaux + n);
-        x.x = a.x > 0.f ? x.x : 0.f; x.y = a.y > 0.f ? x.y : 0.f; x.z = a.z > 0.f ? x.z : 0.f; x.w = a.w > 0.f ? x.w : 0.f;
-      }
-      *reinterpret_cast<float4*>(gC + slab + (long long)m * ldc + n) = x;
-    }
-  } else {
-    for (int i = 0; i < NI; ++i) {
-      const int row = row_first + i * ROW_STEP;
-      const int m = m0 + row;
-      if (m >= M) continue;
-      const float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
+    if (vecC && full) {
+      // Interior tile: no guards, so nothing splits the stores into exec-masked branches
+      // (each of which the compiler fences with vmcnt(0)).  All loads first (tile chunks from
+      // LDS, bias once, ReLU-mask rows), then NI stores back to back.
+      float4 v[NI], am[NI];
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (EPI == kBias || EPI == kBiasRelu) bv = *reinterpret_cast<const float4*>(gbias + n);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (n + c >= N) break;
-        float x = c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
-        if (EPI == kBias || EPI == kBiasRelu) x += gbias[n + c];
-        if (EPI == kBiasRelu) x = fmaxf(x, 0.f);
-        if (EPI == kReluMask) x = gaux[(long long)m * ldaux + n + c] > 0.f ? x : 0.f;
-        gC[slab + (long long)m * ldc + n + c] = x;
+      for (int i = 0; i < NI; ++i) {
+        const int row = row_first + i * ROW_STEP;
+        v[i] = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
+        if (EPI == kReluMask) am[i] = *reinterpret_cast<const float4*>(gaux + (long long)(mrow0 + row) * ldaux + n);
+      }
+      float* __restrict__ cbase = gC + slab + (long long)(mrow0 + row_first) * ldc + n;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        float4 x = v[i];
+        if (EPI == kBias || EPI == kBiasRelu) { x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w; }
+        if (EPI == kBiasRelu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+        if (EPI == kReluMask) {
+          x.x = am[i].x > 0.f ? x.x : 0.f; x.y = am[i].y > 0.f ? x.y : 0.f;
+          x.z = am[i].z > 0.f ? x.z : 0.f; x.w = am[i].w > 0.f ? x.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(cbase + (long long)i * ROW_STEP * ldc) = x;
+      }
+    } else if (vecC) {
+      const bool col_ok = n < N;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((EPI == kBias || EPI == kBiasRelu) && col_ok) bv = *reinterpret_cast<const float4*>(gbias + n);
+      for (int i = 0; i < NI; ++i) {
+        const int row = row_first + i * ROW_STEP;
+        const int m = mrow0 + row;
+        if (m >= M || !col_ok) continue;
+        float4 x = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
+        if (EPI == kBias || EPI == kBiasRelu) { x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w; }
+        if (EPI == kBiasRelu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+        if (EPI == kReluMask) {
+          const float4 a = *reinterpret_cast<const float4*>(gaux + (long long)m * ldaux + n);
+          x.x = a.x > 0.f ? x.x : 0.f; x.y = a.y > 0.f ? x.y : 0.f; x.z = a.z > 0.f ? x.z : 0.f; x.w = a.w > 0.f ? x.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(gC + slab + (long long)m * ldc + n) = x;
+      }
+    } else {
+      for (int i = 0; i < NI; ++i) {
+        const int row = row_first + i * ROW_STEP;
+        const int m = mrow0 + row;
+        if (m >= M) continue;
+        const float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (n + c >= N) break;
+          float x = c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
+          if (EPI == kBias || EPI == kBiasRelu) x += gbias[n + c];
+          if (EPI == kBiasRelu) x = fmaxf(x, 0.f);
+          if (EPI == kReluMask) x = gaux[(long long)m * ldaux + n + c] > 0.f ? x : 0.f;
+          gC[slab + (long long)m * ldc + n + c] = x;
+        }
       }
     }
   }
   if (do_colsum && tid < BM && m0 + tid < M) gcolsum[slab + m0 + tid] = csum;
 }
 
-template <int LAYOUT, int EPI, int WM, int WN, bool VEC>
+// Tile coordinates of this workgroup.  Plain: the 3-D grid.  XCD-aware (Batch::xcd_order): a 1-D grid where
+// workgroup i belongs to class i % 8 and is the (i / 8)-th of its class; a class walks ITS share of the sharing
+// groups (row panels for kNT / kNN, split-K slabs for kTN: group g goes to class g % 8) one group after the other.
+template <int LAYOUT>
+__device__ __forceinline__ bool tile_coords(const Batch& b, int& bx, int& by, int& bz) {
+  if (!b.xcd_order) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    return true;
+  }
+  const int cls = blockIdx.x & 7, t = blockIdx.x >> 3;
+  if (LAYOUT == kTN) {
+    const int per = b.gx * b.gy;                 // tiles of one slab
+    const int slab = (t / per) * 8 + cls, tile = t % per;
+    if (slab >= b.gz) return false;
+    bx = tile % b.gx; by = tile / b.gx; bz = slab;
+  } else {
+    const int panel = (t / b.gx) * 8 + cls;      // row panel index over (group, m-tile)
+    if (panel >= b.gy * b.gz) return false;
+    bx = t % b.gx; by = panel % b.gy; bz = panel / b.gy;
+  }
+  return true;
+}
+
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32>
 __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN>::LDS_FLOATS];
-  gemm_body<LAYOUT, EPI, WM, WN, VEC>(b, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, BK>::LDS_FLOATS];
+  int bx, by, bz;
+  if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
+  gemm_body<LAYOUT, EPI, WM, WN, VEC, BK>(b, lds, bx, by, bz);
+}
+
+// The BK = 16 tile shares a CU with the streaming gather's workgroup (gather_pool.hip): three waves per SIMD's worth
+// of registers (<= 168) leave room for two of these workgroups plus the gather's 4 waves of up to 176.
+template <int LAYOUT, int EPI, int WM, int WN>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 8)))
+void gemm_f32_bk16_kernel(const Batch b) {
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, 16>::LDS_FLOATS];
+  int bx, by, bz;
+  if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
+  gemm_body<LAYOUT, EPI, WM, WN, true, 16>(b, lds, bx, by, bz);
 }
 
 // Two independent GEMMs of the projection backward in ONE launch: the split-K dW2/db2 (kTN,
@@ -416,7 +524,8 @@ bool problem_vec_ok(const Problem& p) {
 }
 
 template <int LAYOUT, int EPI>
-int launch_le(const Batch& b, int wm, int wn, hipStream_t st) {
+int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
+  Batch b = b_in;
   int maxM = 0, maxN = 0;
   for (int i = 0; i < b.count; ++i) {
     maxM = b.p[i].M > maxM ? b.p[i].M : maxM;
@@ -424,12 +533,24 @@ int launch_le(const Batch& b, int wm, int wn, hipStream_t st) {
   }
   if (maxM == 0 || maxN == 0) return TT_OK;
   const int BM = 64 * wm, BN = 64 * wn;
-  const dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count * b.nsplit), block(kThreads);
+  dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count * b.nsplit);
+  const dim3 block(kThreads);
   bool vec = true;
   for (int i = 0; i < b.count; ++i) vec = vec && (b.p[i].M == 0 || problem_vec_ok<LAYOUT>(b.p[i]));
+  if (!vec) b.xcd_order = 0;
+  if (b.xcd_order) {  // 1-D grid, 8 classes x (their share of the sharing groups, rounded up) x tiles per group
+    b.gx = (int)grid.x; b.gy = (int)grid.y; b.gz = (int)grid.z;
+    const long long groups = LAYOUT == kTN ? b.gz : (long long)b.gy * b.gz;
+    const long long per = LAYOUT == kTN ? (long long)b.gx * b.gy : b.gx;
+    const long long total = 8 * ((groups + 7) / 8) * per;
+    if (total > 0x7fffffffLL) b.xcd_order = 0;
+    else grid = dim3((unsigned)total, 1, 1);
+  }
   if (!vec) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1, false>), dim3((maxN + 63) / 64, (maxM + 63) / 64, b.count * b.nsplit), block, 0, st, b);
   else if (wm == 1 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1, true>), grid, block, 0, st, b);
   else if (wm == 2 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 2, 1, true>), grid, block, 0, st, b);
+  else if (wm == 2 && wn == 2 && bk == 16)  // the tile that shares a CU with the streaming gather
+    hipLaunchKernelGGL((gemm_f32_bk16_kernel<LAYOUT, EPI, 2, 2>), grid, block, 0, st, b);
   else if (wm == 2 && wn == 2) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 2, 2, true>), grid, block, 0, st, b);
   else return TT_ERR_UNSUPPORTED;
   TT_CHECK_LAUNCH();
@@ -479,20 +600,24 @@ static size_t lds_of(Layout layout) {
   return (size_t)f * sizeof(float);
 }
 
-size_t tile_lds_bytes(Layout layout, int wm, int wn) {
+size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk) {
+  if (wm == 2 && wn == 2 && bk == 16)
+    return (size_t)(layout == kNT ? TileCfg<kNT, 2, 2, 16>::LDS_FLOATS
+                                  : layout == kNN ? TileCfg<kNN, 2, 2, 16>::LDS_FLOATS : TileCfg<kTN, 2, 2, 16>::LDS_FLOATS) * sizeof(float);
   if (wm == 2 && wn == 2) return lds_of<2, 2>(layout);
   if (wm == 2 && wn == 1) return lds_of<2, 1>(layout);
   return lds_of<1, 1>(layout);
 }
 
-int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st) {
-  if (b.count < 1 || b.count > kMaxGroup || b.nsplit < 1) return TT_ERR_BAD_SHAPE;
-  if (layout == kNT && epi == kBiasRelu) return launch_le<kNT, kBiasRelu>(b, wm, wn, st);
-  if (layout == kNT && epi == kBias) return launch_le<kNT, kBias>(b, wm, wn, st);
-  if (layout == kNT && epi == kStore) return launch_le<kNT, kStore>(b, wm, wn, st);
-  if (layout == kNN && epi == kReluMask) return launch_le<kNN, kReluMask>(b, wm, wn, st);
-  if (layout == kNN && epi == kStore) return launch_le<kNN, kStore>(b, wm, wn, st);
-  if (layout == kTN && epi == kStore) return launch_le<kTN, kStore>(b, wm, wn, st);
+int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st, int bk) {
+  if (b.count < 1 || b.count > kMaxGroup || b.nsplit < 1 || (bk != 32 && bk != 16)) return TT_ERR_BAD_SHAPE;
+  if (layout == kNT && epi == kBiasRelu) return launch_le<kNT, kBiasRelu>(b, wm, wn, st, bk);
+  if (layout == kNT && epi == kBias) return launch_le<kNT, kBias>(b, wm, wn, st, bk);
+  if (layout == kNT && epi == kStore) return launch_le<kNT, kStore>(b, wm, wn, st, bk);
+  if (layout == kNT && epi == kHinge) return launch_le<kNT, kHinge>(b, wm, wn, st, bk);
+  if (layout == kNN && epi == kReluMask) return launch_le<kNN, kReluMask>(b, wm, wn, st, bk);
+  if (layout == kNN && epi == kStore) return launch_le<kNN, kStore>(b, wm, wn, st, bk);
+  if (layout == kTN && epi == kStore) return launch_le<kTN, kStore>(b, wm, wn, st, bk);
   return TT_ERR_UNSUPPORTED;
 }
 

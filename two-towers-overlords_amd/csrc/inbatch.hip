@@ -31,61 +31,72 @@ __global__ __launch_bounds__(kThreads) void unit_rows_norm_kernel(const float* _
   if (lane == 0) nrm[row] = n;
 }
 
-// One workgroup per query row: hinge over the row of S, S overwritten by dL/dS.
-__global__ __launch_bounds__(kThreads) void inbatch_hinge_kernel(float* __restrict__ S, const int* __restrict__ pos_index,
-                                                                 const long long* __restrict__ qid_q,
-                                                                 const long long* __restrict__ qid_d, long long Bd,
-                                                                 float margin, float g, float* __restrict__ row_loss) {
-  __shared__ float red_l[kThreads / 64], red_c[kThreads / 64];
-  const long long i = blockIdx.x;
-  float* __restrict__ s = S + i * Bd;
-  const int pi = pos_index ? pos_index[i] : (int)i;
-  const float s_pos = s[pi];
-  const long long my_q = qid_q ? qid_q[i] : 0;
-  __syncthreads();  // everyone has read s[pi] before anyone overwrites it
-  float loss = 0.f, cnt = 0.f;
-  for (long long j = threadIdx.x; j < Bd; j += kThreads) {
-    float gij = 0.f;
-    const bool valid = j != pi && !(qid_q && qid_d && qid_d[j] == my_q);
-    if (valid) {
-      const float h = s[j] - s_pos + margin;  // = (1 - s_pos) - (1 - s[j]) + margin
-      if (h > 0.f) {
-        loss += h;
-        cnt += 1.f;
-        gij = g;
-      }
-    }
-    if (j != pi) s[j] = gij;
+// s_pos[i] = qhat_i . dhat_{pos_i} — the positive's similarity, needed by every column tile of row i before the
+// S product's epilogue can turn S into dL/dS (one wave per query).
+__global__ __launch_bounds__(kThreads) void pos_dot_kernel(const float* __restrict__ qh, const float* __restrict__ dh,
+                                                           const int* __restrict__ pos_index, float* __restrict__ s_pos,
+                                                           long long Bq, long long Bd, int P) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= Bq) return;
+  long long pi = pos_index ? pos_index[i] : i;
+  pi = pi < 0 ? 0 : (pi >= Bd ? Bd - 1 : pi);
+  float t = 0.f;
+  for (int c = lane; c < P; c += 64) t = fmaf(qh[i * P + c], dh[pi * P + c], t);
+  t = tt_wave_sum(t);
+  if (lane == 0) s_pos[i] = t;
+}
+
+// After the S product (epilogue kHinge: S already replaced by dL/dS except on the positive's column): per query row,
+// add the column tiles' hinge sums and active counts in tile order, store the row loss and
+// dL/dS[i, pos_i] = -g * (number of active negatives of row i).  One wave per row.
+__global__ __launch_bounds__(kThreads) void inbatch_finish_kernel(float* __restrict__ G, const int* __restrict__ pos_index,
+                                                                  const float* __restrict__ part_loss,
+                                                                  const float* __restrict__ part_cnt, int n_tiles,
+                                                                  long long Bq, long long Bd, float g,
+                                                                  float* __restrict__ row_loss) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= Bq) return;
+  float l = 0.f, c = 0.f;
+  for (int t0 = 0; t0 < n_tiles; t0 += 64) {  // fixed order: chunks of 64 tiles, butterfly inside a chunk
+    const int t = t0 + lane;
+    const float lv = t < n_tiles ? part_loss[i * n_tiles + t] : 0.f;
+    const float cv = t < n_tiles ? part_cnt[i * n_tiles + t] : 0.f;
+    l += tt_wave_sum(lv);
+    c += tt_wave_sum(cv);
   }
-  loss = tt_wave_sum(loss);
-  cnt = tt_wave_sum(cnt);
-  if ((threadIdx.x & 63) == 0) {
-    red_l[threadIdx.x >> 6] = loss;
-    red_c[threadIdx.x >> 6] = cnt;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    row_loss[i] = ((red_l[0] + red_l[1]) + red_l[2]) + red_l[3];
-    s[pi] = -g * (((red_c[0] + red_c[1]) + red_c[2]) + red_c[3]);
+  if (lane == 0) {
+    long long pi = pos_index ? pos_index[i] : i;
+    pi = pi < 0 ? 0 : (pi >= Bd ? Bd - 1 : pi);
+    row_loss[i] = l;
+    G[i * Bd + pi] = -g * c;
   }
 }
 
 // d(x / max(|x|, eps))^T applied to the upstream gradient u of the unit row:
 // dx = (u - xhat * (xhat . u) * r) / c,  c = max(|x|, eps), r = c/|x| (|x| > 0) else 0
+// `u` arrives as `nslabs` split-K partial slabs (slab z at u + z * slab_stride), summed here in slab order.
 __global__ __launch_bounds__(kThreads) void unit_rows_bwd_kernel(const float* __restrict__ xhat,
                                                                  const float* __restrict__ nrm,
-                                                                 const float* __restrict__ u, float* __restrict__ dx,
+                                                                 const float* __restrict__ u, int nslabs,
+                                                                 long long slab_stride, float* __restrict__ dx,
                                                                  long long rows, int P, float eps, int accumulate) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const long long o = row * P;
+  auto uval = [&](int c) {
+    float v = u[o + c];
+    for (int z = 1; z < nslabs; ++z) v += u[z * slab_stride + o + c];
+    return v;
+  };
   float t = 0.f;
-  for (int c = lane; c < P; c += 64) t = fmaf(xhat[o + c], u[o + c], t);
+  for (int c = lane; c < P; c += 64) t = fmaf(xhat[o + c], uval(c), t);
   t = tt_wave_sum(t);
   const float n = nrm[row], cden = fmaxf(n, eps), r = n > 0.f ? cden / n : 0.f;
   for (int c = lane; c < P; c += 64) {
-    const float v = (u[o + c] - xhat[o + c] * (t * r)) / cden;
+    const float v = (uval(c) - xhat[o + c] * (t * r)) / cden;
     dx[o + c] = accumulate ? dx[o + c] + v : v;
   }
 }
@@ -94,8 +105,30 @@ inline size_t r4(size_t x) { return (x + 3) / 4 * 4; }
 
 }  // namespace
 
+// split-K factor of the two gradient products (G dhat, G^T qhat): [B x P] outputs are few 64x64 tiles (B = 4096,
+// P = 384: 384 tiles on 256 CUs), so the long contraction (K = B) is cut until there are about three per CU
+static int grad_splits(long long rows, int P, long long K) {
+  const long long tiles = ((rows + 63) / 64) * ((P + 63) / 64);
+  int s = (int)((3 * 256 + tiles - 1) / tiles);
+  if (s < 1) s = 1;
+  if (s > 8) s = 8;
+  while (s > 1 && K / s < 256) --s;  // keep at least 8 K-steps per split
+  return s;
+}
+// block tile of the S product, in units of 64: 128x128 for large batches — only on the vector path (P % 4 == 0; the
+// unit rows live in the 16-byte aligned workspace), the scalar fallback of gemm_f32.hip always runs 64x64 tiles
+static int s_tile(long long Bq, long long Bd, int P) {
+  return (P % 4 == 0 && P >= 4 && ((Bq + 63) / 64) * ((Bd + 63) / 64) >= 2048) ? 2 : 1;
+}
+static int col_tiles(long long Bq, long long Bd, int P) {  // column tiles of the S product: row stride of the partials
+  const int t = s_tile(Bq, Bd, P);
+  return (int)((Bd + 64 * t - 1) / (64 * t));
+}
+
 extern "C" size_t tt_inbatch_workspace_bytes(int64_t Bq, int64_t Bd, int P) {
-  const size_t f = r4((size_t)Bq * P) * 2 + r4((size_t)Bd * P) * 2 + r4(Bq) * 2 + r4(Bd) + r4((size_t)Bq * Bd);
+  const size_t sq = grad_splits(Bq, P, Bd), sd = grad_splits(Bd, P, Bq);
+  const size_t f = r4((size_t)Bq * P) * (1 + sq) + r4((size_t)Bd * P) * (1 + sd) + r4(Bq) * 3 + r4(Bd) +
+                   2 * r4((size_t)Bq * col_tiles(Bq, Bd, P)) + r4((size_t)Bq * Bd);
   return f * sizeof(float);
 }
 
@@ -112,59 +145,77 @@ extern "C" int tt_inbatch_triplet_fwd_bwd_f32(const float* q, const float* d, co
   TT_REQUIRE(workspace_bytes >= tt_inbatch_workspace_bytes(Bq, Bd, P), TT_ERR_WORKSPACE);
   TT_REQUIRE(tt_aligned16(workspace), TT_ERR_ALIGNMENT);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int sq = grad_splits(Bq, P, Bd), sd = grad_splits(Bd, P, Bq), nt = col_tiles(Bq, Bd, P);
+  const long long stride_q = (long long)r4((size_t)Bq * P), stride_d = (long long)r4((size_t)Bd * P);
   float* w = static_cast<float*>(workspace);
-  float* qh = w;            w += r4((size_t)Bq * P);
-  float* dh = w;            w += r4((size_t)Bd * P);
-  float* uq = w;            w += r4((size_t)Bq * P);
-  float* ud = w;            w += r4((size_t)Bd * P);
+  float* qh = w;            w += stride_q;
+  float* dh = w;            w += stride_d;
+  float* uq = w;            w += stride_q * sq;
+  float* ud = w;            w += stride_d * sd;
   float* nq = w;            w += r4(Bq);
   float* row_loss = w;      w += r4(Bq);
+  float* s_pos = w;         w += r4(Bq);
   float* nd = w;            w += r4(Bd);
+  float* part_loss = w;     w += r4((size_t)Bq * nt);
+  float* part_cnt = w;      w += r4((size_t)Bq * nt);
   float* S = w;
 
   hipLaunchKernelGGL(unit_rows_norm_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(kThreads), 0, st, q, qh, nq, (long long)Bq, P, 1e-8f);
   TT_CHECK_LAUNCH();
   hipLaunchKernelGGL(unit_rows_norm_kernel, dim3((unsigned)((Bd + 3) / 4)), dim3(kThreads), 0, st, d, dh, nd, (long long)Bd, P, 1e-8f);
   TT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pos_dot_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(kThreads), 0, st, qh, dh, pos_index, s_pos, (long long)Bq,
+                     (long long)Bd, P);
+  TT_CHECK_LAUNCH();
 
-  auto tile = [](long long m, long long n) { return ((m + 63) / 64) * ((n + 63) / 64) >= 2048 ? 2 : 1; };
-  {  // S = qh dh^T                                         [Bq, Bd]
+  {  // G = dL/dS of S = qh dh^T, the hinge applied in the product's epilogue: S itself is never stored   [Bq, Bd]
     ttg::Batch b{};
     b.count = 1; b.nsplit = 1;
     ttg::Problem& p = b.p[0];
     p.A = qh; p.B = dh; p.C = S; p.M = (int)Bq; p.N = (int)Bd; p.K = P; p.lda = P; p.ldb = P; p.ldc = (int)Bd;
-    const int t = tile(Bq, Bd);
-    int rc = ttg::launch(ttg::kNT, ttg::kStore, b, t, t, st);
+    b.hinge.pos_index = pos_index;
+    b.hinge.qid_q = reinterpret_cast<const long long*>(qid_q);
+    b.hinge.qid_d = reinterpret_cast<const long long*>(qid_d);
+    b.hinge.s_pos = s_pos;
+    b.hinge.margin = margin;
+    b.hinge.g = grad_scale;
+    b.hinge.part_loss = part_loss;
+    b.hinge.part_cnt = part_cnt;
+    b.hinge.n_tiles = nt;
+    const int t = s_tile(Bq, Bd, P);
+    int rc = ttg::launch(ttg::kNT, ttg::kHinge, b, t, t, st);
     if (rc != TT_OK) return rc;
   }
-  hipLaunchKernelGGL(inbatch_hinge_kernel, dim3((unsigned)Bq), dim3(kThreads), 0, st, S, pos_index,
-                     reinterpret_cast<const long long*>(qid_q), reinterpret_cast<const long long*>(qid_d), (long long)Bd,
-                     margin, grad_scale, row_loss);
+  hipLaunchKernelGGL(inbatch_finish_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(kThreads), 0, st, S, pos_index, part_loss, part_cnt,
+                     nt, (long long)Bq, (long long)Bd, grad_scale, row_loss);
   TT_CHECK_LAUNCH();
   if (loss) {
     int rc = tt_launch_loss_mean(row_loss, Bq, loss_denominator, loss, nullptr, nullptr, st);
     if (rc != TT_OK) return rc;
   }
-  {  // uq = G dh                                           [Bq, P]   (G = dL/dS, in S)
+  {  // uq = G dh                                           [Bq, P]   (sq split-K slabs)
     ttg::Batch b{};
-    b.count = 1; b.nsplit = 1;
+    b.count = 1; b.nsplit = sq; b.slab_stride = stride_q;
     ttg::Problem& p = b.p[0];
     p.A = S; p.B = dh; p.C = uq; p.M = (int)Bq; p.N = P; p.K = (int)Bd; p.lda = (int)Bd; p.ldb = P; p.ldc = P;
+    p.k_per_split = (int)(((Bd + sq - 1) / sq + 31) / 32 * 32);
     int rc = ttg::launch(ttg::kNN, ttg::kStore, b, 1, 1, st);
     if (rc != TT_OK) return rc;
   }
-  {  // ud = G^T qh                                         [Bd, P]
+  {  // ud = G^T qh                                         [Bd, P]   (sd split-K slabs)
     ttg::Batch b{};
-    b.count = 1; b.nsplit = 1;
+    b.count = 1; b.nsplit = sd; b.slab_stride = stride_d;
     ttg::Problem& p = b.p[0];
     p.A = S; p.B = qh; p.C = ud; p.M = (int)Bd; p.N = P; p.K = (int)Bq; p.lda = (int)Bd; p.ldb = P; p.ldc = P;
-    p.k_per_split = (int)((Bq + 31) / 32 * 32);
+    p.k_per_split = (int)(((Bq + sd - 1) / sd + 31) / 32 * 32);
     int rc = ttg::launch(ttg::kTN, ttg::kStore, b, 1, 1, st);
     if (rc != TT_OK) return rc;
   }
-  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(kThreads), 0, st, qh, nq, uq, dq, (long long)Bq, P, 1e-8f, 0);
+  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(kThreads), 0, st, qh, nq, uq, sq, stride_q, dq,
+                     (long long)Bq, P, 1e-8f, 0);
   TT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((unsigned)((Bd + 3) / 4)), dim3(kThreads), 0, st, dh, nd, ud, dd, (long long)Bd, P, 1e-8f, accumulate_dd);
+  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((unsigned)((Bd + 3) / 4)), dim3(kThreads), 0, st, dh, nd, ud, sd, stride_d, dd,
+                     (long long)Bd, P, 1e-8f, accumulate_dd);
   TT_CHECK_LAUNCH();
   return TT_OK;
 }

@@ -26,7 +26,8 @@ struct Tower {
 // Block-tile policy of the [rows x P] projection GEMMs: stand-alone choice; 128x64 where 64x64 would do (half the
 // weight re-reads: beside a capped K1); 64x64 below the 128x128 threshold (beside a K1 reserved just above that
 // tile's LDS, engine.hip).
-enum TilePolicy : int { kTileAuto = 0, kTileLowTraffic = 1, kTileSmall = 2 };
+// kTileStream: beside the streaming gather of an HBM-resident table (gather_pool.hip): 128x128 tiles with K-step 16.
+enum TilePolicy : int { kTileAuto = 0, kTileLowTraffic = 1, kTileSmall = 2, kTileStream = 3 };
 int k_per_split(int M, int nsplit);
 // split count used for a standalone backward over M rows
 int choose_nsplit(long long M);
@@ -41,11 +42,13 @@ int forward(const Tower* t, int count, int D, int P, hipStream_t st, int policy 
 int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
 // The three launches of `backward`, separately (dW2/db2 is independent of the dH -> dW1/db1
 // chain, so a caller may run it on another stream):
-int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
+int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
+                 int policy = kTileAuto);
 int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, int policy = kTileAuto);
 // dW2/db2 and dH as ONE launch (they are independent of each other)
 int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
                     int policy = kTileAuto);
-int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
+int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
+                 int policy = kTileAuto);
 
 }  // namespace ttp

@@ -21,24 +21,79 @@ int choose_nsplit(long long M) {
 }
 
 // block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
-static void pick_tile(long long total_rows, int N, int& wm, int& wn, int policy = kTileAuto) {
+// 96x96 tiles (gemm16.hip) or the 64x64 / 128-row tiles of gemm_f32.hip for a grouped [rows x N] product?  Whichever
+// needs fewer tile-rounds x tile area on the chip's CUs (a CU runs its tiles' MFMAs one after the other, so the
+// CU with the most tiles sets the time).  Only where the chain has the chip to itself (cache-fed epochs — what
+// run_training runs by default — evaluation, one-stream steps): beside the token gathers the 64x64 tile is paired with
+// the gather's LDS reservation (engine.hip).  TT_G16=0|1 forces the choice (A/B).
+static bool prefer_tile96(const ttg::Batch& b, int policy, int wm, int wn) {
+  static const char* const v = getenv("TT_G16");
+  if (v && *v) return *v != '0';
+  if (policy != kTileAuto) return false;
+  const long long cus = 256;
+  long long t_cur = 0, t_96 = 0;
+  for (int i = 0; i < b.count; ++i) {
+    const long long M = b.p[i].M, N = b.p[i].N;
+    t_cur += ((M + 64 * wm - 1) / (64 * wm)) * ((N + 64 * wn - 1) / (64 * wn));
+    t_96 += ((M + 95) / 96) * ((N + 95) / 96);
+  }
+  const long long cost_cur = ((t_cur + cus - 1) / cus) * (64LL * wm) * (64LL * wn);
+  const long long cost_96 = ((t_96 + cus - 1) / cus) * 96LL * 96LL;
+  return cost_96 * 10 <= cost_cur * 9;  // at least 10 % fewer tile-rounds x area
+}
+
+static int launch_rows(ttg::Layout layout, ttg::Epilogue epi, const ttg::Batch& b, int wm, int wn, int bk, int policy,
+                       hipStream_t st) {
+  if (ttg::gemm16_supported(layout, epi, b) && prefer_tile96(b, policy, wm, wn)) return ttg::launch16(layout, epi, b, st);
+  return ttg::launch(layout, epi, b, wm, wn, st, bk);
+}
+
+// XCD-aware workgroup order for the projection GEMMs (gemm_f32.h): on beside the streaming gather, where every
+// re-read of an operand block that misses the XCD's L2 competes with the gather for the fabric; TT_XCD=0|1 (A/B).
+static int xcd_order_for(int policy) {
+  static const char* const v = getenv("TT_XCD");
+  if (v && *v) return *v != '0';
+  return policy == kTileStream;
+}
+
+// Tile of the split-K weight-gradient GEMMs: 64x64 (many short workgroups; pairs with the gather's LDS reservation at
+// BERT sizes), or — beside the streaming gather — 128x128 with K-step 16: a quarter of the operand re-reads.
+static void pick_tn_tile(int M, int N, int policy, int& wm, int& wn, int& bk) {
+  static const char* const v = getenv("TT_TN_TILE");  // A/B: "11" / "22"
+  wm = wn = 1; bk = 32;
+  const bool big = (v && *v) ? v[0] == '2' : policy == kTileStream;
+  if (big && M >= 256 && N >= 256) { wm = wn = 2; bk = 16; }
+}
+
+static void pick_tile(long long total_rows, int N, int& wm, int& wn, int& bk, int policy = kTileAuto) {
   const bool low_traffic = policy == kTileLowTraffic;
+  static const char* const bk_env = getenv("TT_BK");  // A/B: "16" / "32" K-step of the 128x128 tiles
+  bk = 32;
   static const char* const tile_env = getenv("TT_TILE");  // read once (A/B: "11", "21", "22")
   if (const char* v = tile_env) {
-    if (v[0] == '1' || v[0] == '2') { wm = v[0] - '0'; wn = (v[1] == '2') ? 2 : 1; if (wm == 1) wn = 1; return; }
+    if (v[0] == '1' || v[0] == '2') {
+      wm = v[0] - '0'; wn = (v[1] == '2') ? 2 : 1; if (wm == 1) wn = 1;
+      if (bk_env && wm == 2 && wn == 2) bk = atoi(bk_env) == 16 ? 16 : 32;
+      return;
+    }
   }
   const long long tiles64 = ((total_rows + 63) / 64) * ((N + 63) / 64);
-  if (tiles64 >= 2048 && N >= 128) { wm = 2; wn = 2; }
+  if (tiles64 >= 2048 && N >= 128) {
+    wm = 2; wn = 2;
+    // beside the streaming gather: K-step 16 (40 KB of LDS, <= 168 registers), two tiles + the gather's waves per CU
+    bk = policy == kTileStream ? 16 : 32;
+    if (bk_env) bk = atoi(bk_env) == 16 ? 16 : 32;
+  }
   else if (policy == kTileSmall) { wm = 1; wn = 1; }
   else if (tiles64 >= 1024 || (low_traffic && tiles64 >= 512)) { wm = 2; wn = 1; }
   else { wm = 1; wn = 1; }
 }
 
 size_t chain_lds_bytes(long long rows, int P, int policy) {
-  int wm, wn;
-  pick_tile(rows, P, wm, wn, policy);
-  size_t m = ttg::tile_lds_bytes(ttg::kNT, wm, wn);
-  const size_t nn = ttg::tile_lds_bytes(ttg::kNN, wm, wn), tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1);
+  int wm, wn, bk;
+  pick_tile(rows, P, wm, wn, bk, policy);
+  size_t m = ttg::tile_lds_bytes(ttg::kNT, wm, wn, bk);
+  const size_t nn = ttg::tile_lds_bytes(ttg::kNN, wm, wn, bk), tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1);
   m = nn > m ? nn : m;
   return tn > m ? tn : m;
 }
@@ -47,6 +102,7 @@ int forward(const Tower* t, int count, int D, int P, hipStream_t st, int policy)
   ttg::Batch b1{}, b2{};
   b1.count = b2.count = count;
   b1.nsplit = b2.nsplit = 1;
+  b1.xcd_order = b2.xcd_order = xcd_order_for(policy);
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -57,11 +113,11 @@ int forward(const Tower* t, int count, int D, int P, hipStream_t st, int policy)
     q.A = t[i].H; q.B = t[i].W2; q.C = t[i].Out; q.bias = t[i].b2;
     q.M = t[i].M; q.N = P; q.K = P; q.lda = P; q.ldb = P; q.ldc = P;
   }
-  int wm, wn;
-  pick_tile(rows, P, wm, wn, policy);
-  int rc = ttg::launch(ttg::kNT, ttg::kBiasRelu, b1, wm, wn, st);
+  int wm, wn, bk;
+  pick_tile(rows, P, wm, wn, bk, policy);
+  int rc = launch_rows(ttg::kNT, ttg::kBiasRelu, b1, wm, wn, bk, policy, st);
   if (rc != TT_OK) return rc;
-  return ttg::launch(ttg::kNT, ttg::kBias, b2, wm, wn, st);
+  return launch_rows(ttg::kNT, ttg::kBias, b2, wm, wn, bk, policy, st);
 }
 
 // Weight-gradient launches put the towers with more rows (longer K loops) first: workgroups are placed in
@@ -72,10 +128,11 @@ static int tn_slot(const Tower* t, int count, int i) {
   return (t[1].M > t[0].M) ? 1 - i : i;
 }
 
-int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
+int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st, int policy) {
   ttg::Batch g2{};
   g2.count = count;
   g2.nsplit = nsplit;
+  g2.xcd_order = xcd_order_for(policy);
   g2.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW2[i,j] = sum_m dOut[m,i] H[m,j];  db2[i] = sum_m dOut[m,i]
@@ -83,13 +140,16 @@ int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long 
     a.A = t[i].dOut; a.B = t[i].H; a.C = t[i].gW2; a.colsum = t[i].gb2;
     a.M = P; a.N = P; a.K = t[i].M; a.lda = P; a.ldb = P; a.ldc = P; a.k_per_split = k_per_split(t[i].M, nsplit);
   }
-  return ttg::launch(ttg::kTN, ttg::kStore, g2, 1, 1, st);
+  int wm, wn, bk;
+  pick_tn_tile(P, P, policy, wm, wn, bk);
+  return ttg::launch(ttg::kTN, ttg::kStore, g2, wm, wn, st, bk);
 }
 
 int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, int policy) {
   ttg::Batch gh{};
   gh.count = count;
   gh.nsplit = 1;
+  gh.xcd_order = xcd_order_for(policy);
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -98,9 +158,9 @@ int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, int pol
     h.A = t[i].dOut; h.B = t[i].W2; h.C = t[i].dH; h.aux = t[i].H;
     h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
   }
-  int wm, wn;
-  pick_tile(rows, P, wm, wn, policy);
-  return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st);
+  int wm, wn, bk;
+  pick_tile(rows, P, wm, wn, bk, policy);
+  return launch_rows(ttg::kNN, ttg::kReluMask, gh, wm, wn, bk, policy, st);
 }
 
 int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
@@ -110,6 +170,7 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
   g2.nsplit = nsplit;
   g2.slab_stride = slab_stride;
   gh.nsplit = 1;
+  g2.xcd_order = gh.xcd_order = xcd_order_for(policy);
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -120,20 +181,30 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
     h.A = t[i].dOut; h.B = t[i].W2; h.C = t[i].dH; h.aux = t[i].H;
     h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
   }
-  int wm, wn;
-  pick_tile(rows, P, wm, wn, policy);
-  if (wm == 2 && wn == 2) {  // the fused kernel carries 64x64 and 128x64 NN tiles only
-    int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, 1, 1, st);
+  int wm, wn, bk;
+  pick_tile(rows, P, wm, wn, bk, policy);
+  if (ttg::gemm16_supported(ttg::kNN, ttg::kReluMask, gh) && prefer_tile96(gh, policy, wm, wn)) {
+    int tm, tn, tbk;
+    pick_tn_tile(P, P, policy, tm, tn, tbk);
+    int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, tm, tn, st, tbk);
     if (rc != TT_OK) return rc;
-    return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st);
+    return ttg::launch16(ttg::kNN, ttg::kReluMask, gh, st);
+  }
+  if (wm == 2 && wn == 2) {  // the fused kernel carries 64x64 and 128x64 NN tiles only
+    int tm, tn, tbk;
+    pick_tn_tile(P, P, policy, tm, tn, tbk);
+    int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, tm, tn, st, tbk);
+    if (rc != TT_OK) return rc;
+    return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st, bk);
   }
   return ttg::launch_tn_nn_pair(g2, gh, wm, wn, st);
 }
 
-int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
+int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st, int policy) {
   ttg::Batch g1{};
   g1.count = count;
   g1.nsplit = nsplit;
+  g1.xcd_order = xcd_order_for(policy);
   g1.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW1[i,j] = sum_m dH[m,i] X[m,j];  db1[i] = sum_m dH[m,i]
@@ -141,7 +212,9 @@ int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long 
     c.A = t[i].dH; c.B = t[i].X; c.C = t[i].gW1; c.colsum = t[i].gb1;
     c.M = P; c.N = D; c.K = t[i].M; c.lda = P; c.ldb = D; c.ldc = D; c.k_per_split = k_per_split(t[i].M, nsplit);
   }
-  return ttg::launch(ttg::kTN, ttg::kStore, g1, 1, 1, st);
+  int wm, wn, bk;
+  pick_tn_tile(P, D, policy, wm, wn, bk);
+  return ttg::launch(ttg::kTN, ttg::kStore, g1, wm, wn, st, bk);
 }
 
 int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {

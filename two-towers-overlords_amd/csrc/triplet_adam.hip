@@ -163,6 +163,70 @@ __global__ __launch_bounds__(kThreads) void scatter_neg_grad_kernel(float* __res
   }
 }
 
+// The same scatter for large batches (the scan above reads all B indices per destination row: B^2 index reads, 268 M
+// at B = 16384).  Sort by destination instead — a CSR of the sources of every destination row: count (integer
+// atomics: the counts do not depend on their order), exclusive scan by one workgroup, fill (the order inside a
+// bucket is whatever the atomics gave), then one wave per destination row adds its sources in ASCENDING source order
+// (repeated minimum selection inside the bucket, which holds a handful of entries), so the sums are still
+// reproducible bit for bit.
+__global__ __launch_bounds__(kThreads) void csr_count_kernel(const int* __restrict__ neg_index, int B, int* __restrict__ counts) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < B) atomicAdd(&counts[min(max(neg_index[i], 0), B - 1)], 1);
+}
+
+// offsets[j] = sum of counts[0..j) (exclusive), offsets[B] = B; `counts` and `offsets` may not alias.  One workgroup.
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const int* __restrict__ counts, int B, int* __restrict__ offsets,
+                                                        int* __restrict__ cursor) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (B + 1023) / 1024;
+  const int lo = min(t * per, B), hi = min(lo + per, B);
+  int s = 0;
+  for (int j = lo; j < hi; ++j) s += counts[j];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the 1024 chunk sums
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;  // exclusive prefix of this thread's chunk
+  for (int j = lo; j < hi; ++j) {
+    offsets[j] = run;
+    cursor[j] = run;
+    run += counts[j];
+  }
+  if (t == 1023) offsets[B] = part[1023];
+}
+
+__global__ __launch_bounds__(kThreads) void csr_fill_kernel(const int* __restrict__ neg_index, int B, int* __restrict__ cursor,
+                                                            int* __restrict__ list) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < B) list[atomicAdd(&cursor[min(max(neg_index[i], 0), B - 1)], 1)] = i;
+}
+
+__global__ __launch_bounds__(kThreads) void scatter_neg_grad_csr_kernel(float* __restrict__ dp, const float* __restrict__ dn,
+                                                                        const int* __restrict__ offsets,
+                                                                        const int* __restrict__ list, int B, int P) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const int j = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (j >= B) return;
+  const int lo = offsets[j], n = offsets[j + 1] - lo;
+  int prev = -1;
+  for (int k = 0; k < n; ++k) {  // the smallest source index above `prev`
+    int cur = 0x7fffffff;
+    for (int base = 0; base < n; base += TT_WAVE) {
+      const int v = base + lane < n ? list[lo + base + lane] : 0x7fffffff;
+      if (v > prev) cur = min(cur, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cur = min(cur, __shfl_xor(cur, off, TT_WAVE));
+    for (int c = lane; c < P; c += TT_WAVE) dp[(long long)j * P + c] += dn[(long long)cur * P + c];
+    prev = cur;
+  }
+}
+
 // Single workgroup: loss = (sum_b hinge_b) / denom in a fixed order; optionally adds
 // into a running {sum, count, last} accumulator (the engine's deferred loss.item()).
 __global__ __launch_bounds__(kThreads) void loss_mean_kernel(const float* __restrict__ hinge_rows,
@@ -273,7 +337,8 @@ int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float
                            long long B, int P, float* pos_dist, float* neg_dist, float* hinge_rows,
                            float* dq, float* dp, float* dn, const int* neg_index, hipStream_t st,
                            float* mean_partials = nullptr, unsigned* mean_ticket = nullptr, float mean_denom = 1.f,
-                           float* mean_loss = nullptr, double* acc_sum = nullptr, long long* acc_count = nullptr) {
+                           float* mean_loss = nullptr, double* acc_sum = nullptr, long long* acc_count = nullptr,
+                           int* csr_ws = nullptr) {
   const TripletMean mean{mean_partials, mean_ticket, mean_denom, mean_loss, acc_sum, acc_count};
   const dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
   const int nc = (P + TT_WAVE - 1) / TT_WAVE;
@@ -297,7 +362,20 @@ int tt_launch_triplet_rows(const float* q, const float* p, const float* n, float
 #undef TT_TRIP
   TT_CHECK_LAUNCH();
   if (neg_index && dp && dn) {
-    hipLaunchKernelGGL(scatter_neg_grad_kernel, grid, block, 0, st, dp, dn, neg_index, (int)B, P);
+    if (csr_ws && B > 4096) {  // csr_ws: 4 * B + 1 ints — counts [B] | offsets [B + 1] | cursor [B] | list [B]
+      int* counts = csr_ws;
+      int* offsets = counts + B;
+      int* cursor = offsets + B + 1;
+      int* list = cursor + B;
+      const dim3 gb((unsigned)((B + kThreads - 1) / kThreads));
+      TT_HIP(hipMemsetAsync(counts, 0, (size_t)B * sizeof(int), st));
+      hipLaunchKernelGGL(csr_count_kernel, gb, block, 0, st, neg_index, (int)B, counts);
+      hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, counts, (int)B, offsets, cursor);
+      hipLaunchKernelGGL(csr_fill_kernel, gb, block, 0, st, neg_index, (int)B, cursor, list);
+      hipLaunchKernelGGL(scatter_neg_grad_csr_kernel, grid, block, 0, st, dp, dn, offsets, list, (int)B, P);
+    } else {
+      hipLaunchKernelGGL(scatter_neg_grad_kernel, grid, block, 0, st, dp, dn, neg_index, (int)B, P);
+    }
     TT_CHECK_LAUNCH();
   }
   return TT_OK;

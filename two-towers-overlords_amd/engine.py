@@ -179,6 +179,28 @@ class HotPathEngine:
             raise ValueError("grad_out: wrong size")
         call("tt_engine_reduce_grads", self._h, out.data_ptr(), int(accumulate), self._stream())
 
+    def k1_census(self, slot: int):
+        """(workgroups admitted, compute units used, most workgroups registered on one CU) of the streaming gather last
+        launched into `slot`; zeros when the engine does not stream this table.  Synchronises the current stream."""
+        a, c, m = C.c_int32(), C.c_int32(), C.c_int32()
+        call("tt_engine_k1_census", self._h, int(slot), C.byref(a), C.byref(c), C.byref(m), self._stream())
+        return a.value, c.value, m.value
+
+    def reduce_grads_range(self, out: torch.Tensor, offset: int, count: int, accumulate: bool = False) -> None:
+        """out[offset : offset + count] (+)= slab sum of those parameters only (`out` is the whole flat bucket)."""
+        _req(out, "grad_out", torch.float32, 1)
+        if out.numel() != self.n_params:
+            raise ValueError("grad_out: wrong size")
+        call("tt_engine_reduce_grads_range", self._h, out.data_ptr(), int(offset), int(count), int(accumulate), self._stream())
+
+    def set_dw2_event(self, event: Optional["torch.cuda.Event"]) -> None:
+        """`event` is recorded inside fwd_bwd()/backward() as soon as the dW2 / db2 slabs of both towers are complete
+        (tt_engine_set_dw2_event); None clears it."""
+        if event is not None:
+            event.record(torch.cuda.current_stream(self.device))  # torch creates the HIP event at its first record()
+        self._dw2_event = event  # keep it alive while the engine holds its handle
+        call("tt_engine_set_dw2_event", self._h, None if event is None else event.cuda_event)
+
     def adam(self, step: int, lr: float, grads: Optional[torch.Tensor] = None, beta1=0.9, beta2=0.999, eps=1e-8) -> None:
         g = None
         if grads is not None:

@@ -85,12 +85,15 @@ def gather_pool_norm(
     out: Optional[torch.Tensor] = None,
     check_ids: bool = False,
     sliced: Optional[bool] = None,
+    stream_form: Optional[int] = None,
 ) -> torch.Tensor:
     """K1: normalize(mean_pool(table[input_ids], attention_mask)) -> [N, D].
     Replaces backend/model.py:51-56 (`embed` mode).  check_ids=True synchronises
     and raises if any unmasked id was outside [0, V).  sliced: force the per-text (False) or the
     XCD-sliced (True, tt_gather_pool_norm_sliced_f32) form; None picks the faster one for the
-    shape (tt_k1_prefers_sliced).  Same result to fp32 summation order."""
+    shape (tt_k1_prefers_sliced).  Same result to fp32 summation order.  stream_form=n: the streaming
+    form (tt_gather_pool_norm_stream_f32: persistent workgroups, at most n per compute unit; bitwise the
+    per-text result) — what the engine uses for tables that stream from HBM."""
     _req(table, "table", torch.float32, 2)
     _req(input_ids, "input_ids", ndim=2)
     iw = _int_tensor(input_ids, "input_ids")
@@ -107,16 +110,22 @@ def gather_pool_norm(
             raise ValueError(f"out: expected {(N, D)}, got {tuple(out.shape)}")
     flag = torch.zeros(1, dtype=torch.int32, device=table.device) if check_ids else None
     with torch.cuda.device(table.device):
-        if sliced is None:
-            sliced = bool(_lib.load().tt_k1_prefers_sliced(V, D, N, S)) and table.data_ptr() % 16 == 0
-        if sliced:
-            nbytes = int(_lib.load().tt_gather_pool_sliced_workspace_bytes(N, D))
-            ws = _scratch(table.device, nbytes)
-            call("tt_gather_pool_norm_sliced_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw,
-                 _ptr(lens), out.data_ptr(), N, S, D, V, _ptr(flag), ws.data_ptr(), nbytes, _stream())
+        if stream_form:
+            nbytes = int(_lib.load().tt_gather_pool_stream_workspace_bytes())
+            ws = _scratch(table.device, nbytes)  # queue head + per-CU registry; stream-ordered reuse
+            call("tt_gather_pool_norm_stream_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw,
+                 _ptr(lens), out.data_ptr(), N, S, D, V, _ptr(flag), ws.data_ptr(), nbytes, int(stream_form), _stream())
         else:
-            call("tt_gather_pool_norm_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw, _ptr(lens),
-                 out.data_ptr(), N, S, D, V, _ptr(flag), _stream())
+            if sliced is None:
+                sliced = bool(_lib.load().tt_k1_prefers_sliced(V, D, N, S)) and table.data_ptr() % 16 == 0
+            if sliced:
+                nbytes = int(_lib.load().tt_gather_pool_sliced_workspace_bytes(N, D))
+                ws = _scratch(table.device, nbytes)
+                call("tt_gather_pool_norm_sliced_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw,
+                     _ptr(lens), out.data_ptr(), N, S, D, V, _ptr(flag), ws.data_ptr(), nbytes, _stream())
+            else:
+                call("tt_gather_pool_norm_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw, _ptr(lens),
+                     out.data_ptr(), N, S, D, V, _ptr(flag), _stream())
     if check_ids and int(flag.item()) != 0:
         raise IndexError(f"input_ids contains a token id outside [0, {V})")
     return out

@@ -196,7 +196,7 @@ class TripletTrainer:
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
                  process_group=None, engine=None, overlap_streams: Optional[bool] = None,
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
-                 freeze_gc: bool = True, exchange: Optional[bool] = None):
+                 freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: Optional[bool] = None):
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -251,6 +251,23 @@ class TripletTrainer:
         self._exchange = (self.world > 1) if exchange is None else bool(exchange)
         self._gather_under_exchange = os.environ.get("TT_GATHER_UNDER_EXCHANGE", "1") != "0"  # A/B knob
         self.bucket = torch.empty_like(self.flat) if (self._exchange or self.accumulation_steps > 1) else None
+        # TT_DP_SPLIT=1 / split_exchange=True: the exchange in two parts — the second-layer gradients (dW2, db2 of both
+        # towers: complete before the dH -> dW1 chain starts) are reduced and all-reduced on a second stream UNDER that
+        # chain, only the first-layer gradients travel after it (see _split_step).  Same sums per element, so with two
+        # replicas bitwise the one-bucket step; an A/B knob until RCCL hardware says which is faster.
+        if split_exchange is None:
+            split_exchange = os.environ.get("TT_DP_SPLIT", "0") == "1"
+        self._split = bool(split_exchange) and self._exchange and hasattr(self.engine, "reduce_grads_range")
+        if self._split:
+            tn = self.engine.n_params // 2                      # floats per tower: W1 | b1 | W2 | b2
+            n1 = self.P * self.D + self.P                       # W1 | b1
+            self._late = [(0, n1), (tn, n1)]
+            self._early = [(n1, tn - n1), (tn + n1, tn - n1)]   # W2 | b2 of the query tower, of the document tower
+            self._comm = self._ev_dw2 = self._ev_early = None
+            if self.device.type == "cuda":
+                self._comm = torch.cuda.Stream(self.device)
+                self._ev_dw2, self._ev_early = torch.cuda.Event(), torch.cuda.Event()
+                self.engine.set_dw2_event(self._ev_dw2)
         self.step_count = 0        # optimizer steps taken
         self._micro = 0            # batches since the last optimizer step (carried across epochs, like the reference)
         if self.world > 1:
@@ -486,6 +503,9 @@ class TripletTrainer:
                 issue_next()
             return
         first_micro = not (k > 1 and self._micro % k != 1)
+        if self._split:
+            self._split_step(local_B, first_micro, do_step, issue_next)
+            return
         if local_B > 0:
             self.engine.reduce_grads(self.bucket, accumulate=not first_micro)
         elif first_micro:  # an empty shard contributes zero gradients but still takes part in the all-reduce
@@ -575,6 +595,64 @@ class TripletTrainer:
         self.engine.read_stats(reset=True)  # the dry steps' losses do not belong to any epoch
         self.calibration = {"backward": pick, "ms_per_step": best, "steps": steps, "rounds": rounds}
         return self.calibration
+
+    def _split_step(self, local_B: int, first_micro: bool, do_step: bool, issue_next) -> None:
+        """Slab reduce + exchange + Adam with the bucket cut in two (TT_DP_SPLIT=1).  `early` = dW2 / db2 of both
+        towers: their slabs are complete when the engine records `_ev_dw2` (inside fwd_bwd, before dH -> dW1), so a
+        second stream reduces and all-reduces them while the caller's stream is still computing dW1 / db1; `late` =
+        dW1 / db1, reduced and exchanged on the caller's stream after that chain, as the whole bucket is otherwise."""
+        eng, bucket = self.engine, self.bucket
+        cuda = self.device.type == "cuda"
+        main = torch.cuda.current_stream(self.device) if cuda else None
+
+        def reduce(parts):
+            for off, n in parts:
+                if local_B > 0:
+                    eng.reduce_grads_range(bucket, off, n, accumulate=not first_micro)
+                elif first_micro:  # an empty shard contributes zeros but takes part in every collective
+                    bucket[off: off + n].zero_()
+
+        if cuda:
+            if local_B > 0:
+                self._comm.wait_event(self._ev_dw2)   # recorded by the engine once dW2 / db2 are complete
+            else:
+                self._comm.wait_stream(main)
+            with torch.cuda.stream(self._comm):
+                reduce(self._early)
+                if do_step:
+                    self._all_reduce_parts(self._early)
+                self._ev_early.record(self._comm)
+        else:
+            reduce(self._early)
+            if do_step:
+                self._all_reduce_parts(self._early)
+        reduce(self._late)
+        if issue_next is not None:
+            issue_next()
+        if do_step:
+            self._all_reduce_parts(self._late)
+        if cuda:
+            main.wait_event(self._ev_early)  # before Adam — or, on a micro-batch, before the next fwd_bwd rewrites the slabs
+        if do_step:
+            self.step_count += 1
+            eng.adam(self.step_count, self.lr, bucket, self.betas[0], self.betas[1], self.eps)
+
+    def _all_reduce_parts(self, parts) -> None:
+        """ONE collective launch over several views of the flat bucket (RCCL: a coalesced group)."""
+        views = [self.bucket[off: off + n] for off, n in parts]
+        if dist.get_backend(self.pg) == "nccl":
+            with dist._coalescing_manager(group=self.pg, device=self.device, async_ops=False):
+                for v in views:
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg)
+        elif self.device.type == "cpu":
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")  # gloo (CPU rehearsal) has no coalescing manager; this call is its equivalent
+                dist.all_reduce_coalesced(views, op=dist.ReduceOp.SUM, group=self.pg)
+        else:  # gloo with device tensors (ranks sharing a GPU in tests): no coalesced form, one collective per view
+            for v in views:
+                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _all_reduce(self, bucket: torch.Tensor) -> None:
         """The step's one gradient exchange: sum of the flat bucket over the replicas (RCCL over xGMI on GPUs).

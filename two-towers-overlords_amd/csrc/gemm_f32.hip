@@ -132,6 +132,28 @@ __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, 
   return make_float4(p[0], p[R], p[2 * R], p[3 * R]);
 }
 
+// ---- split-bf16 products (PREC = 1; TT_BF3=1, an opt-in experiment, never the default) -------------------------------
+// An fp32 value x is split exactly into three bf16 terms, x = hi + mid + lo (hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid): each remainder is exact in fp32, the 24-bit significand is three 8-bit pieces), and a product
+// a * b is taken as the six bf16 products whose weight is >= 2^-16 of it: hi*hi + hi*mid + mid*hi + hi*lo + mid*mid + lo*hi
+// (bf16 x bf16 is exact in the MFMA's fp32 accumulator; the three dropped terms are <= 2^-23 |a b|, one fp32 ulp).
+// v_mfma_f32_32x32x16_bf16 runs 16x the FLOP per cycle of the fp32 MFMA, so six of them cost 3/8 of the cycles.  Operands
+// stay fp32 in memory and in LDS (same staging, same images); the split happens on the fragments, in registers.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 a = (__bf16)x[j];
+    const float r1 = x[j] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    hi[j] = a;
+    mid[j] = b;
+    lo[j] = (__bf16)r2;
+  }
+}
+
 template <int LAYOUT, int WM, int WN, int BK = 32>
 struct TileCfg {
   static constexpr int BM = 64 * WM, BN = 64 * WN, BKP = BK + 4;
@@ -148,10 +170,11 @@ struct TileCfg {
 };
 
 // One workgroup's tile: (bx, by) tile coordinates, bz = group * nsplit + split.
-template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32>
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32, int PREC = 0>
 __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ lds, int bx, int by, int bz) {
   using Cfg = TileCfg<LAYOUT, WM, WN, BK>;
   constexpr int BM = 64 * WM, BN = 64 * WN;
+  [[maybe_unused]] constexpr int BKP = Cfg::BKP;
   constexpr bool A_KC = (LAYOUT != kTN);
   constexpr bool B_KC = (LAYOUT == kNT);
   constexpr int A_TILE = Cfg::A_TILE;
@@ -223,6 +246,53 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   auto compute = [&](int buf) {
     const float* __restrict__ As = lds + buf * (A_TILE + B_TILE);
     const float* __restrict__ Bs = As + A_TILE;
+    if constexpr (PREC == 1) {
+      // 16-wide K chunks; lane (r, h) holds k = 16 c + 8 h + 0..7 of its row / column
+#pragma unroll
+      for (int c = 0; c < BK / 16; ++c) {
+        bf16x8 ah[WM], am[WM], al[WM], bh[WN], bm[WN], bl[WN];
+        const int k8 = 16 * c + 8 * h;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          const int row = (wrow * WM + i) * 32 + r;
+          float x[8];
+          if (A_KC) {
+            const float4 v0 = *reinterpret_cast<const float4*>(As + row * BKP + k8);
+            const float4 v1 = *reinterpret_cast<const float4*>(As + row * BKP + k8 + 4);
+            x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = As[(k8 + j) * BM + row];
+          }
+          split_bf3(x, ah[i], am[i], al[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < WN; ++i) {
+          const int col = (wcol * WN + i) * 32 + r;
+          float x[8];
+          if (B_KC) {
+            const float4 v0 = *reinterpret_cast<const float4*>(Bs + col * BKP + k8);
+            const float4 v1 = *reinterpret_cast<const float4*>(Bs + col * BKP + k8 + 4);
+            x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = Bs[(k8 + j) * BN + col];
+          }
+          split_bf3(x, bh[i], bm[i], bl[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int jj = 0; jj < WN; ++jj) {  // smallest terms first
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[jj], acc[i][jj], 0, 0, 0);
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[jj], acc[i][jj], 0, 0, 0);
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[jj], acc[i][jj], 0, 0, 0);
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+          }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
       float4 fa[WM], fb[WN];
@@ -245,6 +315,7 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
           acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[jj].z, acc[i][jj], 0, 0, 0);
           acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[jj].w, acc[i][jj], 0, 0, 0);
         }
+    }
     }
     if (do_colsum && tid < BM) {
 #pragma unroll
@@ -473,10 +544,22 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   gemm_body<LAYOUT, EPI, WM, WN, VEC, BK>(b, lds, bx, by, bz);
 }
 
+// Split-bf16 variant (PREC = 1) of the vector-path tiles: TT_BF3=1 only.
+template <int LAYOUT, int EPI, int WM, int WN, int BK>
+__global__ __launch_bounds__(kThreads) void gemm_bf3_kernel(const Batch b) {
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, BK>::LDS_FLOATS];
+  int bx, by, bz;
+  if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
+  gemm_body<LAYOUT, EPI, WM, WN, true, BK, 1>(b, lds, bx, by, bz);
+}
+
 // The BK = 16 tile shares a CU with the streaming gather's workgroup (gather_pool.hip): three waves per SIMD's worth
 // of registers (<= 168) leave room for two of these workgroups plus the gather's 4 waves of up to 176.
+#ifndef TT_BK16_WAVES
+#define TT_BK16_WAVES 3  // build-time A/B: 4 = 128 registers (a few dwords of scratch outside the K loop)
+#endif
 template <int LAYOUT, int EPI, int WM, int WN>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 8)))
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TT_BK16_WAVES, 8)))
 void gemm_f32_bk16_kernel(const Batch b) {
   __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, 16>::LDS_FLOATS];
   int bx, by, bz;
@@ -546,6 +629,15 @@ int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
     if (total > 0x7fffffffLL) b.xcd_order = 0;
     else grid = dim3((unsigned)total, 1, 1);
   }
+  static const bool bf3 = getenv("TT_BF3") && getenv("TT_BF3")[0] == '1';  // split-bf16 products: opt-in experiment
+  if (vec && bf3) {  // every vector-path tile has its split-bf16 twin: one arithmetic for the whole run
+    if (wm == 1) hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 1, 1, 32>), grid, block, 0, st, b);
+    else if (wn == 1) hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 2, 1, 32>), grid, block, 0, st, b);
+    else if (bk == 16) hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 2, 2, 16>), grid, block, 0, st, b);
+    else hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 2, 2, 32>), grid, block, 0, st, b);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+  }
   if (!vec) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1, false>), dim3((maxN + 63) / 64, (maxM + 63) / 64, b.count * b.nsplit), block, 0, st, b);
   else if (wm == 1 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1, true>), grid, block, 0, st, b);
   else if (wm == 2 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 2, 1, true>), grid, block, 0, st, b);
@@ -563,7 +655,8 @@ int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStrea
   bool vec = true;
   for (int i = 0; i < bt.count; ++i) vec = vec && (bt.p[i].M == 0 || problem_vec_ok<kTN>(bt.p[i]));
   for (int i = 0; i < bn.count; ++i) vec = vec && (bn.p[i].M == 0 || problem_vec_ok<kNN>(bn.p[i]));
-  if (!vec || !((wm == 1 && wn == 1) || (wm == 2 && wn == 1))) {  // odd shapes: two ordinary launches
+  static const bool bf3 = getenv("TT_BF3") && getenv("TT_BF3")[0] == '1';  // the pair kernel has no split-bf16 twin
+  if (!vec || bf3 || !((wm == 1 && wn == 1) || (wm == 2 && wn == 1))) {  // odd shapes: two ordinary launches
     int rc = launch(kTN, kStore, bt, 1, 1, st);
     if (rc != TT_OK) return rc;
     return launch(kNN, kReluMask, bn, wm, wn, st);

@@ -7,6 +7,7 @@
 //   S[i,j]  = cos(q_i, d_j)                                   (eps 1e-8, like F.cosine_similarity)
 //   L       = loss_scale * sum_i sum_{j valid} relu(S[i,j] - S[i,pos_i] + margin)
 //   valid j : j != pos_i and (no query ids given or qid_d[j] != qid_q[i])
+#include <cstdlib>
 #include "gemm_f32.h"
 
 int tt_launch_loss_mean(const float* hinge_rows, long long B, float denom, float* loss, double* acc_sum,
@@ -16,35 +17,39 @@ namespace {
 
 constexpr int kThreads = 256;
 
-__global__ __launch_bounds__(kThreads) void unit_rows_norm_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                  float* __restrict__ nrm, long long rows, int P,
-                                                                  float eps) {
+// Unit rows and the positives' similarities in one launch.  Rows [0, Bq): query i -> qhat_i = q_i / max(|q_i|, eps),
+// |q_i| and s_pos[i] = qhat_i . dhat_{pos_i}, which every column tile of row i needs before the S product's epilogue
+// can turn S into dL/dS; rows [Bq, Bq + Bd): document j -> dhat_j, |d_j|.  s_pos is formed from the positive's RAW
+// row, normalised on the fly (divide, then fma chain), so it does not have to wait for dhat.
+__global__ __launch_bounds__(kThreads) void inbatch_prep_kernel(const float* __restrict__ q, const float* __restrict__ d,
+                                                                const int* __restrict__ pos_index, float* __restrict__ qh,
+                                                                float* __restrict__ dh, float* __restrict__ nq,
+                                                                float* __restrict__ nd, float* __restrict__ s_pos,
+                                                                long long Bq, long long Bd, int P, float eps) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* __restrict__ xr = x + row * P;
+  if (row >= Bq + Bd) return;
+  const bool is_q = row < Bq;
+  const long long r = is_q ? row : row - Bq;
+  const float* __restrict__ xr = (is_q ? q : d) + r * P;
+  float* __restrict__ yr = (is_q ? qh : dh) + r * P;
   float ss = 0.f;
   for (int c = lane; c < P; c += 64) ss = fmaf(xr[c], xr[c], ss);
   const float n = sqrtf(tt_wave_sum(ss));
   const float den = fmaxf(n, eps);
-  for (int c = lane; c < P; c += 64) y[row * P + c] = xr[c] / den;
-  if (lane == 0) nrm[row] = n;
-}
-
-// s_pos[i] = qhat_i . dhat_{pos_i} — the positive's similarity, needed by every column tile of row i before the
-// S product's epilogue can turn S into dL/dS (one wave per query).
-__global__ __launch_bounds__(kThreads) void pos_dot_kernel(const float* __restrict__ qh, const float* __restrict__ dh,
-                                                           const int* __restrict__ pos_index, float* __restrict__ s_pos,
-                                                           long long Bq, long long Bd, int P) {
-  const int lane = threadIdx.x & 63;
-  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= Bq) return;
-  long long pi = pos_index ? pos_index[i] : i;
+  for (int c = lane; c < P; c += 64) yr[c] = xr[c] / den;
+  if (lane == 0) (is_q ? nq : nd)[r] = n;
+  if (!is_q) return;
+  long long pi = pos_index ? pos_index[r] : r;
   pi = pi < 0 ? 0 : (pi >= Bd ? Bd - 1 : pi);
+  const float* __restrict__ pr = d + pi * P;
+  float sp = 0.f;
+  for (int c = lane; c < P; c += 64) sp = fmaf(pr[c], pr[c], sp);
+  const float pden = fmaxf(sqrtf(tt_wave_sum(sp)), eps);
   float t = 0.f;
-  for (int c = lane; c < P; c += 64) t = fmaf(qh[i * P + c], dh[pi * P + c], t);
+  for (int c = lane; c < P; c += 64) t = fmaf(xr[c] / den, pr[c] / pden, t);
   t = tt_wave_sum(t);
-  if (lane == 0) s_pos[i] = t;
+  if (lane == 0) s_pos[r] = t;
 }
 
 // After the S product (epilogue kHinge: S already replaced by dL/dS except on the positive's column): per query row,
@@ -76,15 +81,25 @@ __global__ __launch_bounds__(kThreads) void inbatch_finish_kernel(float* __restr
 
 // d(x / max(|x|, eps))^T applied to the upstream gradient u of the unit row:
 // dx = (u - xhat * (xhat . u) * r) / c,  c = max(|x|, eps), r = c/|x| (|x| > 0) else 0
-// `u` arrives as `nslabs` split-K partial slabs (slab z at u + z * slab_stride), summed here in slab order.
-__global__ __launch_bounds__(kThreads) void unit_rows_bwd_kernel(const float* __restrict__ xhat,
-                                                                 const float* __restrict__ nrm,
-                                                                 const float* __restrict__ u, int nslabs,
-                                                                 long long slab_stride, float* __restrict__ dx,
-                                                                 long long rows, int P, float eps, int accumulate) {
+// For queries (rows [0, Bq)) and documents (rows [Bq, Bq + Bd)) in one launch; `u` arrives as split-K partial
+// slabs (slab z at u + z * slab_stride), summed here in slab order.
+__global__ __launch_bounds__(kThreads) void unit_rows_bwd2_kernel(
+    const float* __restrict__ qh, const float* __restrict__ nq, const float* __restrict__ uq, int sq, long long stride_q,
+    float* __restrict__ dq, long long Bq, const float* __restrict__ dh, const float* __restrict__ nd,
+    const float* __restrict__ ud, int sd, long long stride_d, float* __restrict__ dd, long long Bd, int P, float eps,
+    int accumulate_dd) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const long long row0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row0 >= Bq + Bd) return;
+  const bool is_q = row0 < Bq;
+  const long long row = is_q ? row0 : row0 - Bq;
+  const float* __restrict__ xhat = is_q ? qh : dh;
+  const float* __restrict__ nrm = is_q ? nq : nd;
+  const float* __restrict__ u = is_q ? uq : ud;
+  const int nslabs = is_q ? sq : sd;
+  const long long slab_stride = is_q ? stride_q : stride_d;
+  float* __restrict__ dx = is_q ? dq : dd;
+  const int accumulate = is_q ? 0 : accumulate_dd;
   const long long o = row * P;
   auto uval = [&](int c) {
     float v = u[o + c];
@@ -118,6 +133,8 @@ static int grad_splits(long long rows, int P, long long K) {
 // block tile of the S product, in units of 64: 128x128 for large batches — only on the vector path (P % 4 == 0; the
 // unit rows live in the 16-byte aligned workspace), the scalar fallback of gemm_f32.hip always runs 64x64 tiles
 static int s_tile(long long Bq, long long Bd, int P) {
+  static const char* const v = getenv("TT_INBATCH_TILE");  // A/B: "1" = 64x64 tiles for the S product
+  if (v && v[0] == '1') return 1;
   return (P % 4 == 0 && P >= 4 && ((Bq + 63) / 64) * ((Bd + 63) / 64) >= 2048) ? 2 : 1;
 }
 static int col_tiles(long long Bq, long long Bd, int P) {  // column tiles of the S product: row stride of the partials
@@ -160,12 +177,8 @@ extern "C" int tt_inbatch_triplet_fwd_bwd_f32(const float* q, const float* d, co
   float* part_cnt = w;      w += r4((size_t)Bq * nt);
   float* S = w;
 
-  hipLaunchKernelGGL(unit_rows_norm_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(kThreads), 0, st, q, qh, nq, (long long)Bq, P, 1e-8f);
-  TT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(unit_rows_norm_kernel, dim3((unsigned)((Bd + 3) / 4)), dim3(kThreads), 0, st, d, dh, nd, (long long)Bd, P, 1e-8f);
-  TT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(pos_dot_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(kThreads), 0, st, qh, dh, pos_index, s_pos, (long long)Bq,
-                     (long long)Bd, P);
+  hipLaunchKernelGGL(inbatch_prep_kernel, dim3((unsigned)((Bq + Bd + 3) / 4)), dim3(kThreads), 0, st, q, d, pos_index, qh, dh, nq,
+                     nd, s_pos, (long long)Bq, (long long)Bd, P, 1e-8f);
   TT_CHECK_LAUNCH();
 
   {  // G = dL/dS of S = qh dh^T, the hinge applied in the product's epilogue: S itself is never stored   [Bq, Bd]
@@ -211,11 +224,8 @@ extern "C" int tt_inbatch_triplet_fwd_bwd_f32(const float* q, const float* d, co
     int rc = ttg::launch(ttg::kTN, ttg::kStore, b, 1, 1, st);
     if (rc != TT_OK) return rc;
   }
-  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(kThreads), 0, st, qh, nq, uq, sq, stride_q, dq,
-                     (long long)Bq, P, 1e-8f, 0);
-  TT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((unsigned)((Bd + 3) / 4)), dim3(kThreads), 0, st, dh, nd, ud, sd, stride_d, dd,
-                     (long long)Bd, P, 1e-8f, accumulate_dd);
+  hipLaunchKernelGGL(unit_rows_bwd2_kernel, dim3((unsigned)((Bq + Bd + 3) / 4)), dim3(kThreads), 0, st, qh, nq, uq, sq, stride_q, dq,
+                     (long long)Bq, dh, nd, ud, sd, stride_d, dd, (long long)Bd, P, 1e-8f, accumulate_dd);
   TT_CHECK_LAUNCH();
   return TT_OK;
 }

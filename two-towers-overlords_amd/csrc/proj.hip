@@ -21,15 +21,15 @@ int choose_nsplit(long long M) {
 }
 
 // block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
-// 96x96 tiles (gemm16.hip) or the 64x64 / 128-row tiles of gemm_f32.hip for a grouped [rows x N] product?  Whichever
-// needs fewer tile-rounds x tile area on the chip's CUs (a CU runs its tiles' MFMAs one after the other, so the
-// CU with the most tiles sets the time).  Only where the chain has the chip to itself (cache-fed epochs — what
-// run_training runs by default — evaluation, one-stream steps): beside the token gathers the 64x64 tile is paired with
-// the gather's LDS reservation (engine.hip).  TT_G16=0|1 forces the choice (A/B).
+// 96x96 tiles (gemm16.hip) for a grouped [rows x N] forward product: TT_G16=1 (A/B runs) where the tile-count model
+// says they need fewer tile-rounds x tile area than the current tiles ([6144 x 384]: 256 tiles of 96x96 = one per CU,
+// against 576 of 64x64 = 2.25, paid as 3).  NOT selected by default — measured on MI355X at that shape
+// (profiles/r03_gemm16_ab.txt): the kernel alone is faster (20.6 vs 24.8 us per forward GEMM), the step is not
+// (cache-fed 129.0 vs 128.9 us, one-stream 234.7 vs 235.3 us, beside the gathers 233 vs 194 us): see DESIGN.md section 8.
 static bool prefer_tile96(const ttg::Batch& b, int policy, int wm, int wn) {
   static const char* const v = getenv("TT_G16");
-  if (v && *v) return *v != '0';
-  if (policy != kTileAuto) return false;
+  if (!(v && v[0] == '1')) return false;
+  (void)policy;
   const long long cus = 256;
   long long t_cur = 0, t_96 = 0;
   for (int i = 0; i < b.count; ++i) {
@@ -39,7 +39,8 @@ static bool prefer_tile96(const ttg::Batch& b, int policy, int wm, int wn) {
   }
   const long long cost_cur = ((t_cur + cus - 1) / cus) * (64LL * wm) * (64LL * wn);
   const long long cost_96 = ((t_96 + cus - 1) / cus) * 96LL * 96LL;
-  return cost_96 * 10 <= cost_cur * 9;  // at least 10 % fewer tile-rounds x area
+  static const bool force = getenv("TT_G16_FORCE") != nullptr;  // every shape (parity tests)
+  return force || cost_96 * 10 <= cost_cur * 9;  // at least 10 % fewer tile-rounds x area
 }
 
 static int launch_rows(ttg::Layout layout, ttg::Epilogue epi, const ttg::Batch& b, int wm, int wn, int bk, int policy,

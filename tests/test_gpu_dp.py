@@ -305,15 +305,22 @@ def _split_worker(rank, world, port, backend, q):
 
 
 def _run_split(backend):
+    import queue as _queue
+
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = 29300 + os.getpid() % 500 + (17 if backend == "nccl" else 0)
     procs = [ctx.Process(target=_split_worker, args=(r, 2, port, backend, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = q.get()
+    try:
+        out = q.get(timeout=420)  # a rank that hangs in a collective must fail the test, not the whole session
+    except _queue.Empty:
+        out = ("error", f"no result from the {backend} ranks within 420 s", None)
     for p in procs:
-        p.join(240)
+        p.join(60)
+        if p.is_alive():
+            p.kill()
     assert out[0] == "ok", out[1]
     assert all(p.exitcode == 0 for p in procs)
     return out[1]

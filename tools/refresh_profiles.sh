@@ -39,7 +39,9 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
         if "gemm" in n:
-            acc[n.split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            import re
+            m = re.search(r"(gemm\w+_kernel<[^>]*>)", n)
+            acc[m.group(1) if m else n[:80]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 print("==", sys.argv[2], "(SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs), second half of the launches)")
 for k, c in acc.items():
     m = {n: sum(v[len(v) // 2:]) / max(len(v[len(v) // 2:]), 1) for n, v in c.items()}

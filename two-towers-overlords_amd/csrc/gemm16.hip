@@ -2,10 +2,12 @@
 //
 // Why a second tile shape.  The 32x32x2 kernel (gemm_f32.hip) builds its block tile from four 32x32 wave tiles, so
 // the finest split of a [6144 x 384] output (BASELINE.json configs[1]: three encodes of 2048 rows, P = 384) is 576
-// tiles of 64x64 on 256 CUs: 2.25 per CU, paid as 3.  6144 x 384 is exactly 256 tiles of 96x96 — one per CU — and
-// a 96x96 tile is 6 x 6 accumulator blocks of 16x16: twelve waves (three per SIMD) own a 16x48 strip each (three
-// accumulators, one A fragment reused over three B fragments).  Same arithmetic as the other kernel: each output is
-// a k-ordered fp32 fmaf chain (what the MFMA computes, bitwise), K-steps in ascending order.
+// tiles of 64x64 on 256 CUs: 2.25 per CU, paid as 3.  A 96x96 tile is 6 x 6 accumulator blocks of 16x16: twelve waves
+// (three per SIMD) own a 16x48 strip each (three accumulators, one A fragment reused over three B fragments), and a
+// single [6144 x 384] matrix would be exactly 256 of them.  Same arithmetic as the other kernel: each output is a
+// k-ordered fp32 fmaf chain (what the MFMA computes, bitwise), K-steps in ascending order.
+// STATUS: opt-in (TT_G16=1).  The step's product is two towers of 2048 + 4096 rows (260 tiles, four CUs get two) and
+// measured slower than the 64x64 tiles in every mode (profiles/r03_gemm16_ab.txt).
 //
 // Work per K-step of 32 and workgroup: every thread stages ONE 16-byte chunk of A and one of B (768 threads = the
 // 96 x 32 / 4 chunks of a tile), two K-steps ahead of their use (two register sets, two LDS buffers, one barrier per

@@ -22,10 +22,10 @@ int choose_nsplit(long long M) {
 
 // block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
 // 96x96 tiles (gemm16.hip) for a grouped [rows x N] forward product: TT_G16=1 (A/B runs) where the tile-count model
-// says they need fewer tile-rounds x tile area than the current tiles ([6144 x 384]: 256 tiles of 96x96 = one per CU,
-// against 576 of 64x64 = 2.25, paid as 3).  NOT selected by default — measured on MI355X at that shape
-// (profiles/r03_gemm16_ab.txt): the kernel alone is faster (20.6 vs 24.8 us per forward GEMM), the step is not
-// (cache-fed 129.0 vs 128.9 us, one-stream 234.7 vs 235.3 us, beside the gathers 233 vs 194 us): see DESIGN.md section 8.
+// says they need at least 10 % fewer tile-rounds x tile area than the current tiles; TT_G16_FORCE=1: every shape.
+// NOT selected by default.  At BASELINE.json configs[1] the two towers' 2048 + 4096 rows make 260 tiles of 96x96 (not
+// the 256 a single [6144 x 384] matrix would), and forced it measured slower: cache-fed 132 vs 129 us, one stream
+// 253 vs 235 us, beside the gathers 233 vs 194 us (profiles/r03_gemm16_ab.txt).
 static bool prefer_tile96(const ttg::Batch& b, int policy, int wm, int wn) {
   static const char* const v = getenv("TT_G16");
   if (!(v && v[0] == '1')) return false;

@@ -728,6 +728,8 @@ int launch_stream(const float* table, const void* ids, const void* mask, const i
       else if (env_u == 5) TT_STREAM_CASE(3, 5);
       else if (env_u == 7) TT_STREAM_CASE(3, 7);
       else if (env_u == 8) TT_STREAM_CASE(3, 8);
+      else if (env_u == 10) TT_STREAM_CASE(3, 10);
+      else if (env_u == 12) TT_STREAM_CASE(3, 12);
       else TT_STREAM_CASE(3, 6);
       break;
     default: if (env_u == 4) TT_STREAM_CASE(4, 4); else TT_STREAM_CASE(4, 5); break;

@@ -102,3 +102,31 @@ def test_k1_form_selection_and_workspace_rules(monkeypatch):
     assert metric - small >= 3 * ws(3 * 2048, 384)            # three slots of partial sums, only where sliced applies
     assert engine_bytes(30522, 384, _lib.TT_K1_SHARE_AUTO) == metric  # sharing mode does not change the layout
     assert engine_bytes(30522, 384, -2) == 0                          # invalid sharing mode
+
+
+def test_k1_streaming_form_selection_and_argument_checks(monkeypatch):
+    """Host-only logic of the streaming gather (tables that come from HBM): which shapes get it
+    (tt_k1_prefers_stream), its fixed-size workspace, and the argument checks that run before any launch."""
+    lib = pkg.load()
+    monkeypatch.delenv("TT_K1_STREAM", raising=False)
+    pref = lib.tt_k1_prefers_stream
+    assert pref(250000, 768, 49152, 256) == 1       # BASELINE.json configs[3]: 768 MB, three Infinity Caches
+    assert pref(30522, 384, 6144, 128) == 0         # the MiniLM table is cache-resident: the XCD-sliced form's territory
+    assert pref(250000, 768, 512, 256) == 0         # too few tokens to keep persistent workgroups busy
+    assert pref(250000, 770, 49152, 256) == 0       # D % 4 != 0: generic path only
+    monkeypatch.setenv("TT_K1_STREAM", "1")
+    assert pref(30522, 384, 6144, 128) == 1
+    monkeypatch.setenv("TT_K1_STREAM", "0")
+    assert pref(250000, 768, 49152, 256) == 0
+    monkeypatch.delenv("TT_K1_STREAM")
+
+    nbytes = lib.tt_gather_pool_stream_workspace_bytes()
+    assert nbytes == (4 + 4096) * 4                 # queue head + counters + one registry slot per compute-unit key
+    f = lib.tt_gather_pool_norm_stream_f32
+    # (table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob, workspace, workspace_bytes, workgroups_per_cu, stream)
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, None, nbytes, 2, None) == -1      # no workspace
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, nbytes - 1, 2, None) == -5    # short workspace
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, nbytes, 0, None) == -2        # no workgroups per CU
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 386, 1000, None, 16, nbytes, 2, None) == -2        # D % 4 != 0
+    assert f(16, 16, 2, None, 4, None, 16, 8, 128, 384, 1000, None, 16, nbytes, 2, None) == -3        # bad id width
+    assert f(16, 16, 4, None, 4, None, 16, 0, 128, 384, 1000, None, 16, nbytes, 2, None) == 0         # no texts: nothing to do

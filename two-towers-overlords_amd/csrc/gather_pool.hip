@@ -274,10 +274,15 @@ __global__ __launch_bounds__(kThreads) void pool_norm_stream_kernel(
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, long long N, int S, int D, long long V,
     int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store, StreamCtl* __restrict__ ctl,
-    int per_cu) {
+    int per_cu, int prio) {
   __shared__ float4 part[kWavesPerText][C * TT_WAVE];
   __shared__ float red[kWavesPerText];
   __shared__ int s_next;
+  // A/B (TT_K1_STREAM_PRIO): the gather's waves issue a handful of vector-memory instructions per microsecond; at a
+  // raised wave priority they win the issue arbitration against the MFMA kernels' waves on their SIMD
+  if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
   if (threadIdx.x == 0) {
     int next = -1;
     if (atomicAdd(&ctl->cu[tt_cu_key()], 1) < per_cu) {
@@ -319,8 +324,10 @@ template <typename IdT, typename MaskT, int C, int U, int NS, int MAXSEG, int WP
 __global__ __launch_bounds__(WPB * TT_WAVE) void pool_sliced_kernel(
     const float* __restrict__ table, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ partial, float* __restrict__ wsum_out, long long N,
-    int S, int D, long long V, int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
+    int S, int D, long long V, int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store, int prio) {
   extern __shared__ int sliced_lds[];  // per wave: 2 x ([S] ids + [S] weights)
+  if (prio == 1) __builtin_amdgcn_s_setprio(1);  // A/B (TT_K1_PRIO): wave priority of the gather beside the MFMA kernels
+  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const int wave = threadIdx.x >> 6;
   static_assert(NS == 8, "one residue class per XCD");
@@ -659,6 +666,7 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   // form.  TT_K1_SLICED_BPC=n (A/B) makes the grid persistent instead: n workgroups per CU walking the
   // texts — within 5 % alone, 4 % slower beside the projection kernels (213-216 vs 205 us per step).
   static const int persist_bpc = getenv("TT_K1_SLICED_BPC") ? atoi(getenv("TT_K1_SLICED_BPC")) : 0;
+  static const int k1_prio = getenv("TT_K1_PRIO") ? atoi(getenv("TT_K1_PRIO")) : 0;
   long long G = groups_all;
   unsigned lds = (unsigned)(4 * wpb * S * sizeof(int));
   if (persist_bpc > 0) {
@@ -673,7 +681,7 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
 #define TT_SLICED_LAUNCH_W(CC, UU, MS, WW)                                                                    \
   hipLaunchKernelGGL((pool_sliced_kernel<IdT, MaskT, CC, UU, kSlices, MS, WW>), dim3((unsigned)(G * kSlices)), \
                      dim3(WW * TT_WAVE), lds, st, table, ids_t, mask_t, lens, partial, wsum, (long long)N, S, D, \
-                     (long long)V, oob, text_rows, (long long)n_store)
+                     (long long)V, oob, text_rows, (long long)n_store, k1_prio)
 #define TT_SLICED_LAUNCH(CC, UU, MS)                       \
   do {                                                     \
     if (wpb == 6) TT_SLICED_LAUNCH_W(CC, UU, MS, 6);       \
@@ -716,10 +724,11 @@ int launch_stream(const float* table, const void* ids, const void* mask, const i
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
   // rows in flight per wave: TT_K1_STREAM_U (A/B) or 96 KB per workgroup (4 waves x U rows x C KiB)
   static const int env_u = getenv("TT_K1_STREAM_U") ? atoi(getenv("TT_K1_STREAM_U")) : 0;
+  static const int prio = getenv("TT_K1_STREAM_PRIO") ? atoi(getenv("TT_K1_STREAM_PRIO")) : 0;
 #define TT_STREAM_CASE(CC, UU)                                                                               \
   hipLaunchKernelGGL((pool_norm_stream_kernel<IdT, MaskT, CC, UU>), dim3((unsigned)wgs), dim3(kThreads),     \
                      k1_dynamic_lds(lds_total, CC * 4096u + 32u), st, table, ids_t, mask_t, lens, out,       \
-                     (long long)N, S, D, (long long)V, oob, text_rows, (long long)n_store, ctl, per_cu)
+                     (long long)N, S, D, (long long)V, oob, text_rows, (long long)n_store, ctl, per_cu, prio)
   switch (C) {
     case 1: if (env_u == 8) TT_STREAM_CASE(1, 8); else TT_STREAM_CASE(1, 16); break;
     case 2: if (env_u == 8) TT_STREAM_CASE(2, 8); else TT_STREAM_CASE(2, 12); break;

@@ -56,6 +56,7 @@ struct Batch {
   // only): tiles that re-read the same operand block run on ONE XCD, back to back, so the block crosses the fabric
   // once instead of once per tile.  kNT / kNN: the n-tiles of a row panel; kTN: all tiles of one split-K slab.
   // Worth it where the fabric is the shared bottleneck (beside the streaming gather); 0 = plain 3-D grid.
+  int wave_prio;   // A/B (TT_GEMM_PRIO): s_setprio of the kernel's waves (0 = leave it)
   HingeEpi hinge;  // kHinge only
   int xcd_order;
   int gx, gy, gz;         // tile grid (filled by the launcher when xcd_order is set)

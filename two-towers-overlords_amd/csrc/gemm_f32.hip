@@ -184,6 +184,9 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
 
   constexpr int CP = Cfg::CP;  // padded row of the epilogue's C tile
 
+  if (b.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (b.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (b.wave_prio == 3) __builtin_amdgcn_s_setprio(3);
   const int grp = bz / b.nsplit;
   const int split = bz - grp * b.nsplit;
   // Copy the problem descriptor out of the kernarg segment once: stores to C could
@@ -609,6 +612,8 @@ bool problem_vec_ok(const Problem& p) {
 template <int LAYOUT, int EPI>
 int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
   Batch b = b_in;
+  static const int gemm_prio = getenv("TT_GEMM_PRIO") ? atoi(getenv("TT_GEMM_PRIO")) : 0;  // A/B
+  b.wave_prio = gemm_prio;
   int maxM = 0, maxN = 0;
   for (int i = 0; i < b.count; ++i) {
     maxM = b.p[i].M > maxM ? b.p[i].M : maxM;
@@ -680,8 +685,11 @@ int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStrea
   static const bool mid = !(getenv("TT_PAIR_ORDER") && getenv("TT_PAIR_ORDER")[0] == '0');
   g.tn_head = (mid && bt.count > 1 && bt.p[0].K > bt.p[1].K) ? g.tn_gx * g.tn_gy * bt.nsplit : g.tn_blocks;
   const dim3 grid((unsigned)total), block(kThreads);
-  if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1>), grid, block, 0, st, bt, bn, g);
-  else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1>), grid, block, 0, st, bt, bn, g);
+  static const int gemm_prio = getenv("TT_GEMM_PRIO") ? atoi(getenv("TT_GEMM_PRIO")) : 0;  // A/B
+  Batch bt2 = bt, bn2 = bn;
+  bt2.wave_prio = bn2.wave_prio = gemm_prio;
+  if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1>), grid, block, 0, st, bt2, bn2, g);
+  else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1>), grid, block, 0, st, bt2, bn2, g);
   TT_CHECK_LAUNCH();
   return TT_OK;
 }

@@ -20,9 +20,11 @@ def _run(*extra, timeout=600):
 @pytest.mark.skipif(torch.cuda.is_available(), reason="the GPU variant below covers a box with a GPU")
 def test_self_launch_spawns_one_rank_per_gpu_and_forwards_the_exit_code():
     r = _run()
-    # no GPU here: both ranks stop with the product's "needs an MI355X" message, and the parent returns their failure
+    # no GPU here: a rank stops with the product's "needs an MI355X" message (the elastic agent tears the other one down
+    # as soon as the first has failed, so it may not get to print its own), and the parent returns that failure
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]
+    assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr  # it did go through torch.distributed.run
 
 
 @pytest.mark.gpu

@@ -65,18 +65,7 @@ def sample_negative_indices_device(query_ids: torch.Tensor, generator: Optional[
     if B < 2:
         raise IndexError("cannot draw an in-batch negative from a batch of one")  # reference: random.choice([])
     q = query_ids.reshape(-1, B)
-    if positive_nonempty is None:
-        key, n_ok = q, B
-    else:
-        ok = positive_nonempty.reshape(-1, B).to(torch.bool)
-        big = torch.iinfo(q.dtype).max
-        key = torch.where(ok, q, torch.full_like(q, big))  # empty positives sort behind every real query id
-        n_ok = ok.sum(1, keepdim=True)
-    sorted_k, perm = torch.sort(key, dim=1)
-    run_lo = torch.searchsorted(sorted_k, q, right=False)
-    run_hi = torch.searchsorted(sorted_k, q, right=True)
-    run = run_hi - run_lo
-    admissible = n_ok - run
+    perm, run_lo, run, admissible = _admissible_runs(q, positive_nonempty)
     if check and int(admissible.min()) <= 0:
         raise RuntimeError("an item of the batch has no admissible negative (every other item shares its query_id "
                            "or has an empty positive)")
@@ -84,6 +73,23 @@ def sample_negative_indices_device(query_ids: torch.Tensor, generator: Optional[
     pick = torch.minimum((u * admissible).long(), (admissible - 1).clamp_(min=0))
     pick = torch.where(pick < run_lo, pick, pick + run)
     return perm.gather(1, pick.clamp_(max=B - 1)).reshape(query_ids.shape)
+
+
+def _admissible_runs(q: torch.Tensor, positive_nonempty: Optional[torch.Tensor]):
+    """For batches q [n, B] of query ids: the sort permutation with empty-positive items moved to the end, and per item
+    the run [run_lo, run_lo + run) of sorted positions it must NOT draw (non-empty items of its own query) and the number
+    of admissible positions among the n_ok non-empty ones.  O(B log B) per batch, no [B, B] intermediate."""
+    B = q.shape[1]
+    if positive_nonempty is None:
+        key, n_ok = q, B
+    else:
+        ok = positive_nonempty.reshape(-1, B).to(torch.bool)
+        key = torch.where(ok, q, torch.full_like(q, torch.iinfo(q.dtype).max))  # empty positives sort behind every real id
+        n_ok = ok.sum(1, keepdim=True)
+    sorted_k, perm = torch.sort(key, dim=1)
+    run_lo = torch.searchsorted(sorted_k, q, right=False)
+    run = torch.searchsorted(sorted_k, q, right=True) - run_lo
+    return perm, run_lo, run, n_ok - run
 
 
 class PackedTokens:
@@ -354,14 +360,13 @@ class TokenTripletLoader:
                 bad = bad | (full.min(1).values == full.max(1).values).any()
             if r:
                 bad = bad | (tail.min() == tail.max())
-        else:  # some item must find a non-empty positive of another query: count them exactly
+        else:  # every item must find a non-empty positive of another query: count them exactly (sort-based, O(B log B))
             for qq, oo in ((full, ok_full), (tail.view(1, -1) if r else None, ok_tail.view(1, -1) if r else None)):
-                if qq is None:
-                    continue
-                same_ok = ((qq.unsqueeze(2) == qq.unsqueeze(1)) & oo.unsqueeze(1)).sum(2)  # O(B^2): only on this rare path
-                bad = bad | ((oo.sum(1, keepdim=True) - same_ok) <= 0).any()
+                if qq is not None:
+                    bad = bad | (_admissible_runs(qq, oo)[3] <= 0).any()
         if bool(bad):  # the reference would spin forever in create_triplets (backend/data.py:124-128)
-            raise RuntimeError("every item of a batch shares one query_id: no admissible negative")
+            raise RuntimeError("an item of some batch has no admissible negative (every other item shares its query_id"
+                               + ("" if okt is None else " or has an empty positive") + ")")
         neg_full = sample_negative_indices_device(full, self.gen, check=False, positive_nonempty=ok_full) if n_full else None
         neg_tail = sample_negative_indices_device(tail, self.gen, check=False, positive_nonempty=ok_tail) if r else None
         return neg_full, neg_tail

@@ -140,6 +140,38 @@ __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, 
 // v_mfma_f32_32x32x16_bf16 runs 16x the FLOP per cycle of the fp32 MFMA, so six of them cost 3/8 of the cycles.  Operands
 // stay fp32 in memory and in LDS (same staging, same images); the split happens on the fragments, in registers.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kPlaneRowBytes = 48;  // one row of a staged bf16 plane (PREC = 2, see TileCfg): 16 bf16 + 8 of padding
+
+// four consecutive-k values of one row -> their hi / mid / lo bf16 quadruples (8 bytes each)
+__device__ __forceinline__ void split_bf3_quad(const float4& v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 a = (__bf16)x[j];
+    const float r1 = x[j] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    hi[j] = a;
+    mid[j] = b;
+    lo[j] = (__bf16)r2;
+  }
+}
+// stage a K-contiguous [R][16] tile as three bf16 planes: plane p, row r, k-quad q at ((p * R + r) * 48 + 8 q) bytes
+template <int R>
+__device__ __forceinline__ void sstore_planes(const float4 (&v)[R * 16 / 4 / kThreads], float* __restrict__ T, int tid) {
+  char* __restrict__ base = reinterpret_cast<char*>(T);
+#pragma unroll
+  for (int i = 0; i < R * 16 / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
+    const int row = f >> 2, kq = f & 3;
+    bf16x4 hi, mid, lo;
+    split_bf3_quad(v[i], hi, mid, lo);
+    *reinterpret_cast<bf16x4*>(base + (0 * R + row) * kPlaneRowBytes + 8 * kq) = hi;
+    *reinterpret_cast<bf16x4*>(base + (1 * R + row) * kPlaneRowBytes + 8 * kq) = mid;
+    *reinterpret_cast<bf16x4*>(base + (2 * R + row) * kPlaneRowBytes + 8 * kq) = lo;
+  }
+}
 
 __device__ __forceinline__ void split_bf3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
 #pragma unroll
@@ -154,13 +186,17 @@ __device__ __forceinline__ void split_bf3(const float (&x)[8], bf16x8& hi, bf16x
   }
 }
 
-template <int LAYOUT, int WM, int WN, int BK = 32>
+// PREC = 2 (kNT, K-step 16 only): the split is done ONCE per workgroup when a tile is staged — three bf16 planes (hi, mid,
+// lo) per operand in LDS, rows of 16 bf16 + 8 of padding = 48 bytes (3 sixteen-byte slots per row, coprime with the 16
+// slots of a bank row) — so a fragment is three ds_read_b128 and no arithmetic.
+template <int LAYOUT, int WM, int WN, int BK = 32, int PREC = 0>
 struct TileCfg {
   static constexpr int BM = 64 * WM, BN = 64 * WN, BKP = BK + 4;
   static constexpr bool A_KC = (LAYOUT != kTN);
   static constexpr bool B_KC = (LAYOUT == kNT);
-  static constexpr int A_TILE = A_KC ? BM * BKP : BK * BM;
-  static constexpr int B_TILE = B_KC ? BN * BKP : BK * BN;
+  static_assert(PREC != 2 || (LAYOUT == kNT && BK == 16), "staged bf16 planes: K-contiguous operands, K-step 16");
+  static constexpr int A_TILE = PREC == 2 ? BM * 3 * kPlaneRowBytes / 4 : (A_KC ? BM * BKP : BK * BM);
+  static constexpr int B_TILE = PREC == 2 ? BN * 3 * kPlaneRowBytes / 4 : (B_KC ? BN * BKP : BK * BN);
   static constexpr int CP = BN + 4;  // padded row of the epilogue's C tile
   // the C tile leaves through LDS in EP passes of BM / EP rows (one pass per wave row), so that it needs no more
   // LDS than the operand buffers do when those are small (BK = 16)
@@ -172,7 +208,7 @@ struct TileCfg {
 // One workgroup's tile: (bx, by) tile coordinates, bz = group * nsplit + split.
 template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32, int PREC = 0>
 __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ lds, int bx, int by, int bz) {
-  using Cfg = TileCfg<LAYOUT, WM, WN, BK>;
+  using Cfg = TileCfg<LAYOUT, WM, WN, BK, PREC>;
   constexpr int BM = 64 * WM, BN = 64 * WN;
   [[maybe_unused]] constexpr int BKP = Cfg::BKP;
   constexpr bool A_KC = (LAYOUT != kTN);
@@ -243,13 +279,48 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   auto sstore = [&](const float4 (&ra)[NVA], const float4 (&rb)[NVB], int buf) {
     float* As = lds + buf * (A_TILE + B_TILE);
     float* Bs = As + A_TILE;
-    if (A_KC) sstore_kc<BM, BK>(ra, As, tid); else sstore_ks<BM, BK>(ra, As, tid);
-    if (B_KC) sstore_kc<BN, BK>(rb, Bs, tid); else sstore_ks<BN, BK>(rb, Bs, tid);
+    if constexpr (PREC == 2) {
+      sstore_planes<BM>(ra, As, tid);
+      sstore_planes<BN>(rb, Bs, tid);
+    } else {
+      if (A_KC) sstore_kc<BM, BK>(ra, As, tid); else sstore_ks<BM, BK>(ra, As, tid);
+      if (B_KC) sstore_kc<BN, BK>(rb, Bs, tid); else sstore_ks<BN, BK>(rb, Bs, tid);
+    }
   };
   auto compute = [&](int buf) {
     const float* __restrict__ As = lds + buf * (A_TILE + B_TILE);
     const float* __restrict__ Bs = As + A_TILE;
-    if constexpr (PREC == 1) {
+    if constexpr (PREC == 2) {
+      // one 16-wide K chunk per step; lane (r, h) reads k = 8 h + 0..7 of its row from each plane: no arithmetic here
+      const char* __restrict__ Ab = reinterpret_cast<const char*>(As);
+      const char* __restrict__ Bb = reinterpret_cast<const char*>(Bs);
+      bf16x8 ah[WM], am[WM], al[WM], bh[WN], bm[WN], bl[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = (wrow * WM + i) * 32 + r;
+        ah[i] = *reinterpret_cast<const bf16x8*>(Ab + (0 * BM + row) * kPlaneRowBytes + 16 * h);
+        am[i] = *reinterpret_cast<const bf16x8*>(Ab + (1 * BM + row) * kPlaneRowBytes + 16 * h);
+        al[i] = *reinterpret_cast<const bf16x8*>(Ab + (2 * BM + row) * kPlaneRowBytes + 16 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < WN; ++i) {
+        const int col = (wcol * WN + i) * 32 + r;
+        bh[i] = *reinterpret_cast<const bf16x8*>(Bb + (0 * BN + col) * kPlaneRowBytes + 16 * h);
+        bm[i] = *reinterpret_cast<const bf16x8*>(Bb + (1 * BN + col) * kPlaneRowBytes + 16 * h);
+        bl[i] = *reinterpret_cast<const bf16x8*>(Bb + (2 * BN + col) * kPlaneRowBytes + 16 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < WN; ++jj) {  // smallest terms first
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[jj], acc[i][jj], 0, 0, 0);
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[jj], acc[i][jj], 0, 0, 0);
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[jj], acc[i][jj], 0, 0, 0);
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
+        }
+    } else if constexpr (PREC == 1) {
       // 16-wide K chunks; lane (r, h) holds k = 16 c + 8 h + 0..7 of its row / column
 #pragma unroll
       for (int c = 0; c < BK / 16; ++c) {
@@ -556,6 +627,15 @@ __global__ __launch_bounds__(kThreads) void gemm_bf3_kernel(const Batch b) {
   gemm_body<LAYOUT, EPI, WM, WN, true, BK, 1>(b, lds, bx, by, bz);
 }
 
+// Split-bf16 with the split at staging time (PREC = 2): kNT, 128x128 or 64x64 tiles, K-step 16.  TT_BF3=2.
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void gemm_bf3s_kernel(const Batch b) {
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<kNT, WM, WN, 16, 2>::LDS_FLOATS];
+  int bx, by, bz;
+  if (!tile_coords<kNT>(b, bx, by, bz)) return;
+  gemm_body<kNT, EPI, WM, WN, true, 16, 2>(b, lds, bx, by, bz);
+}
+
 // The BK = 16 tile shares a CU with the streaming gather's workgroup (gather_pool.hip): three waves per SIMD's worth
 // of registers (<= 168) leave room for two of these workgroups plus the gather's 4 waves of up to 176.
 #ifndef TT_BK16_WAVES
@@ -634,7 +714,16 @@ int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
     if (total > 0x7fffffffLL) b.xcd_order = 0;
     else grid = dim3((unsigned)total, 1, 1);
   }
-  static const bool bf3 = getenv("TT_BF3") && getenv("TT_BF3")[0] == '1';  // split-bf16 products: opt-in experiment
+  static const int bf3_mode = getenv("TT_BF3") ? atoi(getenv("TT_BF3")) : 0;  // split-bf16 products: opt-in experiment
+  const bool bf3 = bf3_mode >= 1;
+  if constexpr (LAYOUT == kNT) {
+    if (vec && bf3_mode == 2 && b.nsplit == 1 && ((wm == 1 && wn == 1) || (wm == 2 && wn == 2))) {  // split at staging time
+      if (wm == 1) hipLaunchKernelGGL((gemm_bf3s_kernel<EPI, 1, 1>), grid, block, 0, st, b);
+      else hipLaunchKernelGGL((gemm_bf3s_kernel<EPI, 2, 2>), grid, block, 0, st, b);
+      TT_CHECK_LAUNCH();
+      return TT_OK;
+    }
+  }
   if (vec && bf3) {  // every vector-path tile has its split-bf16 twin: one arithmetic for the whole run
     if (wm == 1) hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 1, 1, 32>), grid, block, 0, st, b);
     else if (wn == 1) hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 2, 1, 32>), grid, block, 0, st, b);
@@ -660,7 +749,7 @@ int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStrea
   bool vec = true;
   for (int i = 0; i < bt.count; ++i) vec = vec && (bt.p[i].M == 0 || problem_vec_ok<kTN>(bt.p[i]));
   for (int i = 0; i < bn.count; ++i) vec = vec && (bn.p[i].M == 0 || problem_vec_ok<kNN>(bn.p[i]));
-  static const bool bf3 = getenv("TT_BF3") && getenv("TT_BF3")[0] == '1';  // the pair kernel has no split-bf16 twin
+  static const bool bf3 = getenv("TT_BF3") && getenv("TT_BF3")[0] >= '1';  // the pair kernel has no split-bf16 twin
   if (!vec || bf3 || !((wm == 1 && wn == 1) || (wm == 2 && wn == 1))) {  // odd shapes: two ordinary launches
     int rc = launch(kTN, kStore, bt, 1, 1, st);
     if (rc != TT_OK) return rc;

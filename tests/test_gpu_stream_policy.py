@@ -22,8 +22,10 @@ pytestmark = pytest.mark.gpu
     # cycles) — an opt-in experiment (TT_BF3=1), held to the SAME 1e-5 / 1e-6 bounds as the fp32 kernels
     {"TT_BF3": "1"},
     {"TT_BF3": "1", "TT_TILE": "22", "TT_BK": "16", "TT_TN_TILE": "22"},
-    {"TT_BF3": "2"},                      # the same products with the split done once per workgroup at staging time (kNT)
-    {"TT_BF3": "2", "TT_TILE": "22"},
+    {"TT_BF3": "2"},                      # the same products with the split done once per workgroup at staging time
+    {"TT_BF3": "2", "TT_TILE": "22", "TT_TN_TILE": "22"},
+    {"TT_BF3": "2", "TT_TILE": "21"},
+    {"TT_BF3": "3"},                      # A/B mode: staged split for kNT only, fragment split for kNN / kTN
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_parity_suite_under_the_stream_policy_kernels(env):
     e = dict(os.environ)

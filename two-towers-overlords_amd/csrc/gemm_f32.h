@@ -62,7 +62,10 @@ struct Batch {
   int gx, gy, gz;         // tile grid (filled by the launcher when xcd_order is set)
 };
 
-// Static LDS of one workgroup of the (layout, wm, wn) kernel, in bytes.
+// TT_BF3 (read once): 0 exact-fp32 MFMA (default); 1..3 the split-bf16 experiment (gemm_f32.hip).
+int bf3_mode();
+
+// Static LDS of one workgroup of the (layout, wm, wn) kernel the launcher would pick, in bytes.
 size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk = 32);
 
 // Launches one grouped GEMM.  wm/wn pick the block tile: (64*wm) x (64*wn).

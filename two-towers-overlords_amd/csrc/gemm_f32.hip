@@ -141,7 +141,14 @@ __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, 
 // stay fp32 in memory and in LDS (same staging, same images); the split happens on the fragments, in registers.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int kPlaneRowBytes = 48;  // one row of a staged bf16 plane (PREC = 2, see TileCfg): 16 bf16 + 8 of padding
+// Staged bf16 planes (PREC = 2, see TileCfg): a plane holds [R rows or columns][16 k] bf16 = 32 bytes per row, no padding.
+//  * K-contiguous operand (written 16 rows x 32 bytes per wave store): row r at 32 r, its two 16-byte halves (k 0..7 /
+//    k 8..15) swapped when (r >> 3) & 1 — so the 16 lanes of a ds_read_b128 group (rows r0..r0+15, same half) hit 16
+//    distinct 16-byte slots of the 256-byte bank row;
+//  * K-strided operand (written one k-quad of 64 consecutive columns per wave store): quad-major, [4 quads][R][8 bytes],
+//    so both the 8-byte stores and the two 8-byte reads of a fragment (quads 2h, 2h + 1) are contiguous across lanes.
+constexpr int kPlaneRowBytes = 32;
+__device__ __forceinline__ int plane_kc_half(int row, int half) { return (half ^ ((row >> 3) & 1)) << 4; }
 
 // four consecutive-k values of one row -> their hi / mid / lo bf16 quadruples (8 bytes each)
 __device__ __forceinline__ void split_bf3_quad(const float4& v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
@@ -157,19 +164,61 @@ __device__ __forceinline__ void split_bf3_quad(const float4& v, bf16x4& hi, bf16
     lo[j] = (__bf16)r2;
   }
 }
-// stage a K-contiguous [R][16] tile as three bf16 planes: plane p, row r, k-quad q at ((p * R + r) * 48 + 8 q) bytes
-template <int R>
+// stage an [R][16] tile as three bf16 planes.  KC: the registers came from gload_kc (chunk f = row * 4 + q); otherwise
+// from gload_kt (chunk f = q * R + row).
+template <int R, bool KC>
 __device__ __forceinline__ void sstore_planes(const float4 (&v)[R * 16 / 4 / kThreads], float* __restrict__ T, int tid) {
   char* __restrict__ base = reinterpret_cast<char*>(T);
 #pragma unroll
   for (int i = 0; i < R * 16 / 4 / kThreads; ++i) {
     const int f = tid + i * kThreads;
-    const int row = f >> 2, kq = f & 3;
+    const int row = KC ? f >> 2 : f % R, kq = KC ? f & 3 : f / R;
     bf16x4 hi, mid, lo;
     split_bf3_quad(v[i], hi, mid, lo);
-    *reinterpret_cast<bf16x4*>(base + (0 * R + row) * kPlaneRowBytes + 8 * kq) = hi;
-    *reinterpret_cast<bf16x4*>(base + (1 * R + row) * kPlaneRowBytes + 8 * kq) = mid;
-    *reinterpret_cast<bf16x4*>(base + (2 * R + row) * kPlaneRowBytes + 8 * kq) = lo;
+    const int at = KC ? row * kPlaneRowBytes + plane_kc_half(row, kq >> 1) + 8 * (kq & 1) : (kq * R + row) * 8;
+    *reinterpret_cast<bf16x4*>(base + 0 * R * kPlaneRowBytes + at) = hi;
+    *reinterpret_cast<bf16x4*>(base + 1 * R * kPlaneRowBytes + at) = mid;
+    *reinterpret_cast<bf16x4*>(base + 2 * R * kPlaneRowBytes + at) = lo;
+  }
+}
+// one lane's fragment (its row, k = 8 h + 0..7) of plane p
+template <int R, bool KC>
+__device__ __forceinline__ bf16x8 frag_plane(const char* __restrict__ base, int p, int row, int h) {
+  if constexpr (KC) {
+    return *reinterpret_cast<const bf16x8*>(base + (p * R + row) * kPlaneRowBytes + plane_kc_half(row, h));
+  } else {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(base + p * R * kPlaneRowBytes + ((2 * h) * R + row) * 8);
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(base + p * R * kPlaneRowBytes + ((2 * h + 1) * R + row) * 8);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+// K-strided operand for the staged planes: tile [16][R cols], element (k, col) at P[(k0+k)*ld + r0+col].  A thread takes
+// FOUR CONSECUTIVE k of ONE column (dword loads, coalesced across lanes = consecutive columns), i.e. the transposition
+// happens in the register file and the planes are written exactly as for a K-contiguous operand.  A thread's column is
+// tid % R in every chunk (kThreads % R == 0), which the kTN column sums rely on.
+template <int R, bool FULL>
+__device__ __forceinline__ void gload_kt(float4 (&v)[R * 16 / 4 / kThreads], const float* __restrict__ P,
+                                         int ld, int r0, int rmax, int k0, int kend, int tid) {
+  static_assert(kThreads % R == 0, "one column per thread");
+#pragma unroll
+  for (int i = 0; i < R * 16 / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
+    const int col = f % R, kq = f / R;
+    const int gr = r0 + col, gk = k0 + 4 * kq;
+    if (FULL) {
+      const float* __restrict__ src = P + (long long)gk * ld + gr;
+      v[i] = make_float4(src[0], src[ld], src[2 * (long long)ld], src[3 * (long long)ld]);
+    } else {
+      float x[4];
+      const int cr = min(gr, rmax - 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = gr < rmax && gk + j < kend;
+        const float t = P[(long long)min(gk + j, kend - 1) * ld + cr];
+        x[j] = ok ? t : 0.f;
+      }
+      v[i] = make_float4(x[0], x[1], x[2], x[3]);
+    }
   }
 }
 
@@ -186,15 +235,16 @@ __device__ __forceinline__ void split_bf3(const float (&x)[8], bf16x8& hi, bf16x
   }
 }
 
-// PREC = 2 (kNT, K-step 16 only): the split is done ONCE per workgroup when a tile is staged — three bf16 planes (hi, mid,
-// lo) per operand in LDS, rows of 16 bf16 + 8 of padding = 48 bytes (3 sixteen-byte slots per row, coprime with the 16
-// slots of a bank row) — so a fragment is three ds_read_b128 and no arithmetic.
+// PREC = 2 (K-step 16 only): the split is done ONCE per workgroup when a tile is staged — three bf16 planes (hi, mid,
+// lo) per operand in LDS, 32 bytes per row and plane (layouts above: 48 KB for a 128x128 tile's two buffers, 24 KB for
+// 64x64) — so a fragment is three 16-byte LDS reads and no arithmetic, whatever the operand's layout in memory
+// (K-strided operands are transposed on their way in, gload_kt).
 template <int LAYOUT, int WM, int WN, int BK = 32, int PREC = 0>
 struct TileCfg {
   static constexpr int BM = 64 * WM, BN = 64 * WN, BKP = BK + 4;
   static constexpr bool A_KC = (LAYOUT != kTN);
   static constexpr bool B_KC = (LAYOUT == kNT);
-  static_assert(PREC != 2 || (LAYOUT == kNT && BK == 16), "staged bf16 planes: K-contiguous operands, K-step 16");
+  static_assert(PREC != 2 || BK == 16, "staged bf16 planes: K-step 16");
   static constexpr int A_TILE = PREC == 2 ? BM * 3 * kPlaneRowBytes / 4 : (A_KC ? BM * BKP : BK * BM);
   static constexpr int B_TILE = PREC == 2 ? BN * 3 * kPlaneRowBytes / 4 : (B_KC ? BN * BKP : BK * BN);
   static constexpr int CP = BN + 4;  // padded row of the epilogue's C tile
@@ -271,17 +321,23 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   const bool full = VEC && (m0 + BM <= M) && (n0 + BN <= N) && ((kend - kbeg) % BK == 0);
   auto gload = [&](float4 (&ra)[NVA], float4 (&rb)[NVB], int k0, auto full_tag) {
     constexpr bool F = decltype(full_tag)::value;
-    if (A_KC) gload_kc<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
-    else      gload_ks<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
-    if (B_KC) gload_kc<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
-    else      gload_ks<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    if constexpr (A_KC) gload_kc<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+    else if constexpr (PREC == 2) gload_kt<BM, F>(ra, gA, lda, m0, M, k0, kend, tid);
+    else gload_ks<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+    if constexpr (B_KC) gload_kc<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    else if constexpr (PREC == 2) gload_kt<BN, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    else gload_ks<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
   };
   auto sstore = [&](const float4 (&ra)[NVA], const float4 (&rb)[NVB], int buf) {
     float* As = lds + buf * (A_TILE + B_TILE);
     float* Bs = As + A_TILE;
     if constexpr (PREC == 2) {
-      sstore_planes<BM>(ra, As, tid);
-      sstore_planes<BN>(rb, Bs, tid);
+      sstore_planes<BM, A_KC>(ra, As, tid);
+      sstore_planes<BN, B_KC>(rb, Bs, tid);
+      if (do_colsum) {  // kTN: this thread's A chunks are all of column tid % BM (gload_kt)
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) csum += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+      }
     } else {
       if (A_KC) sstore_kc<BM, BK>(ra, As, tid); else sstore_ks<BM, BK>(ra, As, tid);
       if (B_KC) sstore_kc<BN, BK>(rb, Bs, tid); else sstore_ks<BN, BK>(rb, Bs, tid);
@@ -298,16 +354,16 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const int row = (wrow * WM + i) * 32 + r;
-        ah[i] = *reinterpret_cast<const bf16x8*>(Ab + (0 * BM + row) * kPlaneRowBytes + 16 * h);
-        am[i] = *reinterpret_cast<const bf16x8*>(Ab + (1 * BM + row) * kPlaneRowBytes + 16 * h);
-        al[i] = *reinterpret_cast<const bf16x8*>(Ab + (2 * BM + row) * kPlaneRowBytes + 16 * h);
+        ah[i] = frag_plane<BM, A_KC>(Ab, 0, row, h);
+        am[i] = frag_plane<BM, A_KC>(Ab, 1, row, h);
+        al[i] = frag_plane<BM, A_KC>(Ab, 2, row, h);
       }
 #pragma unroll
       for (int i = 0; i < WN; ++i) {
         const int col = (wcol * WN + i) * 32 + r;
-        bh[i] = *reinterpret_cast<const bf16x8*>(Bb + (0 * BN + col) * kPlaneRowBytes + 16 * h);
-        bm[i] = *reinterpret_cast<const bf16x8*>(Bb + (1 * BN + col) * kPlaneRowBytes + 16 * h);
-        bl[i] = *reinterpret_cast<const bf16x8*>(Bb + (2 * BN + col) * kPlaneRowBytes + 16 * h);
+        bh[i] = frag_plane<BN, B_KC>(Bb, 0, col, h);
+        bm[i] = frag_plane<BN, B_KC>(Bb, 1, col, h);
+        bl[i] = frag_plane<BN, B_KC>(Bb, 2, col, h);
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
@@ -391,9 +447,11 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
         }
     }
     }
-    if (do_colsum && tid < BM) {
+    if constexpr (PREC != 2) {
+      if (do_colsum && tid < BM) {
 #pragma unroll
-      for (int k = 0; k < BK; ++k) csum += As[k * BM + tid];
+        for (int k = 0; k < BK; ++k) csum += As[k * BM + tid];
+      }
     }
   };
 
@@ -439,6 +497,18 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   };
   if (VEC && full) kloop(std::true_type{});
   else kloop(std::false_type{});
+  if constexpr (PREC == 2 && LAYOUT == kTN) {
+    if (do_colsum) {  // kThreads / BM threads hold partial sums of each column: add them in thread order (LDS is free here)
+      lds[tid] = csum;
+      __syncthreads();
+      if (tid < BM) {
+        csum = lds[tid];
+#pragma unroll
+        for (int t = 1; t < kThreads / BM; ++t) csum += lds[tid + t * BM];
+      }
+      __syncthreads();
+    }
+  }
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*h.
   // The tile goes through LDS (free after the K loop's last barrier) so that global
@@ -627,13 +697,16 @@ __global__ __launch_bounds__(kThreads) void gemm_bf3_kernel(const Batch b) {
   gemm_body<LAYOUT, EPI, WM, WN, true, BK, 1>(b, lds, bx, by, bz);
 }
 
-// Split-bf16 with the split at staging time (PREC = 2): kNT, 128x128 or 64x64 tiles, K-step 16.  TT_BF3=2.
-template <int EPI, int WM, int WN>
-__global__ __launch_bounds__(kThreads) void gemm_bf3s_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[TileCfg<kNT, WM, WN, 16, 2>::LDS_FLOATS];
+// Split-bf16 with the split at staging time (PREC = 2), K-step 16.  TT_BF3=2.
+// (128x128: at most 168 registers, like the K-step-16 fp32 tile, so that two of them and the streaming gather's waves
+// stay resident together)
+template <int LAYOUT, int EPI, int WM, int WN>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WM * WN == 4 ? 3 : 1, 8)))
+void gemm_bf3s_kernel(const Batch b) {
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, 16, 2>::LDS_FLOATS];
   int bx, by, bz;
-  if (!tile_coords<kNT>(b, bx, by, bz)) return;
-  gemm_body<kNT, EPI, WM, WN, true, 16, 2>(b, lds, bx, by, bz);
+  if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
+  gemm_body<LAYOUT, EPI, WM, WN, true, 16, 2>(b, lds, bx, by, bz);
 }
 
 // The BK = 16 tile shares a CU with the streaming gather's workgroup (gather_pool.hip): three waves per SIMD's worth
@@ -714,15 +787,15 @@ int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
     if (total > 0x7fffffffLL) b.xcd_order = 0;
     else grid = dim3((unsigned)total, 1, 1);
   }
-  static const int bf3_mode = getenv("TT_BF3") ? atoi(getenv("TT_BF3")) : 0;  // split-bf16 products: opt-in experiment
-  const bool bf3 = bf3_mode >= 1;
-  if constexpr (LAYOUT == kNT) {
-    if (vec && bf3_mode == 2 && b.nsplit == 1 && ((wm == 1 && wn == 1) || (wm == 2 && wn == 2))) {  // split at staging time
-      if (wm == 1) hipLaunchKernelGGL((gemm_bf3s_kernel<EPI, 1, 1>), grid, block, 0, st, b);
-      else hipLaunchKernelGGL((gemm_bf3s_kernel<EPI, 2, 2>), grid, block, 0, st, b);
-      TT_CHECK_LAUNCH();
-      return TT_OK;
-    }
+  const int mode = ttg::bf3_mode();  // split-bf16 products: opt-in experiment
+  const bool bf3 = mode >= 1;
+  // mode 2: split at staging time; mode 3 (A/B): that for kNT only, kNN / kTN split on the fragments as in mode 1
+  if (vec && (mode == 2 || (mode == 3 && LAYOUT == kNT))) {
+    if (wm == 1) hipLaunchKernelGGL((gemm_bf3s_kernel<LAYOUT, EPI, 1, 1>), grid, block, 0, st, b);
+    else if (wn == 1) hipLaunchKernelGGL((gemm_bf3s_kernel<LAYOUT, EPI, 2, 1>), grid, block, 0, st, b);
+    else hipLaunchKernelGGL((gemm_bf3s_kernel<LAYOUT, EPI, 2, 2>), grid, block, 0, st, b);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
   }
   if (vec && bf3) {  // every vector-path tile has its split-bf16 twin: one arithmetic for the whole run
     if (wm == 1) hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 1, 1, 32>), grid, block, 0, st, b);
@@ -790,7 +863,24 @@ static size_t lds_of(Layout layout) {
   return (size_t)f * sizeof(float);
 }
 
+int bf3_mode() {
+  static const int mode = getenv("TT_BF3") ? atoi(getenv("TT_BF3")) : 0;
+  return mode;
+}
+
+template <int WM, int WN>
+static size_t lds_of_staged(Layout layout) {
+  const int f = layout == kNT ? TileCfg<kNT, WM, WN, 16, 2>::LDS_FLOATS
+                              : layout == kNN ? TileCfg<kNN, WM, WN, 16, 2>::LDS_FLOATS : TileCfg<kTN, WM, WN, 16, 2>::LDS_FLOATS;
+  return (size_t)f * sizeof(float);
+}
+
 size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk) {
+  if (bf3_mode() == 2 || (bf3_mode() == 3 && layout == kNT)) {  // the staged split-bf16 tiles (vector path)
+    if (wm == 2 && wn == 2) return lds_of_staged<2, 2>(layout);
+    if (wm == 2 && wn == 1) return lds_of_staged<2, 1>(layout);
+    return lds_of_staged<1, 1>(layout);
+  }
   if (wm == 2 && wn == 2 && bk == 16)
     return (size_t)(layout == kNT ? TileCfg<kNT, 2, 2, 16>::LDS_FLOATS
                                   : layout == kNN ? TileCfg<kNN, 2, 2, 16>::LDS_FLOATS : TileCfg<kTN, 2, 2, 16>::LDS_FLOATS) * sizeof(float);

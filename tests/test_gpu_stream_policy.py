@@ -25,7 +25,8 @@ pytestmark = pytest.mark.gpu
     {"TT_BF3": "2"},                      # the same products with the split done once per workgroup at staging time
     {"TT_BF3": "2", "TT_TILE": "22", "TT_TN_TILE": "22"},
     {"TT_BF3": "2", "TT_TILE": "21"},
-    {"TT_BF3": "3"},                      # A/B mode: staged split for kNT only, fragment split for kNN / kTN
+    {"TT_BF3": "3"},
+    {"TT_INBATCH_TILE": "2"},             # 128x128 tiles (two epilogue passes) for the in-batch similarity product                      # A/B mode: staged split for kNT only, fragment split for kNN / kTN
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_parity_suite_under_the_stream_policy_kernels(env):
     e = dict(os.environ)

@@ -8,7 +8,7 @@ pick='import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); 
 B="python3 bench.py --no-cpu-baseline --no-secondary --loss inbatch --batch 4096"
 rm -f $out/ab.txt
 for rep in 1 2; do
-echo "default (128x128 S tiles): $($B | python3 -c "$pick")" >> $out/ab.txt
+echo "default (128x128 S tiles): $(TT_INBATCH_TILE=2 $B | python3 -c "$pick")" >> $out/ab.txt
 echo "TT_INBATCH_TILE=1 (64x64 S tiles): $(TT_INBATCH_TILE=1 $B | python3 -c "$pick")" >> $out/ab.txt
 echo "no-overlap: $($B --no-overlap | python3 -c "$pick")" >> $out/ab.txt
 echo "k1 cap 2: $($B --k1-blocks-per-cu 2 | python3 -c "$pick")" >> $out/ab.txt

@@ -533,8 +533,12 @@ def run_config(args, world, rank, device) -> dict:
     sliced = bool(_ttlib.load().tt_k1_prefers_sliced(V, D, roles * B, S))
     streaming = (trainer.side is not None and trainer.engine_k1_cap < 0
                  and bool(_ttlib.load().tt_k1_prefers_stream(V, D, roles * B, S)))
-    k1_label = ("pool_sliced_kernel + pool_combine_kernel (K1, XCD-sliced form: gather + masked mean-pool + L2 normalise; "
-                "both launches lie inside the timed events)" if sliced
+    columns = sliced and bool(_ttlib.load().tt_k1_sliced_form(V, D, S))
+    k1_label = ("pool_colsliced_kernel + pool_colnorm_kernel (K1, XCD-sliced form, 32-column slices — one 128-byte line per "
+                "row, a slice fits the XCD's L2: gather + masked mean-pool, then the L2 norm; both launches lie inside the "
+                "timed events)" if columns
+                else "pool_sliced_kernel + pool_combine_kernel (K1, XCD-sliced form, row slices: gather + masked mean-pool + "
+                     "L2 normalise; both launches lie inside the timed events)" if sliced
                 else "pool_norm_stream_kernel (K1, streaming form: persistent workgroups, two per compute unit, pulling texts "
                      "from a queue; gather + masked mean-pool + L2 normalise)" if streaming
                 else "pool_norm_kernel (K1 gather + masked mean-pool + L2 normalise)")

@@ -87,13 +87,20 @@ int tt_gather_pool_norm_f32(const float* table, const void* ids, int ids_dtype,
 
 /*
  * XCD-sliced form of tt_gather_pool_norm_f32 (same arguments, same result to fp32 summation order):
- * workgroups that share an XCD gather only token ids of one residue class mod 8, so each XCD's L2
- * serves one eighth of the table; per-slice partial sums meet in `workspace`
- * (tt_gather_pool_sliced_workspace_bytes(N, D) bytes, 16-byte aligned) and a second launch adds them
- * in slice order, divides and normalises.  Requires D % 4 == 0, D <= 1024, S <= 512.  Faster than
- * the per-text form when the table is far larger than one L2 (4 MiB) — BERT-sized vocabularies.
+ * the workgroups that share an XCD read one SLICE of the table, so that slice is served by the XCD's own
+ * L2.  Two ways of slicing, picked per shape (tt_k1_sliced_form):
+ *   0  rows: token ids of one residue class mod 8 (an eighth of the rows); per-slice partial sums meet in
+ *      `workspace` and a second launch adds them in slice order, divides and normalises;
+ *   1  columns: 32 columns of every row (one 128-byte line per row: V x 128 bytes per slice), where
+ *      D % 32 == 0 and such a slice fits the 4 MiB L2 — the partial of a (text, slice) is that slice of
+ *      the output itself; the second launch only applies the L2 norm.
+ * `workspace`: tt_gather_pool_sliced_workspace_bytes(N, D) bytes, 16-byte aligned.  Requires D % 4 == 0,
+ * D <= 1024, S <= 512.  Faster than the per-text form when the table is far larger than one L2 (4 MiB) —
+ * BERT-sized vocabularies.
  */
 size_t tt_gather_pool_sliced_workspace_bytes(int64_t N, int D);
+/* which slicing tt_gather_pool_norm_sliced_f32 uses for this shape: 0 rows (ids mod 8), 1 columns */
+int tt_k1_sliced_form(int64_t V, int D, int S);
 /* 1 if the sliced form is the faster one for this shape on MI355X (host-side rule from measurements;
  * tt_engine_pool applies it by itself). */
 int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S);

@@ -86,6 +86,22 @@ def test_k1_form_selection_and_workspace_rules(monkeypatch):
     assert pref(2000, 384, 64, 128) == 1 and pref(30522, 386, 6144, 128) == 0
     monkeypatch.delenv("TT_K1_SLICED")
 
+    # which slicing the sliced entry point uses: 32-column slices where D % 32 == 0 and a slice (V x 128 bytes) is at
+    # most 13 MB (measured up to V = 100000)
+    monkeypatch.delenv("TT_K1_COLS", raising=False)
+    form = lib.tt_k1_sliced_form
+    assert form(30522, 384, 128) == 1 and form(30522, 768, 256) == 1   # 3.9 MB per slice
+    assert form(101562, 384, 128) == 1 and form(101563, 384, 128) == 0  # the 13e6-byte boundary
+    assert pref(100000, 384, 6144, 128) == 1 and pref(100000, 388, 6144, 128) == 0  # 154 MB table: only with column slices
+    assert form(250000, 768, 256) == 0                                  # 32 MB per column slice: row slices
+    assert form(30522, 100, 128) == 0 and form(30522, 1056, 128) == 0   # partial slice / more than 32 slices
+    assert form(30522, 384, 1024) == 0                                  # S beyond the sliced kernels
+    monkeypatch.setenv("TT_K1_COLS", "0")
+    assert form(30522, 384, 128) == 0
+    monkeypatch.setenv("TT_K1_COLS", "1")
+    assert form(250000, 768, 256) == 1 and form(30522, 100, 128) == 0   # forced on wherever the shape allows it
+    monkeypatch.delenv("TT_K1_COLS")
+
     ws = lib.tt_gather_pool_sliced_workspace_bytes
     assert ws(6144, 384) == (6144 * 8 * 384 + 6144) * 4 and ws(0, 384) == 0
     # null workspace / short workspace / unsupported S are refused before any launch

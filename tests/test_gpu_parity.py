@@ -114,10 +114,13 @@ def test_pool_vs_oracle_shapes(tt, D, S, V, N):
 
 @pytest.mark.parametrize("D,S,V,N", [(384, 128, 30522, 301), (768, 256, 5000, 67), (64, 7, 100, 5), (1024, 33, 777, 9),
                                      (384, 512, 30522, 13), (8, 300, 40, 3), (128, 64, 5, 6), (384, 128, 30522, 5000)])
-def test_pool_sliced_vs_oracle_shapes(tt, D, S, V, N):
-    """XCD-sliced K1 (tt_gather_pool_norm_sliced_f32): same contract as the per-text form — masks with holes,
-    prefix lengths (incl. 0), both index widths, all-ones, vocabularies smaller than the slice count."""
+@pytest.mark.parametrize("cols", ["0", "1"], ids=["row-slices", "column-slices"])
+def test_pool_sliced_vs_oracle_shapes(tt, D, S, V, N, cols, monkeypatch):
+    """XCD-sliced K1 (tt_gather_pool_norm_sliced_f32), both of its forms (slices of rows: ids % 8; slices of 32 columns,
+    wherever D % 32 == 0): same contract as the per-text form — masks with holes, prefix lengths (incl. 0), both index
+    widths, all-ones, vocabularies smaller than the slice count."""
     ops, _ = tt
+    monkeypatch.setenv("TT_K1_COLS", cols)
     gen = torch.Generator().manual_seed(D + S + 1)
     table = torch.randn(V, D, generator=gen)
     ids = torch.randint(0, V, (N, S), generator=gen)
@@ -138,8 +141,10 @@ def test_pool_sliced_vs_oracle_shapes(tt, D, S, V, N):
           ops.gather_pool_norm(table.cuda(), ids.cuda(), holey.cuda()), atol=1e-6)
 
 
-def test_pool_sliced_golden_and_flags(tt):
+@pytest.mark.parametrize("cols", ["0", "1"], ids=["row-slices", "column-slices"])
+def test_pool_sliced_golden_and_flags(tt, cols, monkeypatch):
     ops, _ = tt
+    monkeypatch.setenv("TT_K1_COLS", cols)
     g = load_golden("pool_edges.npz")
     table, ids, mask = dev(g["table"]), dev(g["ids"]), dev(g["mask"])
     out = ops.gather_pool_norm(table, ids, mask, check_ids=True, sliced=True)

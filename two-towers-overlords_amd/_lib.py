@@ -54,6 +54,7 @@ SIGNATURES = {
     "tt_gather_pool_norm_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp]),
     "tt_gather_pool_sliced_workspace_bytes": (_sz, [_i64, _i]),
     "tt_k1_prefers_sliced": (_i, [_i64, _i, _i64, _i]),
+    "tt_k1_sliced_form": (_i, [_i64, _i, _i]),
     "tt_gather_pool_norm_sliced_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "tt_gather_pool_stream_workspace_bytes": (_sz, []),
     "tt_k1_stream_supported": (_i, [_i, _vp, _vp]),

@@ -264,6 +264,8 @@ static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, con
   if (e->shared)
     lds_total = e->tile_above ? (unsigned)ttp::chain_lds_bytes(3 * (long long)e->cfg.max_B, e->cfg.P, ttp::kTileSmall) + 3072u
                               : tt_k1_lds_for_cap(e->cap);
+  static const int share_lds_kb = getenv("TT_K1_SHARE_LDS_KB") ? atoi(getenv("TT_K1_SHARE_LDS_KB")) : -1;  // A/B
+  if (e->shared && share_lds_kb >= 0 && share_lds_kb <= 160) lds_total = (unsigned)share_lds_kb * 1024u;
   // streaming form beside the projection chain when the table really comes from HBM (gather_pool.hip)
   if (e->k1_stream && e->shared && e->cfg.k1_blocks_per_cu == TT_K1_SHARE_AUTO &&
       tt_k1_prefers_stream(e->cfg.V, e->cfg.D, roles * (int64_t)B, S) &&

@@ -492,6 +492,131 @@ __global__ __launch_bounds__(kThreads) void pool_combine_kernel(const float* __r
     if (c < C - 1 || last_ok) op[c * TT_WAVE + lane] = make_float4(m[c].x / dn, m[c].y / dn, m[c].z / dn, m[c].w / dn);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Column-sliced K1 (round 3).  The row-sliced form above still misses its XCD's L2 on ~40 % of the rows at
+// V = 30522 (a 5.9 MB slice in a 4 MiB L2) and pays for N x 8 x D floats of partial sums.  Here a slice is 32
+// COLUMNS of every row — one 128-byte line per row, V x 128 bytes per slice: 3.9 MB at V = 30522 — so a slice
+// fits the L2 whole and the partial of a (text, slice) unit is that slice of the output itself (no partial sums
+// at all; only one float per unit, the slice's sum of squares, for the L2 norm).
+//
+// Units u = slice * N + text, slice-major.  Workgroups with equal blockIdx % 8 share an XCD (placement label:
+// speed only), and class x takes the units [x * UPX, (x + 1) * UPX), UPX = ceil(NS * N / 8), in order: an XCD
+// works through at most two slices (NS = 12 at D = 384: one and a half), one after the other.  One wave per
+// unit: lane = (row slot r = lane >> 3, 16-byte piece q = lane & 7), so one wave instruction reads the
+// 128-byte pieces of 8 rows; 16 instructions (128 tokens) are in flight before the first use.  Token ids and
+// weights are loaded coalesced (non-temporal: they must not displace the slice) and handed to the row slots by
+// ds_bpermute.  Masked-out tokens are never fetched.  The 8 row slots meet in a 3-step butterfly, then mean
+// (clamp 1e-9), the slice's sum of squares, and lanes 0..7 store the 128 bytes of un-normalised mean.  A second
+// launch adds a text's NS sums of squares in slice order and divides its row (clamp 1e-12) in place.
+// Same result as the other forms up to fp32 summation order; run-to-run bitwise reproducible.
+constexpr int kColSliceFloats = 32;
+
+// (66 registers: seven waves per SIMD.  Forced to 64 for eight — 12 bytes of scratch — it is slower alone, 91 vs 85 us,
+// and in the step, 183-187 vs 179 us: profiles/r03_k1_column_slices.txt.)
+template <typename IdT, typename MaskT, int MAXSEG, int WPB>
+__global__ __launch_bounds__(WPB * TT_WAVE) void pool_colsliced_kernel(
+    const float* __restrict__ table, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
+    const int* __restrict__ lens, float* __restrict__ out, float* __restrict__ ssq, long long N, int S, int D,
+    long long V, int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store, int NS,
+    long long units_per_class, int prio) {
+  if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  const int cls = (int)(blockIdx.x & 7);
+  const long long j = (long long)(blockIdx.x >> 3) * WPB + wave;  // this wave's unit within its class
+  const long long u = cls * units_per_class + j;
+  if (j >= units_per_class || u >= (long long)NS * N) return;  // wave-uniform; no workgroup barrier below
+  const int slice = (int)(u / N);
+  const long long text = u - (long long)slice * N;
+  const int rslot = lane >> 3, piece = lane & 7;
+
+  const long long st = text_rows ? store_row(text_rows[text], n_store, oob_flag) : text;
+  const int len = lens ? lens[st] : S;
+  const long long tb = st * (long long)S;
+  int idv[MAXSEG];
+  float wv[MAXSEG];
+  float wtot = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXSEG; ++k) {
+    const int tok = k * TT_WAVE + lane;
+    int id = 0;
+    float w = 0.f;
+    if (tok < S) {
+      w = mask ? static_cast<float>(__builtin_nontemporal_load(mask + tb + tok)) : (tok < len ? 1.f : 0.f);
+      const long long raw = static_cast<long long>(__builtin_nontemporal_load(ids + tb + tok));
+      if (raw < 0 || raw >= V) {
+        if (w != 0.f && oob_flag) atomicOr(oob_flag, 1);
+        id = raw < 0 ? 0 : static_cast<int>(V - 1);
+      } else {
+        id = static_cast<int>(raw);
+      }
+    }
+    idv[k] = id;
+    wv[k] = w;
+    wtot += w;
+  }
+  const float wsum = tt_wave_sum(wtot);
+
+  const float* __restrict__ col = table + slice * kColSliceFloats + piece * 4;
+  float4 acc = f4_zero();
+  // 64 tokens (8 wave loads = 8 KB) in flight before the first use.  (Two segments at once — 16 loads, 108 registers
+  // instead of 66 — measured slower alone, 96 vs 81 us at configs[1]: the waves a CU holds matter more.)
+  constexpr int PAIR = 1;
+#pragma unroll
+  for (int k0 = 0; k0 < MAXSEG; k0 += PAIR) {
+    bool live = false;
+#pragma unroll
+    for (int k = k0; k < k0 + PAIR; ++k) live = live || (__ballot(wv[k] != 0.f) != 0ULL);
+    if (!live) continue;  // 128 masked-out tokens: nothing to fetch (wave-uniform)
+    float4 r[PAIR * 8];
+    float wr[PAIR * 8];
+#pragma unroll
+    for (int i = 0; i < PAIR * 8; ++i) {  // tokens 64 k0 + 8 i + rslot
+      const int k = k0 + (i >> 3);
+      const int from = (i & 7) * 8 + rslot;
+      const int id = __shfl(idv[k], from, TT_WAVE);
+      wr[i] = __shfl(wv[k], from, TT_WAVE);
+      r[i] = f4_zero();
+      if (wr[i] != 0.f) r[i] = *reinterpret_cast<const float4*>(col + (long long)id * D);
+    }
+#pragma unroll
+    for (int i = 0; i < PAIR * 8; ++i) f4_fma(acc, wr[i], r[i]);
+  }
+  // the 8 row slots of a piece: lanes piece, piece + 8, ..., piece + 56
+#pragma unroll
+  for (int off = 8; off < TT_WAVE; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off, TT_WAVE);
+    acc.y += __shfl_xor(acc.y, off, TT_WAVE);
+    acc.z += __shfl_xor(acc.z, off, TT_WAVE);
+    acc.w += __shfl_xor(acc.w, off, TT_WAVE);
+  }
+  const float den = fmaxf(wsum, 1e-9f);  // clamp(mask.sum(1), min=1e-9)
+  const float4 m = make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den);
+  float ss = fmaf(m.x, m.x, fmaf(m.y, m.y, fmaf(m.z, m.z, m.w * m.w)));
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) ss += __shfl_xor(ss, off, TT_WAVE);
+  if (rslot == 0) *reinterpret_cast<float4*>(out + text * (long long)D + slice * kColSliceFloats + piece * 4) = m;
+  if (lane == 0) ssq[text * NS + slice] = ss;
+}
+
+// One wave per text: the NS sums of squares in slice order, then the row divided by max(norm, 1e-12) in place.
+__global__ __launch_bounds__(kThreads) void pool_colnorm_kernel(float* __restrict__ out, const float* __restrict__ ssq,
+                                                                long long N, int D, int NS) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const long long text = (long long)blockIdx.x * kWavesPerText + (threadIdx.x >> 6);
+  if (text >= N) return;
+  const float mine = lane < NS ? ssq[text * NS + lane] : 0.f;  // NS <= 32
+  float total = 0.f;
+  for (int s = 0; s < NS; ++s) total += __shfl(mine, s, TT_WAVE);
+  const float dn = fmaxf(sqrtf(total), 1e-12f);  // F.normalize eps
+  float4* __restrict__ row = reinterpret_cast<float4*>(out + text * (long long)D);
+  for (int c = lane; c < (D >> 2); c += TT_WAVE) {
+    const float4 m = row[c];
+    row[c] = make_float4(m.x / dn, m.y / dn, m.z / dn, m.w / dn);
+  }
+}
+
 // Any D (not a multiple of 4, or > 1024, or unaligned): correct, not fast.
 template <typename IdT, typename MaskT, bool DENSE>
 __global__ __launch_bounds__(kThreads) void pool_norm_generic_kernel(
@@ -647,12 +772,59 @@ static int cu_count() {
   return n;
 }
 
+// The column-sliced form needs whole 32-column slices.  Measured against the row slices (tools/k1_sliced_ab.py, D = 384,
+// 6144 texts x 128 tokens, alone; profiles/r03_k1_column_slices.txt): V = 30522 (3.9 MB per slice: L2-resident, 86 % of
+// the row reads hit) 81-84 vs 97 us; 50000: 94 vs 127; 65000: 109 vs 139; 100000 (12.8 MB per slice) 136 vs 159 — no
+// partial sums and no compaction, so it stays ahead when a slice no longer fits the L2.  D = 768, V = 30522: 158 vs 270.
+// Tables that stream from HBM (several times the Infinity Cache) keep whole-row reads: the streaming form.
+// TT_K1_COLS=0|1 (A/B; looked up per call like TT_K1_SLICED): off / on wherever the shape allows it.
+static bool colsliced_applies(int64_t V, int D, int S) {
+  if (D % kColSliceFloats != 0 || D / kColSliceFloats > 32 || S > kSlicedMaxS) return false;
+  if (const char* v = getenv("TT_K1_COLS"))
+    if (*v) return *v != '0';
+  return (double)V * kColSliceFloats * 4.0 <= 13.0e6;
+}
+
 template <typename IdT, typename MaskT>
 int launch_sliced(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
                   int S, int D, int64_t V, int32_t* oob, float* ws, unsigned lds_total, hipStream_t st,
                   const int32_t* text_rows, int64_t n_store) {
   const IdT* ids_t = static_cast<const IdT*>(ids);
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
+  if (colsliced_applies(V, D, S)) {
+    const int NS = D / kColSliceFloats;
+    const long long upc = ((long long)NS * N + 7) / 8;  // units per XCD class
+    // waves (= units) per workgroup: 8.  Beside the projection chain the gather's residency is a number of WORKGROUPS
+    // per CU, so this sets its waves per CU: 3 x 8 there (register-bound) against 4 x 4 (LDS-bound) — 179 vs 200 us
+    // per configs[1] step; 6 / 12 / 16 waves: 194 / 190 / 201 us.  Alone 4 waves are 3 us faster (TT_K1_COL_WAVES=4, A/B).
+    static const int cwpb = getenv("TT_K1_COL_WAVES") && atoi(getenv("TT_K1_COL_WAVES")) == 4 ? 4 : 8;
+    const long long wgs = 8 * ((upc + cwpb - 1) / cwpb);
+    if (wgs <= 0x7fffffffLL) {
+      static const int k1_prio = getenv("TT_K1_PRIO") ? atoi(getenv("TT_K1_PRIO")) : 0;
+      float* ssq = ws;  // [N][NS]
+      const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
+#define TT_COL_LAUNCH_W(MS, WW)                                                                                    \
+  hipLaunchKernelGGL((pool_colsliced_kernel<IdT, MaskT, MS, WW>), dim3((unsigned)wgs), dim3(WW * TT_WAVE), lds_total, st, \
+                     table, ids_t, mask_t, lens, out, ssq, (long long)N, S, D, (long long)V, oob, text_rows,      \
+                     (long long)n_store, NS, upc, k1_prio)
+#define TT_COL_LAUNCH(MS)                 \
+  do {                                    \
+    if (cwpb == 4) TT_COL_LAUNCH_W(MS, 4); \
+    else TT_COL_LAUNCH_W(MS, 8);          \
+  } while (0)
+      if (nseg <= 1) TT_COL_LAUNCH(1);
+      else if (nseg <= 2) TT_COL_LAUNCH(2);
+      else if (nseg <= 4) TT_COL_LAUNCH(4);
+      else TT_COL_LAUNCH(8);
+#undef TT_COL_LAUNCH
+#undef TT_COL_LAUNCH_W
+      TT_CHECK_LAUNCH();
+      hipLaunchKernelGGL(pool_colnorm_kernel, dim3((unsigned)((N + kWavesPerText - 1) / kWavesPerText)), dim3(kThreads), 0,
+                         st, out, ssq, (long long)N, D, NS);
+      TT_CHECK_LAUNCH();
+      return TT_OK;
+    }
+  }
   float* partial = ws;
   float* wsum = ws + (size_t)N * kSlices * D;
   // waves (= texts) per gather workgroup: TT_K1_WAVES=4|6|8 (A/B)
@@ -806,6 +978,8 @@ extern "C" int tt_embed_gather_f32(const float* table, const void* ids, int ids_
   return TT_OK;
 }
 
+extern "C" int tt_k1_sliced_form(int64_t V, int D, int S) { return colsliced_applies(V, D, S) ? 1 : 0; }
+
 extern "C" size_t tt_gather_pool_sliced_workspace_bytes(int64_t N, int D) {
   if (N <= 0 || D <= 0) return 0;
   return ((size_t)N * kSlices * (size_t)D + (size_t)N) * sizeof(float);
@@ -826,7 +1000,9 @@ extern "C" int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S) {
   if (const char* v = getenv("TT_K1_SLICED"))  // (looked up per call: tests and tools/k1_sliced_ab.py flip it in-process)
     if (*v) return *v != '0';
   const double table_bytes = (double)V * D * 4.0;
-  return table_bytes >= 10e6 && table_bytes <= 128e6 && S >= 48 && (double)N * S >= 131072.0;
+  // (column slices keep their lead up to tables that still fit the 256 MiB Infinity Cache: 154 MB at D = 384: 136 vs 166 us)
+  const double upper = colsliced_applies(V, D, S) ? 200e6 : 128e6;
+  return table_bytes >= 10e6 && table_bytes <= upper && S >= 48 && (double)N * S >= 131072.0;
 }
 
 // internal (engine.hip): sliced K1 with an LDS reservation (0 = none)

@@ -514,7 +514,10 @@ constexpr int kColSliceFloats = 32;
 // (66 registers: seven waves per SIMD.  Forced to 64 for eight — 12 bytes of scratch — it is slower alone, 91 vs 85 us,
 // and in the step, 183-187 vs 179 us: profiles/r03_k1_column_slices.txt.  Several units per wave with the next unit's
 // ids requested ahead: 90 registers, 94 us alone, 191-193 us per step for 1-4 units.  One short-lived wave per unit and
-// as many of them as the register file holds is the form that wins.)
+// as many of them as the register file holds is the form that wins.  Scalar base + 32-bit lane offsets bring it to 62
+// registers — eight waves per SIMD, 82 vs 85 us alone — but beside the projection chain the step is 184-185 vs 178-180 us
+// on one box (tools/r03_colslice9.sh): with 72-register waves three gather workgroups leave no room for a chain wave on
+// their CU, with 64 they do, and sharing a CU wave by wave costs the chain more than taking turns.)
 template <typename IdT, typename MaskT, int MAXSEG, int WPB>
 __global__ __launch_bounds__(WPB * TT_WAVE) void pool_colsliced_kernel(
     const float* __restrict__ table, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,

@@ -512,10 +512,11 @@ def run_config(args, world, rank, device) -> dict:
     # K1 alone (nothing else on the chip), same engine / residency cap, after the timed region
     iso_ev = []
     n_iso = getattr(args, "iso_launches", 20)
+    iso_roles = 3 if args.inputs == "ids3" else 2  # what a step of this mode gathers (index / in-batch modes: q and pos only)
     for i in range(n_iso):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         bb = batches[i % n_distinct] if (args.ragged and args.inputs == "ids3") else (id_batches[i % n_distinct], None, None)
-        e0.record(); trainer.engine.pool(i & 1, bb[0], None, bb[2]); e1.record()
+        e0.record(); trainer.engine.pool(i & 1, bb[0][:iso_roles].contiguous(), None, bb[2]); e1.record()
         iso_ev.append((e0, e1))
     torch.cuda.synchronize(device)
     iso_ms = sum(a.elapsed_time(b) for a, b in iso_ev[n_iso // 5:]) / len(iso_ev[n_iso // 5:])

@@ -52,6 +52,12 @@ def test_gather_bit_exact(tt):
     for dt in (torch.int64, torch.int32):
         out = ops.embed_gather(table.cuda(), ids.to(dt).cuda(), check_ids=True)
         assert torch.equal(out.cpu(), ref)
+    # row counts that are not a multiple of the four rows a wave copies per step, D beyond two chunks per lane, D % 4 != 0
+    for V, D, n in ((100, 384, 1), (100, 384, 7), (977, 768, 1001), (50, 100, 13), (64, 6, 130), (300, 512, 258)):
+        gen = torch.Generator().manual_seed(V + D + n)
+        t = torch.randn(V, D, generator=gen)
+        i = torch.randint(0, V, (1, n), generator=gen)
+        assert torch.equal(ops.embed_gather(t.cuda(), i.int().cuda(), check_ids=True).cpu(), t[i])
 
 
 def test_pool_indices_bit_exact_via_one_hot(tt):

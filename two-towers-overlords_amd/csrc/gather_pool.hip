@@ -503,7 +503,7 @@ __global__ __launch_bounds__(kThreads) void pool_combine_kernel(const float* __r
 // speed only), and class x takes the units [x * UPX, (x + 1) * UPX), UPX = ceil(NS * N / 8), in order: an XCD
 // works through at most two slices (NS = 12 at D = 384: one and a half), one after the other.  One wave per
 // unit: lane = (row slot r = lane >> 3, 16-byte piece q = lane & 7), so one wave instruction reads the
-// 128-byte pieces of 8 rows; 16 instructions (128 tokens) are in flight before the first use.  Token ids and
+// 128-byte pieces of 8 rows; 8 instructions (64 tokens, 8 KB) are in flight before the first use.  Token ids and
 // weights are loaded coalesced (non-temporal: they must not displace the slice) and handed to the row slots by
 // ds_bpermute.  Masked-out tokens are never fetched.  The 8 row slots meet in a 3-step butterfly, then mean
 // (clamp 1e-9), the slice's sum of squares, and lanes 0..7 store the 128 bytes of un-normalised mean.  A second

@@ -740,6 +740,49 @@ def test_pool_forms_fuzz(tt):
         assert (a - b).abs().max().item() <= 1e-6, (case, D, S, V, N, kind)
 
 
+def test_pool_column_slices_random_shapes(tt, monkeypatch):
+    """The column-sliced form over 40 seeded random shapes where it applies (D a multiple of 32 up to 1024, S up to
+    512, vocabularies from a handful of rows up, few and many texts), every kind of weighting (prefix lengths incl.
+    empty texts, masks with holes, integer weights, none), both index widths, out-of-range ids: against the oracle, against
+    the per-text form (1e-6) and against itself (bitwise, twice)."""
+    ops, _ = tt
+    monkeypatch.setenv("TT_K1_COLS", "1")
+    gen = torch.Generator().manual_seed(2027)
+    for case in range(40):
+        D = 32 * int(torch.randint(1, 33, (1,), generator=gen))
+        S = int(torch.randint(1, 513, (1,), generator=gen)) if case % 4 else int(torch.randint(1, 70, (1,), generator=gen))
+        V = int(torch.randint(3, 3000, (1,), generator=gen))
+        N = int(torch.randint(1, 40, (1,), generator=gen)) if case % 3 else int(torch.randint(200, 900, (1,), generator=gen))
+        table = torch.randn(V, D, generator=gen)
+        ids = torch.randint(0, V, (N, S), generator=gen)
+        kind = case % 4
+        mask, lens = None, None
+        if kind == 0:
+            lens = torch.randint(0, S + 1, (N,), generator=gen)
+            eff = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+        elif kind == 1:
+            mask = (torch.rand(N, S, generator=gen) < 0.7).long()
+            eff = mask
+        elif kind == 2:
+            mask = torch.randint(0, 4, (N, S), generator=gen)
+            eff = mask
+        else:
+            eff = torch.ones(N, S, dtype=torch.long)
+        if case % 5 == 0:
+            ids[0, 0] = V + 7
+            ids[-1, -1] = -3
+        ref = orc.gather_pool_normalize(table, ids.clamp(0, V - 1), eff)
+        idt = torch.int32 if case % 2 else torch.int64
+        mt = torch.int32 if case % 3 else torch.int64
+        kw = dict(attention_mask=None if mask is None else mask.to(mt).cuda(), lens=None if lens is None else lens.int().cuda())
+        a = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=False, **kw)
+        b = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=True, **kw)
+        b2 = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=True, **kw)
+        close(b, ref, atol=2e-6)
+        assert (a - b).abs().max().item() <= 1e-6, (case, D, S, V, N, kind)
+        assert torch.equal(b, b2), (case, D, S, V, N, kind)
+
+
 # --------------------------------------------------------------------------- streaming K1 (tables that come from HBM)
 def test_pool_stream_form_is_bitwise_the_per_text_form(tt):
     """tt_gather_pool_norm_stream_f32 (persistent workgroups pulling texts from a queue, at most n per compute
@@ -821,8 +864,10 @@ def test_pool_stream_registry_keys_are_compute_units(tt):
 # --------------------------------------------------------------------------- K1 through a token store (f3)
 @pytest.mark.parametrize("V,D,S,B,idt,sliced", [
     (2000, 128, 24, 64, torch.int32, False),     # small table: per-text K1
-    (30522, 384, 128, 400, torch.int32, True),   # MiniLM-sized table, enough tokens: XCD-sliced K1
+    (30522, 384, 128, 400, torch.int32, True),   # MiniLM-sized table, enough tokens: XCD-sliced K1 (column slices)
+    (30522, 384, 128, 400, torch.int32, "rows"),  # the same through the row slices
     (9000, 384, 64, 700, torch.int64, True),     # int64 store, sliced
+    (9000, 100, 64, 700, torch.int64, True),     # D % 32 != 0: row slices by themselves
     (200, 6, 7, 9, torch.int32, False),          # D % 4 != 0: generic kernel
 ])
 def test_engine_pool_rows_is_bitwise_pool_of_the_gathered_rows(tt, V, D, S, B, idt, sliced, monkeypatch):
@@ -834,6 +879,8 @@ def test_engine_pool_rows_is_bitwise_pool_of_the_gathered_rows(tt, V, D, S, B, i
 
     if sliced:
         monkeypatch.setenv("TT_K1_SLICED", "1")
+    if sliced == "rows":
+        monkeypatch.setenv("TT_K1_COLS", "0")
     N = 3000
     gen = torch.Generator().manual_seed(17)
     table = (orc.synthetic_table(V, D, seed=1) * 30).cuda()

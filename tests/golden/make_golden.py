@@ -398,9 +398,72 @@ def g_eval():
     np.savez_compressed(os.path.join(HERE, "eval.npz"), **out)
 
 
+def g_accum():
+    """`training.train_epoch_optimized` (training.py:66-133) of the reference itself, run UNCHANGED on the CPU in fp32:
+    `torch.set_autocast_dtype("cpu", torch.float32)` makes `autocast("cpu")` a no-op ("target dtype is not supported.
+    Disabling autocast": Linear stays fp32) and `GradScaler("cpu", enabled=False)` scales by 1, so what is left is the
+    accumulation arithmetic: loss / k, `optimizer.step()` + `zero_grad()` when (batch_idx + 1) % k == 0 with batch_idx
+    restarting every epoch, the gradient of an epoch's unpaired last batch neither applied nor cleared (it is still
+    in `.grad` when the next epoch starts), average of the un-scaled per-batch losses.  TWO epochs of FIVE batches
+    with k = 2: epoch 1 steps after batches 1 and 3 and leaves batch 4's gradient behind; epoch 2's first step
+    (after ITS batch 1) therefore applies three micro-gradients.  model.train() is called by the function; the
+    embed-only encoder has no dropout, so the quirk SURVEY.md §3.1 notes does not bite here."""
+    import warnings
+
+    V, D, P, B, S = 400, 40, 24, 19, 13
+    k, n_epochs, n_batches = 2, 2, 5
+    table = orc.synthetic_table(V, D, seed=51) * 50.0
+    params = orc.init_params(D, P, seed=52)
+    batches = [orc.synthetic_batch(B, S, V, seed=300 + i, ragged=True) for i in range(n_batches)]
+    margin, lr = 0.3, 1e-3
+    tok = _StubTokenizer()
+    out = {"table": np_(table), "margin": np.float64(margin), "lr": np.float64(lr), "n_batches": np.int64(n_batches),
+           "n_epochs": np.int64(n_epochs), "accumulation_steps": np.int64(k)}
+    for kk, v in params.items():
+        out["init/" + kk] = np_(v)
+    texts = [register_batch(tok, b, f"b{i}") for i, b in enumerate(batches)]
+    for i, b in enumerate(batches):
+        for role, (ids, mask) in zip("qpn", b):
+            out[f"batch{i}/ids_{role}"] = np_(ids)
+            out[f"batch{i}/mask_{role}"] = np_(mask)
+    m = build_ref_model(table, params, tok)
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    losses = []
+
+    class _Spy(ref_model.TripletLoss):
+        def forward(self, a, p_, n_):
+            l = super().forward(a, p_, n_)
+            assert l.dtype == torch.float32 and a.dtype == torch.float32  # autocast really is off
+            losses.append(float(l.detach()))
+            return l
+
+    torch.set_autocast_dtype("cpu", torch.float32)
+    scaler = torch.GradScaler("cpu", enabled=False)
+    avgs = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # "In CPU autocast, but the target dtype is not supported. Disabling autocast."
+        for e in range(n_epochs):
+            avgs.append(ref_training.train_epoch_optimized(m, texts, _Spy(margin=margin), opt, torch.device("cpu"), scaler,
+                                                           accumulation_steps=k, log_wandb=False))
+            for kk, v in trainable_state(m).items():
+                out[f"epoch{e}/" + kk] = np_(v)
+    out["epoch/avg_loss"] = np.array(avgs, dtype=np.float64)
+    out["epoch/loss_trace"] = np.array(losses, dtype=np.float64)
+    out["optimizer_steps"] = np.int64(next(iter(opt.state.values()))["step"].item())
+    # what is still in .grad after the last epoch: the carried (un-applied) gradient of its 5th batch, already / k
+    for kk, v in m.named_parameters():
+        if v.requires_grad:
+            out["carry/" + kk] = np_(v.grad)
+    np.savez_compressed(os.path.join(HERE, "step_accum.npz"), **out)
+    print(f"step_accum.npz: avgs={avgs} optimizer steps={int(out['optimizer_steps'])} trace={losses}")
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["triplets"]:  # regenerate only the sampling fixture
         g_triplets()
+        sys.exit(0)
+    if sys.argv[1:] == ["accum"]:  # regenerate only the accumulation fixture
+        g_accum()
         sys.exit(0)
     r = g_kat0()
     g_step_mid()
@@ -410,6 +473,7 @@ if __name__ == "__main__":
     g_bert_mode()
     g_triplets()
     g_eval()
+    g_accum()
     with open(os.path.join(HERE, "VERSIONS.txt"), "w") as f:
         import transformers
 

@@ -144,6 +144,56 @@ def test_trainer_accumulation_matches_oracle():
     assert (tr.bucket.cpu() - flat_carry).abs().max() <= TOL * max(1.0, float(flat_carry.abs().max()))
 
 
+@pytest.mark.parametrize("opt", ["fused", "torch"])
+def test_train_epoch_optimized_module_path_matches_reference(opt):
+    """a12 on the module path: `train_epoch_optimized` (same signature as backend/training.py:66-75) against
+    tests/golden/step_accum.npz, made by the reference's own function in fp32 — two epochs of five batches, k = 2:
+    four optimizer steps, epoch 1's fifth gradient applied with epoch 2's first two."""
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import FusedAdam, train_epoch_optimized
+
+    g = load_golden("step_accum.npz")
+    m, texts = build_model(g)
+    lr, k = float(g["lr"]), int(g["accumulation_steps"])
+    optim = FusedAdam(m.parameters(), lr=lr) if opt == "fused" else torch.optim.Adam(m.parameters(), lr=lr)
+    crit = TripletLoss(margin=float(g["margin"]))
+    for e in range(int(g["n_epochs"])):
+        avg = train_epoch_optimized(m, texts, crit, optim, torch.device("cuda"), None, accumulation_steps=k, log_wandb=False)
+        assert abs(avg - float(g["epoch/avg_loss"][e])) <= TOL
+        sd = m.state_dict()
+        for key in orc.PARAM_KEYS:
+            assert_params_close(sd[key].cpu().numpy(), g[f"epoch{e}/" + key], lr, 2 * (e + 1))
+    for key, prm in m.named_parameters():  # the un-applied fifth gradient is still in .grad (training.py:99-102)
+        if prm.requires_grad:
+            ref = g["carry/" + key]
+            assert np.abs(prm.grad.cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_trainer_accumulation_across_epochs_matches_reference(overlap):
+    """a12 on the fused engine: TripletTrainer(accumulation_steps=2) over the same two epochs against the same
+    reference-generated fixture (step counts 2 and 4, per-epoch averages, parameters after each epoch, carried bucket)."""
+    from two_towers_overlords_amd.training import TripletTrainer
+
+    g = load_golden("step_accum.npz")
+    m, _ = build_model(g)
+    nb, lr = int(g["n_batches"]), float(g["lr"])
+    B, S = g["batch0/ids_q"].shape
+    tr = TripletTrainer(m, max_batch=B, max_seq_len=S, margin=float(g["margin"]), lr=lr,
+                        accumulation_steps=int(g["accumulation_steps"]), overlap_streams=overlap)
+    batches = [(torch.stack([T(g[f"batch{i}/ids_{r}"]) for r in "qpn"]).cuda(),
+                torch.stack([T(g[f"batch{i}/mask_{r}"]) for r in "qpn"]).cuda(), None) for i in range(nb)]
+    for e in range(int(g["n_epochs"])):
+        avg = tr.train_epoch(batches)
+        assert tr.step_count == 2 * (e + 1)
+        assert abs(avg - float(g["epoch/avg_loss"][e])) <= TOL
+        sd = m.state_dict()
+        for key in orc.PARAM_KEYS:
+            assert_params_close(sd[key].cpu().numpy(), g[f"epoch{e}/" + key], lr, tr.step_count)
+    carry = np.concatenate([g["carry/" + key].reshape(-1) for key in orc.PARAM_KEYS])
+    assert np.abs(tr.bucket.cpu().numpy() - carry).max() <= TOL * max(1.0, np.abs(carry).max())
+
+
 def test_bert_mode_tower_matches_reference():
     """`bert` encoder mode: a tiny BertModel (rebuilt with the fixture's seed) between gather and pool."""
     transformers = pytest.importorskip("transformers")

@@ -139,3 +139,26 @@ def test_adam_restatement_equals_torch_adam():
         orc.adam_step(mine, grads, st)
     for k in p0:
         np.testing.assert_allclose(mine[k].numpy(), ref[k].detach().numpy(), atol=1e-7, rtol=0)
+
+
+def test_accumulation_epochs_match_reference_train_epoch_optimized():
+    """tests/golden/step_accum.npz: the reference's own `train_epoch_optimized` (backend/training.py:66-133) run in
+    fp32 on the CPU over two epochs of five batches with accumulation_steps = 2 — the fifth batch's gradient is still
+    in .grad when epoch 2 starts (training.py:99-102), so epoch 2's first optimizer step applies three of them."""
+    g = load_golden("step_accum.npz")
+    table, batches = T(g["table"]), _batches(g)
+    k, n_epochs = int(g["accumulation_steps"]), int(g["n_epochs"])
+    assert (len(batches), k, n_epochs) == (5, 2, 2)
+    params = _params(g, "init/")
+    st = orc.AdamState(lr=float(g["lr"]))
+    carry, trace = None, []
+    for e in range(n_epochs):
+        avg, tr, carry = orc.train_epoch_accum(table, batches, params, st, float(g["margin"]), k, carry=carry)
+        trace += tr
+        assert abs(avg - float(g["epoch/avg_loss"][e])) < TOL
+        for key in orc.PARAM_KEYS:
+            assert_params_close(params[key].numpy(), g[f"epoch{e}/" + key], float(g["lr"]), st.step)
+    assert st.step == int(g["optimizer_steps"]) == 4
+    np.testing.assert_allclose(trace, g["epoch/loss_trace"], atol=TOL, rtol=0)
+    for key in orc.PARAM_KEYS:  # what no optimizer step has consumed yet: the last batch's gradient / k
+        np.testing.assert_allclose(carry[key].numpy(), g["carry/" + key], atol=TOL, rtol=0)

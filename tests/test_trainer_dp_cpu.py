@@ -75,19 +75,11 @@ def _worker_body(rank, world, port, accum, q):
 
 
 def _run(world, accum, worker=None):
+    from mp_util import free_port, run_ranks
+
     worker = worker or _worker
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = 29500 + (os.getpid() % 2000) + 7 * world + accum + (0 if worker is _worker else 31)
-    procs = [ctx.Process(target=worker, args=(r, world, port, accum, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    out = q.get()
-    for p in procs:
-        p.join(120)
-    assert out[0] != "error", out[1]
-    assert all(p.exitcode == 0 for p in procs)
-    return out
+    port = free_port(salt=7 * world + accum + (0 if worker is _worker else 31))
+    return run_ranks(worker, world, (accum,), timeout=240, join=60, port=port)
 
 
 @pytest.mark.parametrize("world,accum", [(1, 1), (2, 1), (2, 2), (1, 3)])
@@ -278,3 +270,62 @@ def _worker_split(rank, world, port, accum, q):
 def test_split_exchange_is_bitwise_the_one_bucket_exchange(accum):
     same, avgs, steps = _run(2, accum, worker=_worker_split)
     assert same and avgs[0] == avgs[1] and steps[0] == steps[1] == 6 // accum
+
+
+def _accum_golden():
+    from conftest import load_golden
+
+    g = load_golden("step_accum.npz")
+    T = torch.from_numpy
+    table = T(g["table"])
+    params = {k: T(g["init/" + k]).clone() for k in orc.PARAM_KEYS}
+    gbs = [(torch.stack([T(g[f"batch{i}/ids_{r}"]) for r in "qpn"]), torch.stack([T(g[f"batch{i}/mask_{r}"]) for r in "qpn"]),
+            None) for i in range(int(g["n_batches"]))]
+    return g, table, params, gbs
+
+
+def _worker_accum_golden(rank, world, port, accum, q):
+    try:
+        from oracle_engine import OracleEngine
+        from two_towers_overlords_amd.training import TripletTrainer, shard_batch
+
+        torch.set_num_threads(1)
+        if world > 1:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        g, table, params, gbs = _accum_golden()
+        Bg, Sg = gbs[0][0].shape[1:]
+        tr = TripletTrainer(table=table, params=params, max_batch=Bg, max_seq_len=Sg, margin=float(g["margin"]),
+                            lr=float(g["lr"]), accumulation_steps=accum, engine=OracleEngine(table, params[orc.PARAM_KEYS[1]].shape[0], Bg, Sg))
+        shards, sizes = zip(*(shard_batch(gb, rank, world) for gb in gbs))
+        res = []
+        for _ in range(int(g["n_epochs"])):
+            avg = tr.train_epoch(list(shards), global_batch_sizes=list(sizes))
+            res.append((avg, {k: v.detach().numpy().copy() for k, v in tr.named_parameters().items()}, tr.step_count))
+        if rank == 0:
+            q.put(("ok", res, None))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+
+        q.put(("error", f"rank {rank}: {e}\n{traceback.format_exc()}", None))
+        raise
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_accumulation_across_epochs_matches_the_reference_train_epoch_optimized(world):
+    """The trainer's accumulation logic (oracle-backed engine; 1 replica and 2 gloo replicas with 10 + 9 shards)
+    against tests/golden/step_accum.npz — the reference's own `train_epoch_optimized` in fp32 over two epochs of
+    five batches, k = 2: steps after batches 1 and 3 of each epoch, epoch 1's fifth gradient applied together with
+    epoch 2's first two (backend/training.py:93-102)."""
+    g = _accum_golden()[0]
+    _, res, _ = _run(world, int(g["accumulation_steps"]), worker=_worker_accum_golden)
+    assert [r[2] for r in res] == [2, 4] and int(g["optimizer_steps"]) == 4
+    from conftest import assert_params_close
+
+    for e, (avg, params, steps) in enumerate(res):
+        assert abs(avg - float(g["epoch/avg_loss"][e])) < 2e-6
+        for k in orc.PARAM_KEYS:
+            assert_params_close(params[k], g[f"epoch{e}/" + k], float(g["lr"]), steps, tight=2e-6)

@@ -269,7 +269,12 @@ class TripletTrainer:
                 self._ev_dw2, self._ev_early = torch.cuda.Event(), torch.cuda.Event()
                 self.engine.set_dw2_event(self._ev_dw2)
         self.step_count = 0        # optimizer steps taken
-        self._micro = 0            # batches since the last optimizer step (carried across epochs, like the reference)
+        # backend/training.py:80-102: the optimizer steps when (batch_idx + 1) % k == 0 and batch_idx restarts with every
+        # epoch, while the gradient of an epoch's unpaired last batch stays in .grad — so the next epoch's first step
+        # applies k + 1 micro-gradients.  `_micro` is that batch index (train_epoch() resets it), `_carry` says that
+        # the bucket holds gradients no optimizer step has consumed yet (pinned by tests/golden/step_accum.npz).
+        self._micro = 0
+        self._carry = False
         if self.world > 1:
             self.sync_replicas()   # replicas start from rank 0's weights (what DDP's constructor broadcast does)
             # one all-reduce of the step's exact shape now, so that whatever the backend sets up lazily at the first use
@@ -502,7 +507,8 @@ class TripletTrainer:
             if issue_next is not None:
                 issue_next()
             return
-        first_micro = not (k > 1 and self._micro % k != 1)
+        first_micro = not self._carry  # nothing un-applied in the bucket: this batch's gradients overwrite it
+        self._carry = not do_step
         if self._split:
             self._split_step(local_B, first_micro, do_step, issue_next)
             return
@@ -530,7 +536,7 @@ class TripletTrainer:
         cpu = lambda t: None if t is None else t.detach().to("cpu", copy=True)
         return {"flat": cpu(self.flat), "exp_avg": cpu(self.exp_avg), "exp_avg_sq": cpu(self.exp_avg_sq),
                 "bucket": cpu(self.bucket) if self.accumulation_steps > 1 else None,
-                "step_count": self.step_count, "micro": self._micro, "D": self.D, "P": self.P,
+                "step_count": self.step_count, "micro": self._micro, "carry": self._carry, "D": self.D, "P": self.P,
                 "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "margin": self.margin,
                           "accumulation_steps": self.accumulation_steps}}
 
@@ -546,6 +552,7 @@ class TripletTrainer:
         if sd.get("bucket") is not None and self.bucket is not None:
             self.bucket.copy_(sd["bucket"].to(self.device))
         self.step_count, self._micro = int(sd["step_count"]), int(sd["micro"])
+        self._carry = bool(sd.get("carry", self._micro % self.accumulation_steps != 0))
         if self._auto_step:
             self.engine.set_step(self.step_count)
 
@@ -680,9 +687,9 @@ class TripletTrainer:
             dist.broadcast(t, src=src, group=self.pg)
         if self.bucket is not None:
             dist.broadcast(self.bucket, src=src, group=self.pg)  # an unfinished accumulation window travels too
-        steps = torch.tensor([self.step_count, self._micro], dtype=torch.int64, device=self.device)
+        steps = torch.tensor([self.step_count, self._micro, int(self._carry)], dtype=torch.int64, device=self.device)
         dist.broadcast(steps, src=src, group=self.pg)
-        self.step_count, self._micro = int(steps[0]), int(steps[1])
+        self.step_count, self._micro, self._carry = int(steps[0]), int(steps[1]), bool(steps[2])
 
     def replica_divergence(self) -> float:
         """max over ranks of |parameter checksum - rank 0's| (0.0 when the replicas are in step);
@@ -859,6 +866,7 @@ class TripletTrainer:
             gc.collect()
             gc.freeze()
             TripletTrainer._gc_frozen = True
+        self._micro = 0  # batch_idx of backend/training.py:80 restarts with the epoch; a carried gradient does not
         it = iter(batches)
         depth = self.SLOTS - 1 if self.side is not None else 1
         while len(self._pending) < depth:  # prime the pipeline

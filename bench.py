@@ -234,9 +234,18 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object (the same measurement at configs[3], V=250k d=768 S=256 B=16384: "
                          "the one configuration whose table streams from HBM; ~10 s extra on the default run)")
+    ap.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
+                    help="a tt_tuning field for this run's engine (include/tt_hotpath.h), e.g. --tune k1_form=stream "
+                         "--tune proj_tile=22; repeatable.  Speed only; recorded in config.tuning")
+    ap.add_argument("--dp-split", action="store_true",
+                    help="data-parallel step with the exchange in two parts (TripletTrainer(split_exchange=True))")
     ap.add_argument("--no-cpu-baseline-bert", action="store_true",
                     help="skip `cpu_baseline_bert` (the reference's executed CPU path: frozen MiniLM-shaped encoder, ~10 s)")
     args = ap.parse_args()
+    args.tuning = {}
+    for kv in args.tune:
+        k, _, v = kv.partition("=")
+        args.tuning[k] = v if not v.lstrip("-").isdigit() else int(v)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -261,7 +270,7 @@ def main():
 
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
-                    and not args.zipf and not args.ragged)
+                    and not args.zipf and not args.ragged and not args.tuning and not args.dp_split)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
     # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")
     args.cpu_baseline_later = bool(rank == 0 and world == 1 and default_line and not args.no_secondary)
@@ -313,6 +322,7 @@ def secondary_c4(args, world, rank, device) -> dict:
     step rate, K1 in the loop and K1 alone.  `traffic` is null: PMC counters are not collected in a timed run."""
     a = copy.copy(args)
     a.config, a.steps, a.warmup, a.no_cpu_baseline = "c4", 20, 6, True
+    a.tuning = {}
     # ~130 steps of set-up (0.8 s) before the 20 timed ones: the first ~70 steps after an idle gap run 10-20 % slower
     a.n_distinct, a.calibrate_steps, a.calibrate_rounds, a.iso_launches = 2, 24, 2, 8
     a.no_traffic_file = True  # `traffic` stays null here: nothing is read back from committed profiles
@@ -347,12 +357,11 @@ def run_config(args, world, rank, device) -> dict:
     for name, _, shape in flat_param_slices(D, P):
         bound = 1.0 / (shape[-1] if len(shape) == 2 else (D if ".0." in name else P)) ** 0.5
         params[name] = ((torch.rand(*shape, generator=gp) * 2 - 1) * bound).to(device)
-    if args.simulate_allreduce_us is not None and world == 1:
+    sim = args.simulate_allreduce_us is not None and world == 1
+    if sim:
         class TripletTrainer(TripletTrainer):  # noqa: F811  (diagnostic subclass: the exchange is a timed stand-in)
             def __init__(self, *a, **kw):
-                super().__init__(*a, **kw)
-                self._exchange = True
-                self.bucket = torch.empty_like(self.flat)
+                super().__init__(*a, exchange=True, **kw)  # the data-parallel step's code path on one rank
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda._sleep(1000); torch.cuda.synchronize()
                 e0.record(); torch.cuda._sleep(10_000_000); e1.record(); e1.synchronize()
@@ -362,9 +371,14 @@ def run_config(args, world, rank, device) -> dict:
                 if self._cycles > 0:
                     torch.cuda._sleep(self._cycles)
 
+            def _all_reduce_parts(self, parts):  # --dp-split: each part costs a whole exchange (latency-bound sizes)
+                if self._cycles > 0:
+                    torch.cuda._sleep(self._cycles)
+
     trainer = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
                              overlap_streams=(False if (args.no_overlap or args.k1_only) else None),
-                             k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss)
+                             k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss,
+                             tuning=(args.tuning or None), split_exchange=bool(args.dp_split))
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1
@@ -574,7 +588,7 @@ def run_config(args, world, rank, device) -> dict:
                    "rccl_ranks": (dist.get_world_size() if (world > 1 and args.backend == "nccl") else (1 if world == 1 else 0)),
                    "backend": (args.backend if world > 1 else None), "ids": "int32 [3,B,S], "
                    + ("zipf" if args.zipf else "uniform") + (", ragged lengths" if args.ragged else ", full length"), "parallelism": f"dp{world}", "inputs": args.inputs,
-                   "k1_only": bool(args.k1_only),
+                   "k1_only": bool(args.k1_only), "tuning": (trainer.engine.tuning or None),
                    "gather_overlap": ("side stream, " + ("K1's LDS reservation paired with the projection tile (auto)"
                                                        if trainer.engine_k1_cap < 0 else
                                                        "K1 capped at %d workgroups/CU" % trainer.engine_k1_cap))
@@ -615,7 +629,7 @@ def run_config(args, world, rank, device) -> dict:
         print("TRACE K1 in-loop ms (every %d-th launch):" % trainer.k1_event_every,
               [round(a.elapsed_time(b), 3) for a, b in k1_ev], file=sys.stderr)
     if os.environ.get("TT_TRACE") and hasattr(trainer.engine, "k1_census"):
-        print("TRACE streaming-K1 census per slot (admitted workgroups, CUs used, max registered on one CU):",
+        print("TRACE streaming-K1 census per slot (admitted workgroups, CUs used, max candidates on one CU, planned):",
               [trainer.engine.k1_census(s) for s in range(trainer.SLOTS)], file=sys.stderr)
     trainer.engine.close()  # the workspace goes back to the allocator before a `secondary` configuration is set up
     return result

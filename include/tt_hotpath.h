@@ -22,7 +22,8 @@
  *     exception crosses the boundary, nothing calls exit().
  *   - row-major fp32 everywhere; token ids / masks are int32 or int64 (the HF
  *     tokenizer's int64 tensors are consumed as they are: backend/model.py:43-48).
- *   - re-entrant, no global mutable state; one engine handle per device/rank.
+ *   - re-entrant, no global mutable state, no environment variables: every choice a caller can make is an
+ *     argument (tt_tuning below) or a property of an explicit handle; one engine handle per device/rank.
  */
 #ifndef TT_HOTPATH_H
 #define TT_HOTPATH_H
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 1
+#define TT_ABI_VERSION 2
 
 typedef void* tt_stream_t; /* hipStream_t */
 
@@ -52,6 +53,40 @@ typedef enum {
 /* integer element widths accepted for ids / masks */
 #define TT_I32 4
 #define TT_I64 8
+
+/*
+ * Tuning: which of several equivalent kernels / tilings / schedules a call uses.  Every field 0 = "auto", the
+ * measured-best choice for the shape (DESIGN.md sections 3, 5, 8).  Speed only: no field changes a result beyond fp32
+ * summation order, and the projection tiles do not even do that (every output element is a k-ordered fmaf chain
+ * whatever the tile).  Passed per call (NULL = all auto) or bound to an engine handle (tt_engine_set_tuning); there
+ * is no process-wide state behind it.  Fields a call has no use for are ignored; values a shape does not support
+ * fall back to auto.
+ */
+#define TT_K1_AUTO 0
+#define TT_K1_PER_TEXT 1      /* one workgroup per text */
+#define TT_K1_ROW_SLICES 2    /* XCD-sliced, token ids mod 8 */
+#define TT_K1_COLUMN_SLICES 3 /* XCD-sliced, 32-column slices (D % 32 == 0) */
+#define TT_K1_STREAM 4        /* persistent workgroups + per-CU registry (tables that stream from HBM) */
+#define TT_BWD_AUTO 0
+#define TT_BWD_FORK 1
+#define TT_BWD_FUSED 2
+typedef struct {
+  int32_t k1_form;         /* TT_K1_*: form of the gather+pool kernel */
+  int32_t k1_stream_wgs;   /* streaming K1: gather workgroups kept per compute unit, 1..8 (auto: 2) */
+  int32_t k1_stream_rows;  /* streaming K1: table rows in flight per wave (auto: by D; 4, 6 or 8 at 512 < D <= 768) */
+  int32_t k1_stream_offer; /* streaming K1: candidate workgroups launched per workgroup the chip may keep (auto: 16) */
+  int32_t k1_share_lds_kb; /* engine: KiB of LDS a gather workgroup occupies while it shares the chip with the
+                              projection kernels (auto: paired with the projection tile; -1: no reservation) */
+  int32_t proj_tile;       /* projection block tile, rows x columns in units of 64: 11, 21, 22 (auto: by shape) */
+  int32_t proj_bk;         /* K-step of the 128x128 projection tile: 16 or 32 */
+  int32_t tn_tile;         /* weight-gradient (split-K) tile: 11 or 22 */
+  int32_t xcd_order;       /* XCD-aware workgroup order of the projection GEMMs: 1 on, -1 off */
+  int32_t backward;        /* engine: TT_BWD_* schedule of phase B's backward */
+  int32_t k1_stream_linger;/* streaming K1: ~microseconds a turned-away candidate lingers before it leaves (auto: 0) */
+  int32_t tn_transpose;    /* weight-gradient GEMMs: stage the K-strided operands through a register transpose into
+                              K-contiguous LDS images (one ds_read_b128 per fragment): 1 on, -1 off */
+  int32_t reserved[4];     /* must be 0 */
+} tt_tuning;
 
 int tt_abi_version(void);
 /* Static string for a tt_status / hipError_t value (host pointer, never freed). */
@@ -99,40 +134,49 @@ int tt_gather_pool_norm_f32(const float* table, const void* ids, int ids_dtype,
  * BERT-sized vocabularies.
  */
 size_t tt_gather_pool_sliced_workspace_bytes(int64_t N, int D);
-/* which slicing tt_gather_pool_norm_sliced_f32 uses for this shape: 0 rows (ids mod 8), 1 columns */
+/* which slicing tt_gather_pool_norm_sliced_f32 picks for this shape when asked for TT_K1_AUTO:
+ * TT_K1_ROW_SLICES or TT_K1_COLUMN_SLICES (a pure function of the shape) */
 int tt_k1_sliced_form(int64_t V, int D, int S);
-/* 1 if the sliced form is the faster one for this shape on MI355X (host-side rule from measurements;
- * tt_engine_pool applies it by itself). */
+/* 1 if the sliced form is the faster one for this shape on MI355X (a pure function of the shape, from
+ * measurements; tt_engine_pool applies it by itself). */
 int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S);
+/* form: TT_K1_AUTO (tt_k1_sliced_form), TT_K1_ROW_SLICES or TT_K1_COLUMN_SLICES (needs D % 32 == 0, D <= 1024;
+ * else TT_ERR_UNSUPPORTED) */
 int tt_gather_pool_norm_sliced_f32(const float* table, const void* ids, int ids_dtype,
                                    const void* mask, int mask_dtype, const int32_t* lens,
                                    float* out, int64_t N, int S, int D, int64_t V,
                                    int32_t* oob_flag, void* workspace, size_t workspace_bytes,
-                                   tt_stream_t stream);
+                                   int form, tt_stream_t stream);
 
 /*
  * Streaming form of tt_gather_pool_norm_f32 for tables that really come from HBM (several times the 256 MiB
  * Infinity Cache; BASELINE.json configs[3]), built to share the chip with MFMA kernels of another stream:
  * persistent workgroups pull texts from a queue and at most `workgroups_per_cu` of them stay on any compute
- * unit (a workgroup that finds its CU full leaves at once), so the gather keeps a fixed number of row loads
- * in flight per CU and the rest of every CU stays free.  Same arguments and bitwise the same result as
- * tt_gather_pool_norm_f32.  `workspace`: tt_gather_pool_stream_workspace_bytes() bytes, 16-byte aligned,
- * private to one launch at a time (it holds the queue head and the per-CU registry; cleared by the call).
+ * unit, so the gather keeps a fixed number of row loads in flight per CU and the rest of every CU stays free.
+ * Candidate workgroups are offered well beyond that number (tt_tuning.k1_stream_offer per kept workgroup): a
+ * candidate that finds its CU full leaves at once, the ones the chip has no room for wait in the dispatcher and
+ * arrive as room appears, so every CU gets its share whatever else is running; once the planned number is
+ * admitted (or the queue is empty) the remaining candidates leave without touching anything.  Same arguments
+ * and bitwise the same result as tt_gather_pool_norm_f32.  `workspace`: tt_gather_pool_stream_workspace_bytes()
+ * bytes, 16-byte aligned, private to one launch at a time (it holds the queue head and the per-CU registry;
+ * cleared by the call).  `tuning` (may be NULL): k1_stream_rows, k1_stream_offer.
  * Requires D % 4 == 0, D <= 1024.  Replaces the same reference lines (backend/model.py:51-56, 63-72).
  */
 size_t tt_gather_pool_stream_workspace_bytes(void);
 int tt_k1_stream_supported(int D, const float* table, const float* out);
-/* 1 if the streaming form is the one to use for this shape on MI355X (tt_engine_pool applies it by itself) */
+/* 1 if the streaming form is the one to use for this shape on MI355X (a pure function of the shape;
+ * tt_engine_pool applies it by itself) */
 int tt_k1_prefers_stream(int64_t V, int D, int64_t N, int S);
 int tt_gather_pool_norm_stream_f32(const float* table, const void* ids, int ids_dtype,
                                    const void* mask, int mask_dtype, const int32_t* lens,
                                    float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
                                    void* workspace, size_t workspace_bytes, int workgroups_per_cu,
-                                   tt_stream_t stream);
+                                   const tt_tuning* tuning, tt_stream_t stream);
 /* Diagnostic (synchronises `stream`): workgroups the last streaming launch on `workspace` admitted, compute
- * units that hosted one, and the largest number of workgroups that registered on one CU. */
+ * units that hosted at least one ADMITTED workgroup, the largest number of candidates that tried one CU, and the
+ * workgroups the launch meant to keep (workgroups_per_cu x compute units, or fewer for a short queue). */
 int tt_gather_pool_stream_census(const void* workspace, int32_t* admitted, int32_t* cus_used,
-                                 int32_t* max_registered, tt_stream_t stream);
+                                 int32_t* max_registered, int32_t* planned, tt_stream_t stream);
 
 /*
  * Same pooling + normalisation over dense hidden states [N,S,D] (the `bert`
@@ -161,10 +205,11 @@ int tt_embed_gather_f32(const float* table, const void* ids, int ids_dtype, floa
  * H = relu(X W1^T + b1),  Out = H W2^T + b2.     Replaces backend/model.py:33-38,59.
  *   X [M,D], W1 [P,D], b1 [P], W2 [P,P], b2 [P], H [M,P] (saved for backward), Out [M,P]
  * Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): each output is a k-ordered fmaf chain.
+ * `tuning` (may be NULL): proj_tile, proj_bk, xcd_order.
  */
 int tt_proj_fwd_f32(const float* X, const float* W1, const float* b1, const float* W2,
                     const float* b2, float* H, float* Out, int64_t M, int D, int P,
-                    tt_stream_t stream);
+                    const tt_tuning* tuning, tt_stream_t stream);
 
 /* Bytes of scratch tt_proj_bwd_f32 needs for (M, D, P). */
 size_t tt_proj_bwd_workspace_bytes(int64_t M, int D, int P);
@@ -178,11 +223,12 @@ size_t tt_proj_bwd_workspace_bytes(int64_t M, int D, int P);
  * accumulate != 0 adds into dW1/db1/dW2/db2 (the document tower is called for
  * positives and negatives, backend/training.py:41-42), else overwrites.
  * workspace: tt_proj_bwd_workspace_bytes() bytes, 16-byte aligned.
+ * `tuning` (may be NULL): proj_tile, proj_bk, tn_tile, xcd_order.
  */
 int tt_proj_bwd_f32(const float* dOut, const float* X, const float* H, const float* W2,
                     float* dW1, float* db1, float* dW2, float* db2, void* workspace,
                     size_t workspace_bytes, int accumulate, int64_t M, int D, int P,
-                    tt_stream_t stream);
+                    const tt_tuning* tuning, tt_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* K3 — cosine-distance triplet loss, forward + gradient                      */
@@ -338,10 +384,17 @@ int tt_engine_set_sharing(tt_engine* e, int gathers_share_chip);
  * Which is faster depends on shape and on what shares the chip; TripletTrainer.calibrate() times
  * both on the device at hand.
  */
-#define TT_BWD_AUTO 0
-#define TT_BWD_FORK 1
-#define TT_BWD_FUSED 2
 int tt_engine_set_backward(tt_engine* e, int mode);
+
+/*
+ * Bind a tuning to this handle (host-side, no device work; NULL = all auto).  Every later tt_engine_pool* /
+ * tt_engine_fwd_bwd / tt_engine_forward / tt_engine_backward on the handle uses it; other handles are not
+ * affected.  tuning->backward != TT_BWD_AUTO has the effect of tt_engine_set_backward.  Must be set before the
+ * first tt_engine_pool* if it changes the K1 form (the LDS pairing of gather and projection tile is derived
+ * from it per call, so it may also be changed between steps).
+ */
+int tt_engine_set_tuning(tt_engine* e, const tt_tuning* tuning);
+int tt_engine_get_tuning(const tt_engine* e, tt_tuning* out);
 
 /* Borrow caller-owned device buffers (valid until rebound or destroy). */
 int tt_engine_bind(tt_engine* e, const float* table, float* params, float* exp_avg,
@@ -421,7 +474,7 @@ int tt_engine_add_loss(tt_engine* e, const float* loss_value, tt_stream_t stream
 /* Diagnostic (synchronises `stream`): tt_gather_pool_stream_census of the streaming gather last launched into pooled
  * slot `slot` by tt_engine_pool* (all zeros when the engine does not use the streaming form for its table). */
 int tt_engine_k1_census(tt_engine* e, int slot, int32_t* admitted, int32_t* cus_used, int32_t* max_registered,
-                        tt_stream_t stream);
+                        int32_t* planned, tt_stream_t stream);
 
 /* grad_out[param_count] (+)= sum of slabs — the flat bucket handed to the RCCL all-reduce. */
 int tt_engine_reduce_grads(tt_engine* e, float* grad_out, int accumulate, tt_stream_t stream);

@@ -69,9 +69,11 @@ def test_product_package_never_imports_oracle():
 
 def test_k1_form_selection_and_workspace_rules(monkeypatch):
     """Host-only logic: which K1 form a shape gets (tt_k1_prefers_sliced, measured rule in gather_pool.hip) and
-    what that means for the engine's workspace; the sliced entry point's argument checks."""
+    what that means for the engine's workspace; the sliced entry point's argument checks.  The rules are pure
+    functions of the shape: environment variables of round 3's A/B knobs must change nothing."""
     lib = pkg.load()
-    monkeypatch.delenv("TT_K1_SLICED", raising=False)
+    for k, v in (("TT_K1_SLICED", "0"), ("TT_K1_COLS", "0"), ("TT_K1_STREAM", "1"), ("TT_TILE", "22"), ("TT_BWD", "fork")):
+        monkeypatch.setenv(k, v)
     pref = lib.tt_k1_prefers_sliced
     assert pref(30522, 384, 6144, 128) == 1        # the metric shape: 46.9 MB table
     assert pref(30522, 384, 6144, 32) == 0         # too few rows per slice
@@ -80,42 +82,36 @@ def test_k1_form_selection_and_workspace_rules(monkeypatch):
     assert pref(250000, 768, 49152, 256) == 0      # 768 MB table: a slice no longer fits an L2
     assert pref(30522, 386, 6144, 128) == 0        # D % 4 != 0: generic path only
     assert pref(30522, 384, 6144, 1024) == 0       # S beyond the sliced kernel's list buffers
-    monkeypatch.setenv("TT_K1_SLICED", "0")
-    assert pref(30522, 384, 6144, 128) == 0
-    monkeypatch.setenv("TT_K1_SLICED", "1")
-    assert pref(2000, 384, 64, 128) == 1 and pref(30522, 386, 6144, 128) == 0
-    monkeypatch.delenv("TT_K1_SLICED")
 
     # which slicing the sliced entry point uses: 32-column slices where D % 32 == 0 and a slice (V x 128 bytes) is at
     # most 13 MB (measured up to V = 100000)
-    monkeypatch.delenv("TT_K1_COLS", raising=False)
     form = lib.tt_k1_sliced_form
-    assert form(30522, 384, 128) == 1 and form(30522, 768, 256) == 1   # 3.9 MB per slice
-    assert form(101562, 384, 128) == 1 and form(101563, 384, 128) == 0  # the 13e6-byte boundary
+    ROWS, COLS = _lib.TT_K1_ROW_SLICES, _lib.TT_K1_COLUMN_SLICES
+    assert form(30522, 384, 128) == COLS and form(30522, 768, 256) == COLS   # 3.9 MB per slice
+    assert form(101562, 384, 128) == COLS and form(101563, 384, 128) == ROWS  # the 13e6-byte boundary
     assert pref(100000, 384, 6144, 128) == 1 and pref(100000, 388, 6144, 128) == 0  # 154 MB table: only with column slices
-    assert form(250000, 768, 256) == 0                                  # 32 MB per column slice: row slices
-    assert form(30522, 100, 128) == 0 and form(30522, 1056, 128) == 0   # partial slice / more than 32 slices
-    assert form(30522, 384, 1024) == 0                                  # S beyond the sliced kernels
-    monkeypatch.setenv("TT_K1_COLS", "0")
-    assert form(30522, 384, 128) == 0
-    monkeypatch.setenv("TT_K1_COLS", "1")
-    assert form(250000, 768, 256) == 1 and form(30522, 100, 128) == 0   # forced on wherever the shape allows it
-    monkeypatch.delenv("TT_K1_COLS")
+    assert form(250000, 768, 256) == ROWS                                  # 32 MB per column slice: row slices
+    assert form(30522, 100, 128) == ROWS and form(30522, 1056, 128) == ROWS   # partial slice / more than 32 slices
+    assert form(30522, 384, 1024) == ROWS                                  # S beyond the sliced kernels
 
     ws = lib.tt_gather_pool_sliced_workspace_bytes
     assert ws(6144, 384) == (6144 * 8 * 384 + 6144) * 4 and ws(0, 384) == 0
     # null workspace / short workspace / unsupported S are refused before any launch
-    f = lib.tt_gather_pool_norm_sliced_f32
-    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, None, 0, None) == -1
-    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, 64, None) == -5
-    assert f(16, 16, 4, None, 4, None, 16, 8, 4096, 384, 1000, None, 16, 1 << 30, None) == -2
+    f = lib.tt_gather_pool_norm_sliced_f32  # (..., workspace, workspace_bytes, form, stream)
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, None, 0, 0, None) == -1
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, 64, 0, None) == -5
+    assert f(16, 16, 4, None, 4, None, 16, 8, 4096, 384, 1000, None, 16, 1 << 30, 0, None) == -2
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 100, 1000, None, 16, 1 << 30, COLS, None) == -7   # no whole 32-column slices
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, 1 << 30, _lib.TT_K1_STREAM, None) == -7  # not a slicing
 
     def engine_bytes(V, D, share):
         cfg = _lib.TTEngineConfig(V, D, 384, 2048, 128, 0, share)
         return lib.tt_engine_workspace_bytes(ctypes.byref(cfg))
 
     small, metric = engine_bytes(2000, 384, 0), engine_bytes(30522, 384, 0)
-    assert metric - small >= 3 * ws(3 * 2048, 384)            # three slots of partial sums, only where sliced applies
+    # three slots of partial sums where the sliced form can win (or they are small enough to let a tuning force it:
+    # 75.5 MB per slot at this batch is not, so the 3 MB table's engine goes without)
+    assert metric - small >= 3 * ws(3 * 2048, 384)
     assert engine_bytes(30522, 384, _lib.TT_K1_SHARE_AUTO) == metric  # sharing mode does not change the layout
     assert engine_bytes(30522, 384, -2) == 0                          # invalid sharing mode
 
@@ -124,25 +120,40 @@ def test_k1_streaming_form_selection_and_argument_checks(monkeypatch):
     """Host-only logic of the streaming gather (tables that come from HBM): which shapes get it
     (tt_k1_prefers_stream), its fixed-size workspace, and the argument checks that run before any launch."""
     lib = pkg.load()
-    monkeypatch.delenv("TT_K1_STREAM", raising=False)
+    monkeypatch.setenv("TT_K1_STREAM", "0")  # round 3's A/B knob: no longer read by anything
     pref = lib.tt_k1_prefers_stream
     assert pref(250000, 768, 49152, 256) == 1       # BASELINE.json configs[3]: 768 MB, three Infinity Caches
     assert pref(30522, 384, 6144, 128) == 0         # the MiniLM table is cache-resident: the XCD-sliced form's territory
     assert pref(250000, 768, 512, 256) == 0         # too few tokens to keep persistent workgroups busy
     assert pref(250000, 770, 49152, 256) == 0       # D % 4 != 0: generic path only
-    monkeypatch.setenv("TT_K1_STREAM", "1")
-    assert pref(30522, 384, 6144, 128) == 1
-    monkeypatch.setenv("TT_K1_STREAM", "0")
-    assert pref(250000, 768, 49152, 256) == 0
-    monkeypatch.delenv("TT_K1_STREAM")
 
     nbytes = lib.tt_gather_pool_stream_workspace_bytes()
     assert nbytes == (4 + 4096) * 4                 # queue head + counters + one registry slot per compute-unit key
     f = lib.tt_gather_pool_norm_stream_f32
-    # (table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob, workspace, workspace_bytes, workgroups_per_cu, stream)
-    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, None, nbytes, 2, None) == -1      # no workspace
-    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, nbytes - 1, 2, None) == -5    # short workspace
-    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, nbytes, 0, None) == -2        # no workgroups per CU
-    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 386, 1000, None, 16, nbytes, 2, None) == -2        # D % 4 != 0
-    assert f(16, 16, 2, None, 4, None, 16, 8, 128, 384, 1000, None, 16, nbytes, 2, None) == -3        # bad id width
-    assert f(16, 16, 4, None, 4, None, 16, 0, 128, 384, 1000, None, 16, nbytes, 2, None) == 0         # no texts: nothing to do
+    # (table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob, workspace, workspace_bytes, workgroups_per_cu, tuning, stream)
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, None, nbytes, 2, None, None) == -1      # no workspace
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, nbytes - 1, 2, None, None) == -5    # short workspace
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, nbytes, 0, None, None) == -2        # no workgroups per CU
+    assert f(16, 16, 4, None, 4, None, 16, 8, 128, 386, 1000, None, 16, nbytes, 2, None, None) == -2        # D % 4 != 0
+    assert f(16, 16, 2, None, 4, None, 16, 8, 128, 384, 1000, None, 16, nbytes, 2, None, None) == -3        # bad id width
+    assert f(16, 16, 4, None, 4, None, 16, 0, 128, 384, 1000, None, 16, nbytes, 2, None, None) == 0         # no texts: nothing to do
+
+
+def test_tuning_is_an_argument_not_process_state():
+    """tt_tuning: the struct's layout matches the header (16 int32), unknown fields are refused by the Python shim,
+    and the library reads no environment variable (include/tt_hotpath.h: "no global mutable state, no environment
+    variables")."""
+    assert ctypes.sizeof(_lib.TTTuning) == 64
+    hdr = open(os.path.join(ROOT, "include", "tt_hotpath.h")).read()
+    body = re.search(r"typedef struct \{(.*?)\} tt_tuning;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"int32_t\s+(\w+)", body)
+    assert fields == [n for n, _ in _lib.TTTuning._fields_]
+    t = _lib.make_tuning({"k1_form": "stream", "proj_tile": 22, "backward": "fork"})
+    assert (t.k1_form, t.proj_tile, t.backward) == (_lib.TT_K1_STREAM, 22, _lib.TT_BWD_FORK)
+    with pytest.raises(KeyError):
+        _lib.make_tuning({"no_such_field": 1})
+    for dp, _, files in os.walk(os.path.join(ROOT, "two-towers-overlords_amd", "csrc")):
+        for f in files:
+            if f.endswith((".hip", ".h")):
+                assert "getenv" not in open(os.path.join(dp, f)).read(), f

@@ -118,15 +118,21 @@ def test_pool_vs_oracle_shapes(tt, D, S, V, N):
     close(ops.pool_norm_dense(hidden.cuda(), mask.cuda()), ref)
 
 
+def _slicing(cols: str, D: int) -> str:
+    """The slicing a parametrised case asks for: column slices wherever the width allows them (D % 32 == 0, D <= 1024),
+    else row slices — the explicit `form` argument of tt_gather_pool_norm_sliced_f32 (no environment knob)."""
+    return "columns" if (cols == "1" and D % 32 == 0 and D <= 1024) else "rows"
+
+
 @pytest.mark.parametrize("D,S,V,N", [(384, 128, 30522, 301), (768, 256, 5000, 67), (64, 7, 100, 5), (1024, 33, 777, 9),
                                      (384, 512, 30522, 13), (8, 300, 40, 3), (128, 64, 5, 6), (384, 128, 30522, 5000)])
 @pytest.mark.parametrize("cols", ["0", "1"], ids=["row-slices", "column-slices"])
-def test_pool_sliced_vs_oracle_shapes(tt, D, S, V, N, cols, monkeypatch):
+def test_pool_sliced_vs_oracle_shapes(tt, D, S, V, N, cols):
     """XCD-sliced K1 (tt_gather_pool_norm_sliced_f32), both of its forms (slices of rows: ids % 8; slices of 32 columns,
     wherever D % 32 == 0): same contract as the per-text form — masks with holes, prefix lengths (incl. 0), both index
     widths, all-ones, vocabularies smaller than the slice count."""
     ops, _ = tt
-    monkeypatch.setenv("TT_K1_COLS", cols)
+    form = _slicing(cols, D)
     gen = torch.Generator().manual_seed(D + S + 1)
     table = torch.randn(V, D, generator=gen)
     ids = torch.randint(0, V, (N, S), generator=gen)
@@ -135,45 +141,45 @@ def test_pool_sliced_vs_oracle_shapes(tt, D, S, V, N, cols, monkeypatch):
     lens[-1] = 0
     mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
     ref = orc.gather_pool_normalize(table, ids, mask)
-    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), mask.cuda(), check_ids=True, sliced=True), ref)
-    close(ops.gather_pool_norm(table.cuda(), ids.int().cuda(), lens=lens.int().cuda(), sliced=True), ref)
-    close(ops.gather_pool_norm(table.cuda(), ids.int().cuda(), mask.int().cuda(), sliced=True), ref)
+    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), mask.cuda(), check_ids=True, form=form), ref)
+    close(ops.gather_pool_norm(table.cuda(), ids.int().cuda(), lens=lens.int().cuda(), form=form), ref)
+    close(ops.gather_pool_norm(table.cuda(), ids.int().cuda(), mask.int().cuda(), form=form), ref)
     holey = (torch.rand(N, S, generator=gen) < 0.6).long()
-    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), holey.cuda(), sliced=True),
+    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), holey.cuda(), form=form),
           orc.gather_pool_normalize(table, ids, holey))
-    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), sliced=True), orc.gather_pool_normalize(table, ids, torch.ones_like(ids)))
+    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), form=form), orc.gather_pool_normalize(table, ids, torch.ones_like(ids)))
     # the two forms differ only in fp32 summation order
-    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), holey.cuda(), sliced=True),
+    close(ops.gather_pool_norm(table.cuda(), ids.cuda(), holey.cuda(), form=form),
           ops.gather_pool_norm(table.cuda(), ids.cuda(), holey.cuda()), atol=1e-6)
 
 
 @pytest.mark.parametrize("cols", ["0", "1"], ids=["row-slices", "column-slices"])
-def test_pool_sliced_golden_and_flags(tt, cols, monkeypatch):
+def test_pool_sliced_golden_and_flags(tt, cols):
     ops, _ = tt
-    monkeypatch.setenv("TT_K1_COLS", cols)
     g = load_golden("pool_edges.npz")
+    f = lambda t: _slicing(cols, t.shape[1])  # per call: the fixture tables have different widths
     table, ids, mask = dev(g["table"]), dev(g["ids"]), dev(g["mask"])
-    out = ops.gather_pool_norm(table, ids, mask, check_ids=True, sliced=True)
+    out = ops.gather_pool_norm(table, ids, mask, check_ids=True, form=f(table))
     close(out, g["out"])
     assert torch.all(out[2] == 0)  # all-padding row
     for name in ("kat0.npz", "step_d384.npz"):
         g = load_golden(name)
         for r in "qpn":
-            close(ops.gather_pool_norm(dev(g["table"]), dev(g[f"batch0/ids_{r}"]), dev(g[f"batch0/mask_{r}"]), sliced=True),
+            close(ops.gather_pool_norm(dev(g["table"]), dev(g[f"batch0/ids_{r}"]), dev(g[f"batch0/mask_{r}"]), form=f(g["table"])),
                   g[f"fwd/pooled_{r}"])
     t = torch.randn(10, 8).cuda()
     bad = torch.tensor([[1, 2, 99], [3, -4, 5]]).cuda()
     with pytest.raises(IndexError):
-        ops.gather_pool_norm(t, bad, check_ids=True, sliced=True)
+        ops.gather_pool_norm(t, bad, check_ids=True, form=f(t))
     m = torch.tensor([[1, 1, 0], [1, 0, 1]]).cuda()  # the out-of-range ids are masked out: no flag, no read
-    close(ops.gather_pool_norm(t, bad, m, check_ids=True, sliced=True),
+    close(ops.gather_pool_norm(t, bad, m, check_ids=True, form=f(t)),
           orc.gather_pool_normalize(t.cpu(), bad.cpu().clamp(0, 9), m.cpu()))
     # one-hot table: the pooled sum is the histogram of the unmasked ids
     V = 256
     gen = torch.Generator().manual_seed(9)
     ids = torch.randint(0, V, (37, 50), generator=gen)
     lens = torch.randint(1, 51, (37,), generator=gen)
-    out = ops.gather_pool_norm(torch.eye(V).cuda(), ids.int().cuda(), lens=lens.int().cuda(), sliced=True).cpu()
+    out = ops.gather_pool_norm(torch.eye(V).cuda(), ids.int().cuda(), lens=lens.int().cuda(), form=_slicing(cols, V)).cpu()
     hist = torch.stack([torch.bincount(ids[b, : lens[b]], minlength=V).float() for b in range(37)])
     assert torch.equal(out != 0, hist != 0)
 
@@ -200,8 +206,24 @@ def test_bert_mode_dense_pool_golden(tt):
 
 
 # --------------------------------------------------------------------------- K2
+# Every tiling / staging / workgroup order the projection GEMMs exist in, forced through the explicit tt_tuning argument
+# for EVERY shape below — odd shapes, edge tiles and the scalar path included (the policies that pick them by
+# themselves live in proj.hip / engine.hip).  Round 3 did this with environment knobs in eleven child processes.
+PROJ_TUNINGS = [
+    None,
+    {"proj_tile": 22, "proj_bk": 16, "tn_tile": 22, "xcd_order": 1},  # what runs beside the streaming gather (configs[3])
+    {"xcd_order": 1},
+    {"proj_tile": 21, "xcd_order": 1},
+    {"proj_tile": 22},                                                 # 128x128, K-step 32
+    {"tn_transpose": 1},                                               # weight gradients staged through a register transpose
+    {"tn_transpose": 1, "tn_tile": 22, "xcd_order": 1},
+]
+_tid = lambda t: "auto" if t is None else ",".join(f"{k}={v}" for k, v in t.items())
+
+
+@pytest.mark.parametrize("tuning", PROJ_TUNINGS, ids=_tid)
 @pytest.mark.parametrize("M,D,P", [(33, 48, 40), (4, 8, 4), (2048, 384, 384), (257, 384, 64), (100, 30, 37), (640, 768, 512)])
-def test_projection_fwd_bwd_vs_oracle(tt, M, D, P):
+def test_projection_fwd_bwd_vs_oracle(tt, M, D, P, tuning):
     ops, _ = tt
     gen = torch.Generator().manual_seed(M + D + P)
     x = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=1)
@@ -210,11 +232,17 @@ def test_projection_fwd_bwd_vs_oracle(tt, M, D, P):
     ref = orc.projection(x, w1, b1, w2, b2)
     d_out = torch.randn(M, P, generator=gen) / M
     ref.backward(d_out)
-    out, h = ops.proj_fwd(x.cuda(), w1.detach().cuda(), b1.detach().cuda(), w2.detach().cuda(), b2.detach().cuda())
+    out, h = ops.proj_fwd(x.cuda(), w1.detach().cuda(), b1.detach().cuda(), w2.detach().cuda(), b2.detach().cuda(),
+                          tuning=tuning)
     close(out, ref.detach())
-    dW1, db1, dW2, db2 = ops.proj_bwd(d_out.cuda(), x.cuda(), h, w2.detach().cuda())
+    dW1, db1, dW2, db2 = ops.proj_bwd(d_out.cuda(), x.cuda(), h, w2.detach().cuda(), tuning=tuning)
     for a, r in ((dW1, w1.grad), (db1, b1.grad), (dW2, w2.grad), (db2, b2.grad)):
         close(a, r, rel_to_max=True)
+    if tuning is not None:  # tiles never change a product: every output element is the same k-ordered fmaf chain
+        out0, h0 = ops.proj_fwd(x.cuda(), w1.detach().cuda(), b1.detach().cuda(), w2.detach().cuda(), b2.detach().cuda())
+        assert torch.equal(out, out0) and torch.equal(h, h0)
+        g0 = ops.proj_bwd(d_out.cuda(), x.cuda(), h0, w2.detach().cuda())
+        assert torch.equal(dW1, g0[0]) and torch.equal(dW2, g0[2])  # (bias gradients: another summation order under tn_transpose)
 
 
 # --------------------------------------------------------------------------- K3
@@ -288,8 +316,25 @@ def _unflat(flat, D, P):
     return out
 
 
+# The engine under every K1 form / chip-sharing pairing / tiling it can be told to use, per handle (tt_engine_set_tuning):
+# (k1_blocks_per_cu, tuning).  TT_K1_SHARE_AUTO = -1.
+ENGINE_SETUPS = [
+    (0, None),
+    (-1, None),
+    (-1, {"k1_form": "stream"}),                                        # streaming gather -> 128x128 K-step-16 tiles, XCD order
+    (-1, {"k1_form": "stream", "k1_stream_wgs": 1, "k1_stream_rows": 8, "k1_stream_offer": 2, "k1_stream_linger": 3}),
+    (0, {"k1_form": "rows"}),
+    (0, {"k1_form": "columns"}),
+    (-1, {"k1_form": "columns", "tn_transpose": 1, "proj_tile": 21, "xcd_order": 1}),
+    (2, {"backward": "fork", "k1_form": "per_text"}),
+    (-1, {"backward": "fused", "tn_tile": 22, "proj_tile": 22, "proj_bk": 16, "k1_share_lds_kb": 40}),
+]
+_eid = lambda s: f"share={s[0]}," + _tid(s[1])
+
+
+@pytest.mark.parametrize("setup", ENGINE_SETUPS, ids=_eid)
 @pytest.mark.parametrize("name", ["kat0.npz", "step_mid.npz", "step_d384.npz"])
-def test_engine_matches_reference_golden(tt, name):
+def test_engine_matches_reference_golden(tt, name, setup):
     _, engine = tt
     g = load_golden(name)
     table = dev(g["table"])
@@ -300,7 +345,7 @@ def test_engine_matches_reference_golden(tt, name):
     ids = [torch.stack([T(g[f"batch{i}/ids_{r}"]) for r in "qpn"]).cuda() for i in range(nb)]
     mask = [torch.stack([T(g[f"batch{i}/mask_{r}"]) for r in "qpn"]).cuda() for i in range(nb)]
     B, S = ids[0].shape[1:]
-    eng = engine.HotPathEngine(table, P, B, S)
+    eng = engine.HotPathEngine(table, P, B, S, k1_blocks_per_cu=setup[0], tuning=setup[1])
     flat = _flat({k: T(g["init/" + k]) for k in orc.PARAM_KEYS}).cuda()
     m, v = torch.zeros_like(flat), torch.zeros_like(flat)
     eng.bind(flat, m, v)
@@ -471,7 +516,8 @@ def test_feature_cache_is_bitwise_the_gather(tt):
     (200, 6, 5, 9, 7, torch.int32, True),        # D % 4 != 0 -> generic gather kernel, scalar GEMM path
     (4000, 768, 512, 130, 20, torch.int32, False),
 ])
-def test_engine_awkward_shapes_vs_oracle(tt, V, D, P, B, S, idt, use_mask):
+@pytest.mark.parametrize("setup", [ENGINE_SETUPS[0], ENGINE_SETUPS[2], ENGINE_SETUPS[6], ENGINE_SETUPS[8]], ids=_eid)
+def test_engine_awkward_shapes_vs_oracle(tt, V, D, P, B, S, idt, use_mask, setup):
     _, engine = tt
     gen = torch.Generator().manual_seed(V + D + P + B + S)
     table = torch.randn(V, D, generator=gen)
@@ -487,7 +533,7 @@ def test_engine_awkward_shapes_vs_oracle(tt, V, D, P, B, S, idt, use_mask):
         mask = (torch.arange(S).view(1, 1, S) < lens.unsqueeze(-1)).long()
     batch = tuple((ids[r], mask[r]) for r in range(3))
     loss, grads, embs = orc.loss_and_grads(table, batch, params, 0.25)
-    eng = engine.HotPathEngine(table.cuda(), P, B, S)
+    eng = engine.HotPathEngine(table.cuda(), P, B, S, k1_blocks_per_cu=setup[0], tuning=setup[1])
     flat = _flat(params).cuda()
     m, v = torch.zeros_like(flat), torch.zeros_like(flat)
     eng.bind(flat, m, v)
@@ -511,6 +557,61 @@ def test_engine_awkward_shapes_vs_oracle(tt, V, D, P, B, S, idt, use_mask):
     if float(hinge.min()) > 1e-5:
         for k, pt in _unflat(flat, D, P).items():
             assert_params_close(pt.cpu().numpy(), params[k].numpy(), 1e-3, 1)
+    eng.close()
+
+
+def test_engine_streams_a_table_beyond_the_infinity_cache_only_for_long_batches(tt):
+    """The default policy, nothing forced: an engine that shares the chip (TT_K1_SHARE_AUTO) over a table of 400 MB —
+    beyond the 256 MiB Infinity Cache — takes the streaming gather (per-slot queue + registry, row indirection
+    included) and the 128x128 K-step-16 tiles for a batch of >= 1 M tokens, and the per-text gather with the ordinary
+    tiles for a short batch of the SAME engine; both against the per-text kernel (bitwise), the oracle on a subsample
+    (embeddings) and fp64 autograd on the device (loss, gradients) — the wiring bench.py's `secondary` runs."""
+    ops, engine = tt
+    from two_towers_overlords_amd import _lib
+
+    V, D, P, S = 131072, 768, 256, 256
+    gen = torch.Generator().manual_seed(41)
+    table = (torch.randn(V, D, generator=gen) * 0.5).cuda()
+    assert V * D * 4 >= 400e6
+    params = orc.init_params(D, P, seed=9)
+    Bmax = 1408
+    eng = engine.HotPathEngine(table, P, Bmax, S, k1_blocks_per_cu=_lib.TT_K1_SHARE_AUTO)
+    flat = _flat(params).cuda()
+    eng.bind(flat, torch.zeros_like(flat), torch.zeros_like(flat))
+    store = torch.randint(0, V, (5000, S), generator=gen, dtype=torch.int32).cuda()
+    store_lens = torch.randint(1, S + 1, (5000,), generator=gen).int().cuda()
+    for B, streams in ((Bmax, True), (96, False)):
+        assert bool(_lib.load().tt_k1_prefers_stream(V, D, 3 * B, S)) == streams
+        rows = torch.randint(0, 5000, (3, B), generator=gen).int().cuda()
+        eng.pool_rows(1, store, store_lens, rows)
+        adm, cus, _, plan = eng.k1_census(1)
+        assert (adm > 0 and adm == plan and cus > 0) if streams else (adm, cus, plan) == (0, 0, 0)
+        ids = store[rows.long()].reshape(3 * B, S).contiguous()
+        lens = store_lens[rows.long()].reshape(-1).contiguous()
+        pooled = eng.pooled(1, B).reshape(3 * B, D)
+        assert torch.equal(pooled, ops.gather_pool_norm(table, ids, lens=lens, sliced=False))
+        eng.fwd_bwd(1, B, 0.3)
+        g = torch.empty_like(flat)
+        eng.reduce_grads(g)
+        _, _, last = eng.read_stats()
+        # fp64 autograd on the device from the engine's own pooled rows
+        x = pooled.double().reshape(3, B, D)
+        leaves = {k: v.double().cuda().requires_grad_(True) for k, v in params.items()}
+        embs = []
+        for r, tower in enumerate(("query_tower", "document_tower", "document_tower")):
+            k = tower + ".projection."
+            embs.append(torch.relu(x[r] @ leaves[k + "0.weight"].T + leaves[k + "0.bias"]) @ leaves[k + "2.weight"].T + leaves[k + "2.bias"])
+        cos = torch.nn.functional.cosine_similarity
+        loss = torch.relu((1 - cos(embs[0], embs[1])) - (1 - cos(embs[0], embs[2])) + 0.3).mean()
+        loss.backward()
+        assert abs(last - loss.item()) <= TOL
+        for r in range(3):
+            close(eng.embeddings(B)[r], embs[r].detach().float())
+        ref_g = torch.cat([leaves[k].grad.reshape(-1) for k in orc.PARAM_KEYS]).float()
+        close(g, ref_g, rel_to_max=True)
+        sub = torch.arange(0, 3 * B, max(1, 3 * B // 40))[:40].cuda()
+        mask = (torch.arange(S, device="cuda").unsqueeze(0) < lens[sub].unsqueeze(1)).long()
+        close(pooled[sub], orc.gather_pool_normalize(table.cpu(), ids[sub].long().cpu(), mask.cpu()), atol=2e-6)
     eng.close()
 
 
@@ -740,13 +841,12 @@ def test_pool_forms_fuzz(tt):
         assert (a - b).abs().max().item() <= 1e-6, (case, D, S, V, N, kind)
 
 
-def test_pool_column_slices_random_shapes(tt, monkeypatch):
+def test_pool_column_slices_random_shapes(tt):
     """The column-sliced form over 40 seeded random shapes where it applies (D a multiple of 32 up to 1024, S up to
     512, vocabularies from a handful of rows up, few and many texts), every kind of weighting (prefix lengths incl.
     empty texts, masks with holes, integer weights, none), both index widths, out-of-range ids: against the oracle, against
     the per-text form (1e-6) and against itself (bitwise, twice)."""
     ops, _ = tt
-    monkeypatch.setenv("TT_K1_COLS", "1")
     gen = torch.Generator().manual_seed(2027)
     for case in range(40):
         D = 32 * int(torch.randint(1, 33, (1,), generator=gen))
@@ -776,8 +876,8 @@ def test_pool_column_slices_random_shapes(tt, monkeypatch):
         mt = torch.int32 if case % 3 else torch.int64
         kw = dict(attention_mask=None if mask is None else mask.to(mt).cuda(), lens=None if lens is None else lens.int().cuda())
         a = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=False, **kw)
-        b = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=True, **kw)
-        b2 = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=True, **kw)
+        b = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), form="columns", **kw)
+        b2 = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), form="columns", **kw)
         close(b, ref, atol=2e-6)
         assert (a - b).abs().max().item() <= 1e-6, (case, D, S, V, N, kind)
         assert torch.equal(b, b2), (case, D, S, V, N, kind)
@@ -829,20 +929,30 @@ def test_pool_stream_form_is_bitwise_the_per_text_form(tt):
         if N <= 700:
             close(b, orc.gather_pool_normalize(table, ids.clamp(0, V - 1), eff), atol=2e-6)
         ws = ops._scratch(torch.device("cuda", torch.cuda.current_device()), int(lib.tt_gather_pool_stream_workspace_bytes()))
-        adm, cus, mx = C.c_int32(), C.c_int32(), C.c_int32()
-        assert lib.tt_gather_pool_stream_census(ws.data_ptr(), C.byref(adm), C.byref(cus), C.byref(mx),
+        adm, cus, mx, plan = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        assert lib.tt_gather_pool_stream_census(ws.data_ptr(), C.byref(adm), C.byref(cus), C.byref(mx), C.byref(plan),
                                                 torch.cuda.current_stream().cuda_stream) == 0
         n_cu = torch.cuda.get_device_properties(0).multi_processor_count
-        assert 1 <= adm.value <= min(N, per_cu * n_cu) and 1 <= cus.value <= n_cu, (adm.value, cus.value, mx.value)
+        assert plan.value == min(N, per_cu * n_cu)
+        assert 1 <= adm.value <= plan.value and 1 <= cus.value <= n_cu, (adm.value, cus.value, mx.value)
         assert adm.value <= per_cu * cus.value
+        if N >= 2600:  # a queue much longer than the chip: alone on the chip the planned residency is reached
+            assert adm.value == plan.value and cus.value == n_cu, (adm.value, cus.value, mx.value, plan.value)
+
+
+def _census(lib, ws):
+    import ctypes as C
+
+    adm, cus, mx, plan = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.tt_gather_pool_stream_census(ws.data_ptr(), C.byref(adm), C.byref(cus), C.byref(mx), C.byref(plan),
+                                            torch.cuda.current_stream().cuda_stream) == 0
+    return adm.value, cus.value, mx.value, plan.value
 
 
 def test_pool_stream_registry_keys_are_compute_units(tt):
     """The registry key (XCC id + SE / SH / CU bits of HW_ID) names a physical compute unit: a launch of far more
     workgroups than the chip holds registers on exactly `multi_processor_count` distinct keys and admits exactly
     one workgroup on each of them with workgroups_per_cu = 1."""
-    import ctypes as C
-
     from two_towers_overlords_amd import _lib
 
     ops, _ = tt
@@ -853,12 +963,46 @@ def test_pool_stream_registry_keys_are_compute_units(tt):
     ids = torch.randint(0, V, (N, S), generator=gen, dtype=torch.int32).cuda()
     out = ops.gather_pool_norm(table, ids, stream_form=1)
     ws = ops._scratch(torch.device("cuda", torch.cuda.current_device()), int(lib.tt_gather_pool_stream_workspace_bytes()))
-    adm, cus, mx = C.c_int32(), C.c_int32(), C.c_int32()
-    assert lib.tt_gather_pool_stream_census(ws.data_ptr(), C.byref(adm), C.byref(cus), C.byref(mx),
-                                            torch.cuda.current_stream().cuda_stream) == 0
+    adm, cus, mx, plan = _census(lib, ws)
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
-    assert cus.value == n_cu and adm.value == n_cu, (adm.value, cus.value, mx.value, n_cu)
+    assert cus == n_cu and adm == n_cu and plan == n_cu, (adm, cus, mx, plan, n_cu)
     assert torch.equal(out, ops.gather_pool_norm(table, ids, sliced=False))
+
+
+def test_pool_stream_fills_the_chip_beside_a_projection_stream(tt):
+    """The streaming gather must end up with its PLANNED residency — workgroups_per_cu on every compute unit — also
+    when the chip is full of projection tiles at the moment it is launched (BASELINE.json configs[3]'s situation: round 3
+    offered twice the planned number of candidates, the dispatcher placed them all at once wherever there was room, and
+    a traced launch ended with 430 of 512 admitted on 232 of 256 CUs).  A second stream runs 128x128 projection GEMMs
+    back to back; the gather is launched into the middle of them, three times; every launch must admit
+    2 x multi_processor_count workgroups on multi_processor_count compute units, and the result stays bitwise."""
+    from two_towers_overlords_amd import _lib
+
+    ops, _ = tt
+    lib = _lib.load()
+    V, D, S, N, P, M = 20000, 768, 256, 24000, 768, 32768
+    gen = torch.Generator().manual_seed(6)
+    table = torch.randn(V, D, generator=gen).cuda()
+    ids = torch.randint(0, V, (N, S), generator=gen, dtype=torch.int32).cuda()
+    x = torch.randn(M, D, generator=gen).cuda()
+    w1, b1 = (torch.randn(P, D, generator=gen) / 28).cuda(), torch.zeros(P).cuda()
+    w2, b2 = (torch.randn(P, P, generator=gen) / 28).cuda(), torch.zeros(P).cuda()
+    ref = ops.gather_pool_norm(table, ids, sliced=False)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    side = torch.cuda.Stream()
+    tiles = {"proj_tile": 22, "proj_bk": 16, "xcd_order": 1}  # what the engine runs beside this gather
+    torch.cuda.synchronize()
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6):  # ~0.5 ms each: the gather below starts while these hold the chip
+                ops.proj_fwd(x, w1, b1, w2, b2, tuning=tiles)
+        torch.cuda._sleep(200_000 * (rep + 1))  # let the projection stream get going before the gather is enqueued
+        out = ops.gather_pool_norm(table, ids, stream_form=2)
+        ws = ops._scratch(torch.device("cuda", torch.cuda.current_device()), int(lib.tt_gather_pool_stream_workspace_bytes()))
+        adm, cus, mx, plan = _census(lib, ws)
+        side.synchronize()
+        assert plan == 2 * n_cu and adm == plan and cus == n_cu, (rep, adm, cus, mx, plan, n_cu)
+        assert torch.equal(out, ref)
 
 
 # --------------------------------------------------------------------------- K1 through a token store (f3)
@@ -869,24 +1013,24 @@ def test_pool_stream_registry_keys_are_compute_units(tt):
     (9000, 384, 64, 700, torch.int64, True),     # int64 store, sliced
     (9000, 100, 64, 700, torch.int64, True),     # D % 32 != 0: row slices by themselves
     (200, 6, 7, 9, torch.int32, False),          # D % 4 != 0: generic kernel
+    (5000, 768, 64, 300, torch.int32, "stream"),  # the streaming form reads the store through the same indirection
+    (5000, 384, 40, 1500, torch.int64, "stream"),  # ... more texts than the chip keeps workgroups, int64 store
 ])
-def test_engine_pool_rows_is_bitwise_pool_of_the_gathered_rows(tt, V, D, S, B, idt, sliced, monkeypatch):
+def test_engine_pool_rows_is_bitwise_pool_of_the_gathered_rows(tt, V, D, S, B, idt, sliced):
     """tt_engine_pool_rows (batch = rows of a resident token store) == tt_engine_pool on the rows
     gathered into a [roles,B,S] tensor, bit for bit, for roles 2 and 3, with and without lengths;
-    an out-of-range row is clamped and reported, never read."""
-    _, engine = tt
+    an out-of-range row is clamped and reported, never read.  The K1 form is this engine's tuning."""
+    ops, engine = tt
     from two_towers_overlords_amd import _lib
 
-    if sliced:
-        monkeypatch.setenv("TT_K1_SLICED", "1")
-    if sliced == "rows":
-        monkeypatch.setenv("TT_K1_COLS", "0")
+    form = {False: "per_text", True: "columns" if D % 32 == 0 else "rows", "rows": "rows", "stream": "stream"}[sliced]
     N = 3000
     gen = torch.Generator().manual_seed(17)
     table = (orc.synthetic_table(V, D, seed=1) * 30).cuda()
     store = torch.randint(0, V, (N, S), generator=gen).to(idt).cuda()
     lens = torch.randint(0, S + 1, (N,), generator=gen).int().cuda()   # includes empty rows (clamp 1e-9 path)
-    eng = engine.HotPathEngine(table, 16, B, S)
+    eng = engine.HotPathEngine(table, 16, B, S, k1_blocks_per_cu=(_lib.TT_K1_SHARE_AUTO if sliced == "stream" else 0),
+                               tuning={"k1_form": form})
     flat = torch.zeros(eng.n_params, device="cuda")
     eng.bind(flat, torch.zeros_like(flat), torch.zeros_like(flat))
     for roles in (3, 2):
@@ -897,6 +1041,14 @@ def test_engine_pool_rows_is_bitwise_pool_of_the_gathered_rows(tt, V, D, S, B, i
             eng.pool(1, store[rows.long()].contiguous(), None, None if ln is None else ln[rows.long()].contiguous())
             b = eng.pooled(1, B, roles).clone()
             assert torch.equal(a, b)
+            if sliced == "stream":  # ... and bitwise the per-text kernel on the materialised rows; the slot really streamed
+                fl = None if ln is None else ln[rows.long()].reshape(-1).contiguous()
+                ref = ops.gather_pool_norm(table, store[rows.long()].reshape(roles * B, S).contiguous(), lens=fl, sliced=False)
+                assert torch.equal(a.reshape(roles * B, D), ref)
+                adm, cus, _, plan = eng.k1_census(0)
+                assert 1 <= adm <= plan and cus >= 1
+            else:
+                assert eng.k1_census(0) == (0, 0, 0, 0)
     torch.cuda.synchronize()
     assert eng.read_stats()[1] == 0
     bad = rows.clone()

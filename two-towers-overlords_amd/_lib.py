@@ -19,7 +19,10 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 TT_I32, TT_I64 = 4, 8
 TT_BWD_AUTO, TT_BWD_FORK, TT_BWD_FUSED = 0, 1, 2
 TT_K1_SHARE_AUTO = -1  # tt_engine_config.k1_blocks_per_cu: pair the K1 form with the projection tile
-ABI_VERSION = 1
+TT_K1_AUTO, TT_K1_PER_TEXT, TT_K1_ROW_SLICES, TT_K1_COLUMN_SLICES, TT_K1_STREAM = 0, 1, 2, 3, 4
+K1_FORMS = {"auto": TT_K1_AUTO, "per_text": TT_K1_PER_TEXT, "rows": TT_K1_ROW_SLICES, "columns": TT_K1_COLUMN_SLICES,
+            "stream": TT_K1_STREAM}
+ABI_VERSION = 2
 
 _lib = None
 _lock = threading.Lock()
@@ -45,6 +48,52 @@ class TTEngineConfig(C.Structure):
     ]
 
 
+class TTTuning(C.Structure):
+    """tt_tuning (include/tt_hotpath.h): every field 0 = auto.  Speed only, never results."""
+
+    _fields_ = [
+        ("k1_form", C.c_int32),
+        ("k1_stream_wgs", C.c_int32),
+        ("k1_stream_rows", C.c_int32),
+        ("k1_stream_offer", C.c_int32),
+        ("k1_share_lds_kb", C.c_int32),
+        ("proj_tile", C.c_int32),
+        ("proj_bk", C.c_int32),
+        ("tn_tile", C.c_int32),
+        ("xcd_order", C.c_int32),
+        ("backward", C.c_int32),
+        ("k1_stream_linger", C.c_int32),
+        ("tn_transpose", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+TUNING_FIELDS = tuple(n for n, _ in TTTuning._fields_ if n != "reserved")
+
+
+def make_tuning(tuning=None):
+    """None | dict | TTTuning -> TTTuning or None.  Dict values may name a K1 form ("stream", "columns", ...) or a
+    backward schedule ("fork" / "fused"); unknown keys raise."""
+    if tuning is None or isinstance(tuning, TTTuning):
+        return tuning
+    t = TTTuning()
+    for k, v in dict(tuning).items():
+        if k not in TUNING_FIELDS:
+            raise KeyError(f"tt_tuning has no field {k!r}; fields: {', '.join(TUNING_FIELDS)}")
+        if k == "k1_form" and isinstance(v, str):
+            v = K1_FORMS[v]
+        if k == "backward" and isinstance(v, str):
+            v = {"auto": TT_BWD_AUTO, "fork": TT_BWD_FORK, "fused": TT_BWD_FUSED}[v]
+        setattr(t, k, int(v))
+    return t
+
+
+def tuning_ref(tuning):
+    t = make_tuning(tuning)
+    return None if t is None else C.byref(t)
+
+
+_tp = C.POINTER(TTTuning)
 _vp, _i, _i32, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/tt_hotpath.h one to one
@@ -55,17 +104,17 @@ SIGNATURES = {
     "tt_gather_pool_sliced_workspace_bytes": (_sz, [_i64, _i]),
     "tt_k1_prefers_sliced": (_i, [_i64, _i, _i64, _i]),
     "tt_k1_sliced_form": (_i, [_i64, _i, _i]),
-    "tt_gather_pool_norm_sliced_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _vp]),
+    "tt_gather_pool_norm_sliced_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _i, _vp]),
     "tt_gather_pool_stream_workspace_bytes": (_sz, []),
     "tt_k1_stream_supported": (_i, [_i, _vp, _vp]),
     "tt_k1_prefers_stream": (_i, [_i64, _i, _i64, _i]),
-    "tt_gather_pool_norm_stream_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _i, _vp]),
-    "tt_gather_pool_stream_census": (_i, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
+    "tt_gather_pool_norm_stream_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _i, _tp, _vp]),
+    "tt_gather_pool_stream_census": (_i, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "tt_pool_norm_dense_f32": (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _i, _vp]),
     "tt_embed_gather_f32": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i64, _vp, _vp]),
-    "tt_proj_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "tt_proj_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _tp, _vp]),
     "tt_proj_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
-    "tt_proj_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, _i, _vp]),
+    "tt_proj_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, _i, _tp, _vp]),
     "tt_triplet_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _f, _f, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_adam_f32": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i64, _d, _d, _d, _d, _i64, _f, _vp]),
     "tt_reduce_slabs_f32": (_i, [_vp, _i, _i64, _vp, _i64, _i, _vp]),
@@ -79,6 +128,8 @@ SIGNATURES = {
     "tt_engine_destroy": (_i, [_vp]),
     "tt_engine_set_sharing": (_i, [_vp, _i]),
     "tt_engine_set_backward": (_i, [_vp, _i]),
+    "tt_engine_set_tuning": (_i, [_vp, _tp]),
+    "tt_engine_get_tuning": (_i, [_vp, _tp]),
     "tt_engine_pool_rows": (_i, [_vp, _i, _vp, _i, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "tt_engine_param_count": (_i64, [_vp]),
     "tt_engine_grad_slabs": (_i, [_vp]),
@@ -91,7 +142,7 @@ SIGNATURES = {
     "tt_engine_dout": (_vp, [_vp]),
     "tt_engine_add_loss": (_i, [_vp, _vp, _vp]),
     "tt_engine_reduce_grads": (_i, [_vp, _vp, _i, _vp]),
-    "tt_engine_k1_census": (_i, [_vp, _i, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
+    "tt_engine_k1_census": (_i, [_vp, _i, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "tt_engine_reduce_grads_range": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "tt_engine_set_dw2_event": (_i, [_vp, _vp]),
     "tt_engine_adam": (_i, [_vp, _vp, _d, _d, _d, _d, _i64, _vp]),

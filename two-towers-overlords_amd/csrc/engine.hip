@@ -7,7 +7,6 @@
 //              the positive and negative calls of training.py:41-42 share one GEMM
 //              and their gradients accumulate inside it), K3, K2 bwd     -> grad slabs
 //   adam     : K4, folding the slab sum into the update
-#include <cstdlib>
 #include <new>
 #include "proj.h"
 
@@ -17,13 +16,13 @@ int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void*
                  unsigned lds_total, hipStream_t st, const int32_t* text_rows, int64_t n_store);
 int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st,
+                        void* workspace, size_t workspace_bytes, unsigned lds_total, int form, hipStream_t st,
                         const int32_t* text_rows, int64_t n_store);
 int tt_k1_sliced_supported(int S, int D, const float* table, const float* out);
 int tt_k1_stream_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                        void* workspace, size_t workspace_bytes, int per_cu, unsigned lds_total, hipStream_t st,
-                        const int32_t* text_rows, int64_t n_store);
+                        void* workspace, size_t workspace_bytes, int per_cu, const tt_tuning* tuning,
+                        unsigned lds_total, hipStream_t st, const int32_t* text_rows, int64_t n_store);
 int tt_launch_adam_auto(float* params, const float* grads, int nslabs, long long slab_stride, float* exp_avg,
                         float* exp_avg_sq, long long n, double lr, double beta1, double beta2, double eps,
                         long long* dev_step, float* dev_scal, hipStream_t st);
@@ -54,10 +53,10 @@ struct tt_engine {
   float* pooled[TT_ENGINE_SLOTS];
   float* k1_partial[TT_ENGINE_SLOTS];  // XCD-sliced K1: per-slice partial sums + mask sums of one batch
   size_t k1_partial_bytes;
-  void* k1_stream_ctl[TT_ENGINE_SLOTS];  // streaming K1 (HBM-resident tables): queue head + per-CU registry of one launch
-  bool k1_stream;                        // cfg says the streaming form applies (table far beyond the Infinity Cache)
-  int k1_stream_wgs;                     // gather workgroups kept per compute unit
-  unsigned k1_stream_lds;                // LDS a streaming gather workgroup occupies (0: its own 12 KB)
+  void* k1_stream_ctl[TT_ENGINE_SLOTS];  // streaming K1: queue head + per-CU registry of one launch (every engine has them: 16 KB each)
+  bool k1_streamed[TT_ENGINE_SLOTS];     // the last tt_engine_pool* into this slot used the streaming form
+  bool stream_beside;                    // the most recent tt_engine_pool* streamed: phase B pairs its tiles with that
+  tt_tuning tuning;                      // tt_engine_set_tuning (all zero: auto)
   // sharing with the gathers (cfg.k1_blocks_per_cu != 0), see gather_pool.hip "Sharing the chip"
   bool shared;           // gathers run beside phase B on another stream
   bool tile_above;       // sliced K1 reserved just above the 64x64 projection tile's LDS (else: capped K1, 128x64 tiles)
@@ -85,7 +84,6 @@ struct tt_engine {
   bool gathers_share_chip;  // tt_engine_set_sharing: token-id gathers are running beside phase B
   int bwd_mode;             // tt_engine_set_backward: TT_BWD_AUTO / TT_BWD_FORK / TT_BWD_FUSED
   hipEvent_t ev_dw2;        // tt_engine_set_dw2_event: recorded once the dW2 / db2 slabs are complete (may be null)
-  int env_bwd;              // TT_BWD read once at creation: -1 unset, 0 "fused", 1 "fork" (A/B runs)
 };
 
 namespace {
@@ -108,14 +106,14 @@ void carve(tt_engine* e, char* base, size_t* total) {
   Carver c{base};
   const size_t rows = 3 * (size_t)e->cfg.max_B;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->pooled[i] = c.take<float>(rows * e->cfg.D);
-  // partial sums of the XCD-sliced K1: only for tables the sliced form can win on (any N, S)
-  e->k1_partial_bytes = tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, (int64_t)1 << 40, 128)
-                            ? tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D) : 0;
+  // partial sums of the XCD-sliced K1: for tables the sliced form can win on (any N, S), or — so that a tuning can
+  // force that form on any table — whenever they are small (<= 64 MB per slot)
+  const size_t sliced_bytes = tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D);
+  e->k1_partial_bytes = (tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, (int64_t)1 << 40, 128) || sliced_bytes <= (64u << 20))
+                            ? sliced_bytes : 0;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i)
     e->k1_partial[i] = e->k1_partial_bytes ? c.take<float>(e->k1_partial_bytes / sizeof(float)) : nullptr;
-  e->k1_stream = tt_k1_prefers_stream(e->cfg.V, e->cfg.D, (int64_t)1 << 40, 512) != 0;
-  for (int i = 0; i < TT_ENGINE_SLOTS; ++i)
-    e->k1_stream_ctl[i] = e->k1_stream ? c.take<char>(tt_gather_pool_stream_workspace_bytes()) : nullptr;
+  for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->k1_stream_ctl[i] = c.take<char>(tt_gather_pool_stream_workspace_bytes());
   e->H = c.take<float>(rows * e->cfg.P);
   e->emb = c.take<float>(rows * e->cfg.P);
   e->dOut = c.take<float>(rows * e->cfg.P);
@@ -189,13 +187,6 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
     e->aux = nullptr;
   }
   e->gathers_share_chip = true;
-  e->env_bwd = -1;
-  if (const char* v = getenv("TT_BWD"))  // "fork" / "fused" force a schedule (A/B runs); anything else: automatic
-    if (v[0] == 'f') e->env_bwd = (v[1] == 'o') ? 1 : 0;
-  e->k1_stream_wgs = 2;  // two 4-wave workgroups x 6 rows x C KiB in flight per CU; leaves room for two 128x128 K-step-16 tiles
-  if (const char* v = getenv("TT_K1_STREAM_WGS")) e->k1_stream_wgs = atoi(v) >= 1 && atoi(v) <= 8 ? atoi(v) : 2;  // A/B
-  e->k1_stream_lds = 0;
-  if (const char* v = getenv("TT_K1_STREAM_LDS_KB")) e->k1_stream_lds = (unsigned)(atoi(v) > 0 && atoi(v) <= 160 ? atoi(v) : 0) * 1024u;
   e->shared = cfg->k1_blocks_per_cu != 0;
   e->tile_above = cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO && e->k1_partial_bytes != 0 &&
                   tt_k1_prefers_sliced(cfg->V, cfg->D, 3 * (int64_t)cfg->max_B, cfg->max_S);
@@ -231,6 +222,25 @@ extern "C" int tt_engine_set_backward(tt_engine* e, int mode) {
   return TT_OK;
 }
 
+extern "C" int tt_engine_set_tuning(tt_engine* e, const tt_tuning* tuning) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  const tt_tuning t = tuning ? *tuning : tt_tuning{};
+  TT_REQUIRE(t.k1_form >= TT_K1_AUTO && t.k1_form <= TT_K1_STREAM, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(t.k1_stream_wgs >= 0 && t.k1_stream_wgs <= 8 && t.k1_share_lds_kb >= -1 && t.k1_share_lds_kb <= 160, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(t.backward == TT_BWD_AUTO || t.backward == TT_BWD_FORK || t.backward == TT_BWD_FUSED, TT_ERR_BAD_SHAPE);
+  for (int r : t.reserved) TT_REQUIRE(r == 0, TT_ERR_BAD_SHAPE);
+  e->tuning = t;
+  if (t.backward != TT_BWD_AUTO) e->bwd_mode = t.backward;
+  return TT_OK;
+}
+
+extern "C" int tt_engine_get_tuning(const tt_engine* e, tt_tuning* out) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(out, TT_ERR_NULL_POINTER);
+  *out = e->tuning;
+  return TT_OK;
+}
+
 extern "C" int64_t tt_engine_param_count(const tt_engine* e) { return ok(e) ? e->nparam : -1; }
 extern "C" int tt_engine_grad_slabs(const tt_engine* e) { return ok(e) ? e->nslabs : -1; }
 extern "C" const float* tt_engine_pooled(const tt_engine* e, int slot) {
@@ -252,6 +262,16 @@ extern "C" int tt_engine_bind(tt_engine* e, const float* table, float* params, f
   return TT_OK;
 }
 
+// The projection plan phase B runs with: tiles that pair with how the gathers are reserved (gather_pool.hip "Sharing
+// the chip") + the handle's tuning.  Beside the streaming gather: 128x128 K-step-16 tiles in XCD order — chosen from
+// what the most recent tt_engine_pool* actually launched, not from the table alone (a short batch of a big table
+// does not stream).
+static ttp::Plan chain_plan(const tt_engine* e) {
+  int policy = !e->shared ? ttp::kTileAuto : (e->tile_above ? ttp::kTileSmall : ttp::kTileLowTraffic);
+  if (e->shared && e->stream_beside) policy = ttp::kTileStream;
+  return ttp::plan_of(&e->tuning, policy);
+}
+
 static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                      const int32_t* lens, int32_t roles, int32_t B, int32_t S, const int32_t* text_rows,
                      int64_t n_store, tt_stream_t stream) {
@@ -259,30 +279,53 @@ static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, con
   TT_REQUIRE(e->table, TT_ERR_NULL_POINTER);
   TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (roles == 2 || roles == 3), TT_ERR_BAD_SHAPE);
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B && S >= 1 && S <= e->cfg.max_S, TT_ERR_BAD_SHAPE);
+  const tt_tuning& tn = e->tuning;
+  const int64_t N = roles * (int64_t)B;
+  const bool auto_share = e->shared && e->cfg.k1_blocks_per_cu == TT_K1_SHARE_AUTO;
+  // which form: the tuning's, else the measured rule for the shape
+  int form = tn.k1_form;
+  if (form == TT_K1_STREAM && !tt_k1_stream_supported(e->cfg.D, e->table, e->pooled[slot])) form = TT_K1_AUTO;
+  if ((form == TT_K1_ROW_SLICES || form == TT_K1_COLUMN_SLICES) &&
+      !(e->k1_partial_bytes && tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]) &&
+        (form == TT_K1_ROW_SLICES || (e->cfg.D % 32 == 0 && e->cfg.D / 32 <= 32))))
+    form = TT_K1_AUTO;
+  if (form == TT_K1_AUTO) {
+    if (auto_share && tt_k1_prefers_stream(e->cfg.V, e->cfg.D, N, S) &&
+        tt_k1_stream_supported(e->cfg.D, e->table, e->pooled[slot]))
+      form = TT_K1_STREAM;  // beside the projection chain when the table really comes from HBM (gather_pool.hip)
+    else if (e->k1_partial_bytes && tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, N, S) &&
+             tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]))
+      form = tt_k1_sliced_form(e->cfg.V, e->cfg.D, S);  // table several times an XCD's L2 (tt_k1_prefers_sliced)
+    else
+      form = TT_K1_PER_TEXT;
+  }
+  e->k1_streamed[slot] = form == TT_K1_STREAM;
+  e->stream_beside = form == TT_K1_STREAM;
   // LDS a gather workgroup occupies while it shares the chip (0 = no reservation)
   unsigned lds_total = 0;
   if (e->shared)
-    lds_total = e->tile_above ? (unsigned)ttp::chain_lds_bytes(3 * (long long)e->cfg.max_B, e->cfg.P, ttp::kTileSmall) + 3072u
+    lds_total = e->tile_above ? (unsigned)ttp::chain_lds_bytes(3 * (long long)e->cfg.max_B, e->cfg.P,
+                                                               ttp::plan_of(&e->tuning, ttp::kTileSmall)) + 3072u
                               : tt_k1_lds_for_cap(e->cap);
-  static const int share_lds_kb = getenv("TT_K1_SHARE_LDS_KB") ? atoi(getenv("TT_K1_SHARE_LDS_KB")) : -1;  // A/B
-  if (e->shared && share_lds_kb >= 0 && share_lds_kb <= 160) lds_total = (unsigned)share_lds_kb * 1024u;
-  // streaming form beside the projection chain when the table really comes from HBM (gather_pool.hip)
-  if (e->k1_stream && e->shared && e->cfg.k1_blocks_per_cu == TT_K1_SHARE_AUTO &&
-      tt_k1_prefers_stream(e->cfg.V, e->cfg.D, roles * (int64_t)B, S) &&
-      tt_k1_stream_supported(e->cfg.D, e->table, e->pooled[slot]))
-    return tt_k1_stream_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B, S,
-                               e->cfg.D, e->cfg.V, e->oob, e->k1_stream_ctl[slot], tt_gather_pool_stream_workspace_bytes(),
-                               e->k1_stream_wgs, e->k1_stream_lds, static_cast<hipStream_t>(stream), text_rows, n_store);
-  // XCD-sliced form where it is the faster one (table several times an XCD's L2, see tt_k1_prefers_sliced)
-  if (e->k1_partial_bytes && tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, roles * (int64_t)B, S) &&
-      tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot])) {
-    if (e->shared && !e->tile_above && e->cfg.k1_blocks_per_cu == TT_K1_SHARE_AUTO) lds_total = tt_k1_lds_for_cap(3);
-    return tt_k1_sliced_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B,
-                               S, e->cfg.D, e->cfg.V, e->oob, e->k1_partial[slot], e->k1_partial_bytes, lds_total,
-                               static_cast<hipStream_t>(stream), text_rows, n_store);
+  if (e->shared && tn.k1_share_lds_kb > 0) lds_total = (unsigned)tn.k1_share_lds_kb * 1024u;
+  if (e->shared && tn.k1_share_lds_kb < 0) lds_total = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (form == TT_K1_STREAM) {
+    // two 4-wave workgroups x 6 rows x C KiB in flight per CU; leaves room for two 128x128 K-step-16 tiles.
+    // The streaming workgroups hold their own 12 KB; a reservation applies only when the tuning asks for one.
+    const int per_cu = tn.k1_stream_wgs > 0 ? tn.k1_stream_wgs : 2;
+    const unsigned lds = tn.k1_share_lds_kb > 0 ? lds_total : 0;
+    return tt_k1_stream_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], N, S, e->cfg.D, e->cfg.V,
+                               e->oob, e->k1_stream_ctl[slot], tt_gather_pool_stream_workspace_bytes(), per_cu, &e->tuning,
+                               lds, st, text_rows, n_store);
   }
-  return tt_k1_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], roles * (int64_t)B, S,
-                      e->cfg.D, e->cfg.V, e->oob, lds_total, static_cast<hipStream_t>(stream), text_rows, n_store);
+  if (form == TT_K1_ROW_SLICES || form == TT_K1_COLUMN_SLICES) {
+    if (e->shared && !e->tile_above && auto_share && tn.k1_share_lds_kb == 0) lds_total = tt_k1_lds_for_cap(3);
+    return tt_k1_sliced_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], N, S, e->cfg.D, e->cfg.V,
+                               e->oob, e->k1_partial[slot], e->k1_partial_bytes, lds_total, form, st, text_rows, n_store);
+  }
+  return tt_k1_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], N, S, e->cfg.D, e->cfg.V, e->oob,
+                      lds_total, st, text_rows, n_store);
 }
 
 extern "C" int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask,
@@ -346,14 +389,7 @@ static void fill_towers(tt_engine* e, int slot, int32_t B, int32_t doc_rows, ttp
 //          before the caller's next stream-ordered call.  Shortest critical path beside a CAPPED K1
 //          (explicit k1_blocks_per_cu, per-text form): 232 vs 248 us per step; there the in-launch loss
 //          mean also loses (its ticket round trip queues behind the gather's loads).
-// projection tiles that pair with how the gathers are reserved (gather_pool.hip "Sharing the chip")
-static int tile_policy(const tt_engine* e) {
-  if (e->shared && e->k1_stream && e->cfg.k1_blocks_per_cu == TT_K1_SHARE_AUTO) return ttp::kTileStream;
-  return !e->shared ? ttp::kTileAuto : (e->tile_above ? ttp::kTileSmall : ttp::kTileLowTraffic);
-}
-
 static bool use_fork(const tt_engine* e) {
-  if (e->env_bwd >= 0) return e->env_bwd == 1 && e->aux != nullptr;  // TT_BWD forces a schedule, also over calibrate()'s pick
   if (e->bwd_mode == TT_BWD_FORK) return e->aux != nullptr;
   if (e->bwd_mode == TT_BWD_FUSED) return false;
   return e->shared && !e->tile_above && e->aux != nullptr && e->gathers_share_chip;
@@ -362,7 +398,7 @@ static bool use_fork(const tt_engine* e) {
 static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_rows, float loss_denominator,
                           hipStream_t st) {
   const int D = e->cfg.D, P = e->cfg.P;
-  const int shared = tile_policy(e);
+  const ttp::Plan shared = chain_plan(e);
   int rc;
   if (!use_fork(e)) {
     if (loss_rows > 0) {
@@ -402,7 +438,7 @@ extern "C" int tt_engine_fwd_bwd(tt_engine* e, int slot, int32_t B, const int32_
   const int D = e->cfg.D, P = e->cfg.P;
   ttp::Tower t[2];
   fill_towers(e, slot, B, neg_index ? B : 2 * B, t);
-  int rc = ttp::forward(t, 2, D, P, st, tile_policy(e));
+  int rc = ttp::forward(t, 2, D, P, st, chain_plan(e));
   if (rc != TT_OK) return rc;
   const float* q = e->emb;
   const float* p = e->emb + (int64_t)B * P;
@@ -430,7 +466,7 @@ extern "C" int tt_engine_forward(tt_engine* e, int slot, int32_t B, int32_t role
   TT_REQUIRE(B >= 1 && B <= e->cfg.max_B, TT_ERR_BAD_SHAPE);
   ttp::Tower t[2];
   fill_towers(e, slot, B, (roles - 1) * B, t);
-  return ttp::forward(t, 2, e->cfg.D, e->cfg.P, static_cast<hipStream_t>(stream), tile_policy(e));
+  return ttp::forward(t, 2, e->cfg.D, e->cfg.P, static_cast<hipStream_t>(stream), chain_plan(e));
 }
 
 extern "C" int tt_engine_backward(tt_engine* e, int slot, int32_t B, int32_t roles, tt_stream_t stream) {
@@ -482,16 +518,17 @@ extern "C" int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event) {
 }
 
 extern "C" int tt_engine_k1_census(tt_engine* e, int slot, int32_t* admitted, int32_t* cus_used, int32_t* max_registered,
-                                   tt_stream_t stream) {
+                                   int32_t* planned, tt_stream_t stream) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
-  if (!e->k1_stream_ctl[slot]) {  // the streaming form is not in use for this table
+  if (!e->k1_streamed[slot]) {  // the last gather into this slot did not use the streaming form
     if (admitted) *admitted = 0;
     if (cus_used) *cus_used = 0;
     if (max_registered) *max_registered = 0;
+    if (planned) *planned = 0;
     return TT_OK;
   }
-  return tt_gather_pool_stream_census(e->k1_stream_ctl[slot], admitted, cus_used, max_registered, stream);
+  return tt_gather_pool_stream_census(e->k1_stream_ctl[slot], admitted, cus_used, max_registered, planned, stream);
 }
 
 extern "C" int tt_engine_adam(tt_engine* e, const float* grads, double lr, double beta1, double beta2,

@@ -15,7 +15,8 @@
 //
 // Row ids are wave-uniform (v_readlane from the lane that loaded them), so the
 // row base address is scalar and each load is `global_load_dwordx4 v, v_off, s[base]`.
-#include <cstdlib>
+#include <atomic>
+#include <new>
 #include "tt_common.h"
 
 namespace {
@@ -77,51 +78,14 @@ __device__ __forceinline__ void pool_group(unsigned long long& mine, const float
   }
 }
 
-// A/B variant (north_star wording: "rows into LDS tiles"): the K rows go global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: per-lane source address, wave-uniform LDS base + lane*16), are waited
-// for once, then read back and accumulated.  `tile` is this wave's [U][C*256]-float slab.
-typedef __attribute__((address_space(1))) const void* tt_gptr_t;
-typedef __attribute__((address_space(3))) void* tt_lptr_t;
-
-template <int K, int C>
-__device__ __forceinline__ void pool_group_lds(unsigned long long& mine, const float* __restrict__ src, int id_lane,
-                                               float w_lane, int D, int lane, bool last_ok, float4 (&acc)[C],
-                                               float* __restrict__ tile) {
-  float wk[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int pos = __builtin_ctzll(mine);
-    mine &= mine - 1;
-    wk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_lane), pos));
-    const long long row = (long long)__builtin_amdgcn_readlane(id_lane, pos);
-    const float* __restrict__ rp = src + row * (long long)D;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      if (c < C - 1 || last_ok)
-        __builtin_amdgcn_global_load_lds((tt_gptr_t)(rp + (c * TT_WAVE + lane) * 4),
-                                         (tt_lptr_t)(tile + (k * C + c) * 256), 16, 0, 0);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      if (c < C - 1 || last_ok) {
-        const float4 r = *reinterpret_cast<const float4*>(tile + (k * C + c) * 256 + lane * 4);
-        f4_fma(acc[c], wk[k], r);
-      }
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is overwritten by the next group's DMA
-}
-
-// One text by one 4-wave workgroup (see the file header).  `part` / `red` / `stage` are the workgroup's LDS.
+// One text by one 4-wave workgroup (see the file header).  `part` / `red` are the workgroup's LDS.
 // C = float4 chunks per lane = ceil(D/4/64); U = rows in flight per wave.
-// LDS_STAGE: the A/B variant above (token-id gathers only).
-template <typename IdT, typename MaskT, int C, int U, bool DENSE, bool LDS_STAGE>
+// (Register accumulation, not LDS-tile staging: the LDS-DMA form — 8 rows per wave by global_load_lds_dwordx4 into a
+// 16 KB slab, one vmcnt(0), read back and accumulate — was built and measured in round 1: bit-identical, 152.0 vs
+// 153.6 us on the 46.9 MB table, 243 vs 243 us per step, at 72 KB of LDS per workgroup; profiles/r01_k1_form_ab.txt.)
+template <typename IdT, typename MaskT, int C, int U, bool DENSE>
 __device__ __forceinline__ void pool_one_text(
-    long long text, float4 (*part)[C * TT_WAVE], float* red, float* stage,
+    long long text, float4 (*part)[C * TT_WAVE], float* red,
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, int S, int D, long long V,
     int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
@@ -163,13 +127,6 @@ __device__ __forceinline__ void pool_one_text(
     unsigned long long mine = live & (0x1111111111111111ULL << wave);
     int cnt = __popcll(mine);
     const long long drow0 = tbase + seg;
-    if (LDS_STAGE) {
-      float* __restrict__ tile = stage + wave * (U * C * 256);
-      while (cnt >= U) {
-        pool_group_lds<U, C>(mine, src, id, w, D, lane, last_ok, acc, tile);
-        cnt -= U;
-      }
-    }
     while (cnt >= U) {
       pool_group<U, C, DENSE>(mine, src, id, w, drow0, D, lane, last_ok, acc);
       cnt -= U;
@@ -227,16 +184,15 @@ __device__ __forceinline__ void pool_one_text(
   }
 }
 
-template <typename IdT, typename MaskT, int C, int U, bool DENSE, bool LDS_STAGE = false>
+template <typename IdT, typename MaskT, int C, int U, bool DENSE>
 __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, int S, int D, long long V,
     int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
   __shared__ float4 part[kWavesPerText][C * TT_WAVE];
   __shared__ float red[kWavesPerText];
-  __shared__ __attribute__((aligned(16))) float stage[LDS_STAGE ? kWavesPerText * U * C * 256 : 4];
-  pool_one_text<IdT, MaskT, C, U, DENSE, LDS_STAGE>(blockIdx.x, part, red, stage, src, ids, mask, lens, out, S, D, V,
-                                                    oob_flag, text_rows, n_store);
+  pool_one_text<IdT, MaskT, C, U, DENSE>(blockIdx.x, part, red, src, ids, mask, lens, out, S, D, V, oob_flag, text_rows,
+                                         n_store);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -249,17 +205,27 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
 // keeps them to a CU they then share one-for-one with a tile (K1 5.2 -> 6.8 ms) — 7.5 ms per step both ways.
 // Here residency is explicit instead:
 //   * persistent workgroups pull texts from a queue head (one relaxed atomic per 0.8 MB of rows);
-//   * a workgroup first registers on ITS compute unit (XCC id + SE/SH/CU bits of HW_ID -> a counter per CU); when
-//     `per_cu` workgroups are already registered there it leaves at once, so no CU ever hosts more gather waves
-//     than planned, whatever the dispatcher does, and the MFMA kernels keep the rest.
+//   * a candidate workgroup first registers on ITS compute unit (XCC id + SE/SH/CU bits of HW_ID -> a counter per
+//     CU); when `per_cu` candidates have registered there before it, it leaves at once, so no CU ever hosts more
+//     gather waves than planned, whatever the dispatcher does, and the MFMA kernels keep the rest;
+//   * candidates are offered far beyond the `target` = per_cu x CUs the chip may keep (round 4; round 3 offered
+//     2 x target, all of which the dispatcher placed within microseconds wherever there was room at that moment —
+//     a traced launch beside the chain ended with 430 of 512 admitted, 24 CUs without a gather workgroup and 20
+//     candidates on one CU).  The candidates the chip has no room for wait in the dispatcher's queue and are
+//     placed as room appears — on a CU where a projection tile has just finished — so a CU that was full of tiles
+//     when the launch started still gets its share.  A candidate costs one load when the target is reached or
+//     the queue is empty (it leaves without registering), one atomic otherwise.
 // Placement decides speed only: every text is pooled by exactly one workgroup, with the arithmetic of
-// pool_norm_kernel (same order => bitwise the same output).  No wave ever waits for another workgroup.
+// pool_norm_kernel (same order => bitwise the same output).  No wave ever waits for another workgroup: a
+// turned-away candidate may linger for a BOUNDED number of sleep instructions (tt_tuning.k1_stream_linger, default
+// none) and admitted workgroups leave when the queue runs dry.
 constexpr int kCuSlots = 4096;  // 4 bits of XCC id x 8 bits of SE / SH / CU id
 struct StreamCtl {
   int head;            // next text to hand out
-  int admitted;        // workgroups that registered successfully (diagnostic)
-  int pad[2];
-  int cu[kCuSlots];    // registered workgroups per compute unit
+  int admitted;        // workgroups that registered successfully
+  int target;          // workgroups the launch means to keep (diagnostic, written by workgroup 0)
+  int pad;
+  int cu[kCuSlots];    // candidates that registered per compute unit (admitted: the first per_cu of them)
 };
 
 __device__ __forceinline__ unsigned tt_cu_key() {
@@ -274,20 +240,25 @@ __global__ __launch_bounds__(kThreads) void pool_norm_stream_kernel(
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, long long N, int S, int D, long long V,
     int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store, StreamCtl* __restrict__ ctl,
-    int per_cu, int prio) {
+    int per_cu, int target, int linger) {
   __shared__ float4 part[kWavesPerText][C * TT_WAVE];
   __shared__ float red[kWavesPerText];
   __shared__ int s_next;
-  // A/B (TT_K1_STREAM_PRIO): the gather's waves issue a handful of vector-memory instructions per microsecond; at a
-  // raised wave priority they win the issue arbitration against the MFMA kernels' waves on their SIMD
-  if (prio == 1) __builtin_amdgcn_s_setprio(1);
-  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
   if (threadIdx.x == 0) {
     int next = -1;
-    if (atomicAdd(&ctl->cu[tt_cu_key()], 1) < per_cu) {
-      atomicAdd(&ctl->admitted, 1);
-      next = atomicAdd(&ctl->head, 1);
+    if (blockIdx.x == 0) ctl->target = target;
+    // relaxed agent-scope loads: a stale value only costs this candidate the registration it would have been refused
+    const bool open = __hip_atomic_load(&ctl->admitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
+                      __hip_atomic_load(&ctl->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < N;
+    if (open) {
+      if (atomicAdd(&ctl->cu[tt_cu_key()], 1) < per_cu) {
+        if (atomicAdd(&ctl->admitted, 1) < target) next = atomicAdd(&ctl->head, 1);
+      } else {
+        // this CU has its share.  Leaving at once hands the room straight to the next candidate, which the
+        // dispatcher is likely to place here again; lingering (bounded) spends fewer candidates per microsecond
+        // while some other CU is still short of its share.
+        for (int i = 0; i < linger; ++i) __builtin_amdgcn_s_sleep(32);  // 32 x 64 clocks ~ 1 us
+      }
     }
     s_next = next;
   }
@@ -296,8 +267,8 @@ __global__ __launch_bounds__(kThreads) void pool_norm_stream_kernel(
   while (text >= 0 && text < N) {
     // the next text's number travels through LDS; thread 0 asks for it now, everyone reads it after the two
     // barriers inside pool_one_text (so the write below cannot overtake this iteration's read above)
-    pool_one_text<IdT, MaskT, C, U, false, false>(text, part, red, nullptr, src, ids, mask, lens, out, S, D, V, oob_flag,
-                                                  text_rows, n_store);
+    pool_one_text<IdT, MaskT, C, U, false>(text, part, red, src, ids, mask, lens, out, S, D, V, oob_flag, text_rows,
+                                           n_store);
     if (threadIdx.x == 0) s_next = atomicAdd(&ctl->head, 1);
     __syncthreads();
     text = s_next;
@@ -311,9 +282,11 @@ __global__ __launch_bounds__(kThreads) void pool_norm_stream_kernel(
 // workgroup b gathers only the tokens whose id % NS == b % NS: every XCD then re-reads one 1/NS
 // slice of the table (5.9 MB at NS = 8) and most row reads hit its own L2.
 //
-// The grid is NS x G workgroups; wave w of workgroup (slice, g) takes texts g*4+w, +4G, +8G, ...  By
-// default G covers all texts (one text per wave); with fewer workgroups (TT_K1_SLICED_BPC, an A/B
-// knob) the same loop makes the grid persistent.  One (text, slice) step: the ids / mask of the NEXT
+// The grid is NS x G workgroups; wave w of workgroup (slice, g) takes texts g*4+w, +4G, +8G, ...; G covers
+// all texts (one text per wave).  (A persistent grid of n workgroups per CU walking the texts with the same loop
+// measured within 5 % alone and 4 % slower beside the projection kernels — 213-216 vs 205 us per step — and 6- or
+// 8-wave workgroups no better: round 1-2 records, profiles/r01_k1_form_ab.txt; removed in round 4.)
+// One (text, slice) step: the ids / mask of the NEXT
 // text, if any, are loaded into registers first (their latency hides under this text's rows), this
 // text's selected (id, weight) list — compacted into LDS one step earlier — is gathered U rows at a
 // time, the slice's partial sum [D] goes to a workspace, then the next text's list is compacted.
@@ -324,10 +297,8 @@ template <typename IdT, typename MaskT, int C, int U, int NS, int MAXSEG, int WP
 __global__ __launch_bounds__(WPB * TT_WAVE) void pool_sliced_kernel(
     const float* __restrict__ table, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ partial, float* __restrict__ wsum_out, long long N,
-    int S, int D, long long V, int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store, int prio) {
+    int S, int D, long long V, int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
   extern __shared__ int sliced_lds[];  // per wave: 2 x ([S] ids + [S] weights)
-  if (prio == 1) __builtin_amdgcn_s_setprio(1);  // A/B (TT_K1_PRIO): wave priority of the gather beside the MFMA kernels
-  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const int wave = threadIdx.x >> 6;
   static_assert(NS == 8, "one residue class per XCD");
@@ -523,9 +494,7 @@ __global__ __launch_bounds__(WPB * TT_WAVE) void pool_colsliced_kernel(
     const float* __restrict__ table, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, float* __restrict__ ssq, long long N, int S, int D,
     long long V, int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store, int NS,
-    long long units_per_class, int prio) {
-  if (prio == 1) __builtin_amdgcn_s_setprio(1);
-  else if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    long long units_per_class) {
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int cls = (int)(blockIdx.x & 7);
@@ -727,12 +696,6 @@ int launch_pool(const float* src, const void* ids, const void* mask, const int32
     return TT_OK;
   }
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
-  if (!DENSE && (D / 4 + TT_WAVE - 1) / TT_WAVE == 2 && getenv("TT_K1_LDS")) {  // A/B experiment, D in (256, 512]
-    hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, 2, 8, false, true>), grid, block, 0, st, src, ids_t, mask_t, lens,
-                       out, S, D, (long long)V, oob, text_rows, (long long)n_store);
-    TT_CHECK_LAUNCH();
-    return TT_OK;
-  }
 #define TT_POOL_CASE(CC, UU)                                                                      \
   hipLaunchKernelGGL((pool_norm_kernel<IdT, MaskT, CC, UU, DENSE>), grid, block,                    \
                      k1_dynamic_lds(lds_total, CC * 4096u + 16u), st, src, ids_t, mask_t, lens, out, S, D, \
@@ -764,15 +727,18 @@ int dispatch_pool(const float* src, const void* ids, int ids_dtype, const void* 
 constexpr int kSlices = 8;  // = XCDs per MI355X
 constexpr int kSlicedMaxS = 512;
 
+// Compute units of the CURRENT device.  Cached per device ordinal; the cache only ever goes from 0 to the device's
+// (immutable) count, so concurrent first calls agree.
 static int cu_count() {
-  static int n = 0;
+  constexpr int kMaxDev = 64;
+  static std::atomic<int> cache[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+  int n = cache[dev].load(std::memory_order_relaxed);
   if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n = v;
-    else
-      n = 256;
+    int v = 0;
+    n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    cache[dev].store(n, std::memory_order_relaxed);
   }
   return n;
 }
@@ -782,96 +748,65 @@ static int cu_count() {
 // the row reads hit) 81-84 vs 97 us; 50000: 94 vs 127; 65000: 109 vs 139; 100000 (12.8 MB per slice) 136 vs 159 — no
 // partial sums and no compaction, so it stays ahead when a slice no longer fits the L2.  D = 768, V = 30522: 158 vs 270.
 // Tables that stream from HBM (several times the Infinity Cache) keep whole-row reads: the streaming form.
-// TT_K1_COLS=0|1 (A/B; looked up per call like TT_K1_SLICED): off / on wherever the shape allows it.
+static bool colsliced_supported(int D, int S) {
+  return D % kColSliceFloats == 0 && D / kColSliceFloats <= 32 && S <= kSlicedMaxS;
+}
 static bool colsliced_applies(int64_t V, int D, int S) {
-  if (D % kColSliceFloats != 0 || D / kColSliceFloats > 32 || S > kSlicedMaxS) return false;
-  if (const char* v = getenv("TT_K1_COLS"))
-    if (*v) return *v != '0';
-  return (double)V * kColSliceFloats * 4.0 <= 13.0e6;
+  return colsliced_supported(D, S) && (double)V * kColSliceFloats * 4.0 <= 13.0e6;
 }
 
 template <typename IdT, typename MaskT>
 int launch_sliced(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
-                  int S, int D, int64_t V, int32_t* oob, float* ws, unsigned lds_total, hipStream_t st,
+                  int S, int D, int64_t V, int32_t* oob, float* ws, unsigned lds_total, int form, hipStream_t st,
                   const int32_t* text_rows, int64_t n_store) {
   const IdT* ids_t = static_cast<const IdT*>(ids);
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
-  if (colsliced_applies(V, D, S)) {
+  const bool columns = form == TT_K1_COLUMN_SLICES || (form == TT_K1_AUTO && colsliced_applies(V, D, S));
+  if (columns) {
     const int NS = D / kColSliceFloats;
     const long long upc = ((long long)NS * N + 7) / 8;  // units per XCD class
     // waves (= units) per workgroup: 8.  Beside the projection chain the gather's residency is a number of WORKGROUPS
     // per CU, so this sets its waves per CU: 3 x 8 there (register-bound) against 4 x 4 (LDS-bound) — 179 vs 200 us
-    // per configs[1] step; 6 / 12 / 16 waves: 194 / 190 / 201 us.  Alone 4 waves are 3 us faster (TT_K1_COL_WAVES=4, A/B).
-    static const int cwpb = getenv("TT_K1_COL_WAVES") && atoi(getenv("TT_K1_COL_WAVES")) == 4 ? 4 : 8;
-    const long long wgs = 8 * ((upc + cwpb - 1) / cwpb);
-    if (wgs <= 0x7fffffffLL) {
-      static const int k1_prio = getenv("TT_K1_PRIO") ? atoi(getenv("TT_K1_PRIO")) : 0;
-      float* ssq = ws;  // [N][NS]
-      const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
-#define TT_COL_LAUNCH_W(MS, WW)                                                                                    \
-  hipLaunchKernelGGL((pool_colsliced_kernel<IdT, MaskT, MS, WW>), dim3((unsigned)wgs), dim3(WW * TT_WAVE), lds_total, st, \
-                     table, ids_t, mask_t, lens, out, ssq, (long long)N, S, D, (long long)V, oob, text_rows,      \
-                     (long long)n_store, NS, upc, k1_prio)
-#define TT_COL_LAUNCH(MS)                 \
-  do {                                    \
-    if (cwpb == 4) TT_COL_LAUNCH_W(MS, 4); \
-    else TT_COL_LAUNCH_W(MS, 8);          \
-  } while (0)
-      if (nseg <= 1) TT_COL_LAUNCH(1);
-      else if (nseg <= 2) TT_COL_LAUNCH(2);
-      else if (nseg <= 4) TT_COL_LAUNCH(4);
-      else TT_COL_LAUNCH(8);
+    // per configs[1] step; 6 / 12 / 16 waves: 194 / 190 / 201 us.  (Alone 4-wave workgroups are 3 us faster.)
+    constexpr int kColWaves = 8;
+    const long long wgs = 8 * ((upc + kColWaves - 1) / kColWaves);
+    if (wgs > 0x7fffffffLL) return TT_ERR_BAD_SHAPE;
+    float* ssq = ws;  // [N][NS]
+    const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
+#define TT_COL_LAUNCH(MS)                                                                                              \
+  hipLaunchKernelGGL((pool_colsliced_kernel<IdT, MaskT, MS, kColWaves>), dim3((unsigned)wgs), dim3(kColWaves * TT_WAVE), \
+                     lds_total, st, table, ids_t, mask_t, lens, out, ssq, (long long)N, S, D, (long long)V, oob,        \
+                     text_rows, (long long)n_store, NS, upc)
+    if (nseg <= 1) TT_COL_LAUNCH(1);
+    else if (nseg <= 2) TT_COL_LAUNCH(2);
+    else if (nseg <= 4) TT_COL_LAUNCH(4);
+    else TT_COL_LAUNCH(8);
 #undef TT_COL_LAUNCH
-#undef TT_COL_LAUNCH_W
-      TT_CHECK_LAUNCH();
-      hipLaunchKernelGGL(pool_colnorm_kernel, dim3((unsigned)((N + kWavesPerText - 1) / kWavesPerText)), dim3(kThreads), 0,
-                         st, out, ssq, (long long)N, D, NS);
-      TT_CHECK_LAUNCH();
-      return TT_OK;
-    }
+    TT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pool_colnorm_kernel, dim3((unsigned)((N + kWavesPerText - 1) / kWavesPerText)), dim3(kThreads), 0,
+                       st, out, ssq, (long long)N, D, NS);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
   }
   float* partial = ws;
   float* wsum = ws + (size_t)N * kSlices * D;
-  // waves (= texts) per gather workgroup: TT_K1_WAVES=4|6|8 (A/B)
-  static const int wpb = [] {
-    const int v = getenv("TT_K1_WAVES") ? atoi(getenv("TT_K1_WAVES")) : kWavesPerText;
-    return (v == 4 || v == 6 || v == 8) ? v : kWavesPerText;  // only these are instantiated; anything else: the default
-  }();
-  const long long groups_all = (N + wpb - 1) / wpb;
-  const long long combine_groups = (N + kWavesPerText - 1) / kWavesPerText;
-  // Default: one workgroup per (4 texts, slice), residency steered through dynamic LDS like the per-text
-  // form.  TT_K1_SLICED_BPC=n (A/B) makes the grid persistent instead: n workgroups per CU walking the
-  // texts — within 5 % alone, 4 % slower beside the projection kernels (213-216 vs 205 us per step).
-  static const int persist_bpc = getenv("TT_K1_SLICED_BPC") ? atoi(getenv("TT_K1_SLICED_BPC")) : 0;
-  static const int k1_prio = getenv("TT_K1_PRIO") ? atoi(getenv("TT_K1_PRIO")) : 0;
-  long long G = groups_all;
-  unsigned lds = (unsigned)(4 * wpb * S * sizeof(int));
-  if (persist_bpc > 0) {
-    G = (long long)cu_count() * persist_bpc / 8;
-    if (G > groups_all) G = groups_all;
-    if (G < 1) G = 1;
-  } else {
-    if (lds_total > lds) lds = lds_total;
-  }
+  // one workgroup per (4 texts, slice); residency steered through dynamic LDS like the per-text form
+  const long long G = (N + kWavesPerText - 1) / kWavesPerText;
+  unsigned lds = (unsigned)(4 * kWavesPerText * S * sizeof(int));
+  if (lds_total > lds) lds = lds_total;
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
   const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
-#define TT_SLICED_LAUNCH_W(CC, UU, MS, WW)                                                                    \
-  hipLaunchKernelGGL((pool_sliced_kernel<IdT, MaskT, CC, UU, kSlices, MS, WW>), dim3((unsigned)(G * kSlices)), \
-                     dim3(WW * TT_WAVE), lds, st, table, ids_t, mask_t, lens, partial, wsum, (long long)N, S, D, \
-                     (long long)V, oob, text_rows, (long long)n_store, k1_prio)
-#define TT_SLICED_LAUNCH(CC, UU, MS)                       \
-  do {                                                     \
-    if (wpb == 6) TT_SLICED_LAUNCH_W(CC, UU, MS, 6);       \
-    else if (wpb == 8) TT_SLICED_LAUNCH_W(CC, UU, MS, 8);  \
-    else TT_SLICED_LAUNCH_W(CC, UU, MS, 4);                \
-  } while (0)
+#define TT_SLICED_LAUNCH(CC, UU, MS)                                                                            \
+  hipLaunchKernelGGL((pool_sliced_kernel<IdT, MaskT, CC, UU, kSlices, MS>), dim3((unsigned)(G * kSlices)),      \
+                     dim3(kThreads), lds, st, table, ids_t, mask_t, lens, partial, wsum, (long long)N, S, D,   \
+                     (long long)V, oob, text_rows, (long long)n_store)
 #define TT_SLICED_CASE(CC, UU)                  \
   do {                                          \
     if (nseg <= 2) TT_SLICED_LAUNCH(CC, UU, 2); \
     else if (nseg <= 4) TT_SLICED_LAUNCH(CC, UU, 4); \
     else TT_SLICED_LAUNCH(CC, UU, 8);           \
     TT_CHECK_LAUNCH();                          \
-    hipLaunchKernelGGL((pool_combine_kernel<CC, kSlices>), dim3((unsigned)combine_groups), dim3(kThreads), 0, st, \
+    hipLaunchKernelGGL((pool_combine_kernel<CC, kSlices>), dim3((unsigned)G), dim3(kThreads), 0, st, \
                        partial, wsum, out, (long long)N, D); \
   } while (0)
   switch (C) {
@@ -882,43 +817,42 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   }
 #undef TT_SLICED_CASE
 #undef TT_SLICED_LAUNCH
-#undef TT_SLICED_LAUNCH_W
   TT_CHECK_LAUNCH();
   return TT_OK;
 }
 
 template <typename IdT, typename MaskT>
 int launch_stream(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
-                  int S, int D, int64_t V, int32_t* oob, void* ctl_ws, int per_cu, unsigned lds_total, hipStream_t st,
-                  const int32_t* text_rows, int64_t n_store) {
+                  int S, int D, int64_t V, int32_t* oob, void* ctl_ws, int per_cu, int rows, int offer, int linger,
+                  unsigned lds_total, hipStream_t st, const int32_t* text_rows, int64_t n_store) {
   const IdT* ids_t = static_cast<const IdT*>(ids);
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
   StreamCtl* ctl = static_cast<StreamCtl*>(ctl_ws);
   TT_HIP(hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
-  // twice the workgroups the chip may keep: those that find their CU full leave at once
-  long long wgs = 2LL * per_cu * cu_count();
-  if (wgs > N) wgs = N;
+  long long target = (long long)per_cu * cu_count();  // workgroups the chip may keep
+  if (target > N) target = N;
+  // candidates: `offer` per kept workgroup (see the kernel's header); never fewer than the target itself
+  if (offer <= 0) offer = 16;
+  if (offer > 256) offer = 256;
+  const long long wgs = target * offer;
+  if (linger < 0) linger = 0;
+  if (linger > 64) linger = 64;
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
-  // rows in flight per wave: TT_K1_STREAM_U (A/B) or 96 KB per workgroup (4 waves x U rows x C KiB)
-  static const int env_u = getenv("TT_K1_STREAM_U") ? atoi(getenv("TT_K1_STREAM_U")) : 0;
-  static const int prio = getenv("TT_K1_STREAM_PRIO") ? atoi(getenv("TT_K1_STREAM_PRIO")) : 0;
+  // rows in flight per wave: ~96 KB per workgroup (4 waves x U rows x C KiB) unless the caller says otherwise
 #define TT_STREAM_CASE(CC, UU)                                                                               \
   hipLaunchKernelGGL((pool_norm_stream_kernel<IdT, MaskT, CC, UU>), dim3((unsigned)wgs), dim3(kThreads),     \
                      k1_dynamic_lds(lds_total, CC * 4096u + 32u), st, table, ids_t, mask_t, lens, out,       \
-                     (long long)N, S, D, (long long)V, oob, text_rows, (long long)n_store, ctl, per_cu, prio)
+                     (long long)N, S, D, (long long)V, oob, text_rows, (long long)n_store, ctl, per_cu,      \
+                     (int)target, linger)
   switch (C) {
-    case 1: if (env_u == 8) TT_STREAM_CASE(1, 8); else TT_STREAM_CASE(1, 16); break;
-    case 2: if (env_u == 8) TT_STREAM_CASE(2, 8); else TT_STREAM_CASE(2, 12); break;
+    case 1: TT_STREAM_CASE(1, 16); break;
+    case 2: TT_STREAM_CASE(2, 12); break;
     case 3:  // D in (512, 768]: U rows x 3 KiB in flight per wave
-      if (env_u == 4) TT_STREAM_CASE(3, 4);
-      else if (env_u == 5) TT_STREAM_CASE(3, 5);
-      else if (env_u == 7) TT_STREAM_CASE(3, 7);
-      else if (env_u == 8) TT_STREAM_CASE(3, 8);
-      else if (env_u == 10) TT_STREAM_CASE(3, 10);
-      else if (env_u == 12) TT_STREAM_CASE(3, 12);
+      if (rows == 4) TT_STREAM_CASE(3, 4);
+      else if (rows == 8) TT_STREAM_CASE(3, 8);
       else TT_STREAM_CASE(3, 6);
       break;
-    default: if (env_u == 4) TT_STREAM_CASE(4, 4); else TT_STREAM_CASE(4, 5); break;
+    default: TT_STREAM_CASE(4, 5); break;
   }
 #undef TT_STREAM_CASE
   TT_CHECK_LAUNCH();
@@ -983,7 +917,9 @@ extern "C" int tt_embed_gather_f32(const float* table, const void* ids, int ids_
   return TT_OK;
 }
 
-extern "C" int tt_k1_sliced_form(int64_t V, int D, int S) { return colsliced_applies(V, D, S) ? 1 : 0; }
+extern "C" int tt_k1_sliced_form(int64_t V, int D, int S) {
+  return colsliced_applies(V, D, S) ? TT_K1_COLUMN_SLICES : TT_K1_ROW_SLICES;
+}
 
 extern "C" size_t tt_gather_pool_sliced_workspace_bytes(int64_t N, int D) {
   if (N <= 0 || D <= 0) return 0;
@@ -999,11 +935,10 @@ int tt_k1_sliced_supported(int S, int D, const float* table, const float* out) {
 // table is well beyond one XCD's 4 MiB L2 but a slice still mostly fits (15 MB table: 121 -> 77 us,
 // 47 MB: 153 -> 96 us; 7.7 MB and 184 MB: equal; 3 MB: 55 vs 83 us), the texts are long enough to
 // leave each slice a few rows (S = 32: 41 vs 55 us) and there are enough of them to amortise the
-// second launch (512 texts: equal).  TT_K1_SLICED=0/1 overrides (A/B runs).
+// second launch (512 texts: equal).  A pure function of the shape; callers that want another form say so
+// (tt_tuning.k1_form, the `form` argument of tt_gather_pool_norm_sliced_f32).
 extern "C" int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S) {
   if (D < 4 || (D % 4) != 0 || D > 1024 || S > kSlicedMaxS || S < 1 || V < 1 || N < 1) return 0;
-  if (const char* v = getenv("TT_K1_SLICED"))  // (looked up per call: tests and tools/k1_sliced_ab.py flip it in-process)
-    if (*v) return *v != '0';
   const double table_bytes = (double)V * D * 4.0;
   // (column slices keep their lead up to tables that still fit the 256 MiB Infinity Cache: 154 MB at D = 384: 136 vs 166 us)
   const double upper = colsliced_applies(V, D, S) ? 200e6 : 128e6;
@@ -1013,10 +948,12 @@ extern "C" int tt_k1_prefers_sliced(int64_t V, int D, int64_t N, int S) {
 // internal (engine.hip): sliced K1 with an LDS reservation (0 = none)
 int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st,
+                        void* workspace, size_t workspace_bytes, unsigned lds_total, int form, hipStream_t st,
                         const int32_t* text_rows, int64_t n_store) {
   TT_REQUIRE(table && ids && out && workspace, TT_ERR_NULL_POINTER);
   TT_REQUIRE(!text_rows || n_store >= 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(form == TT_K1_AUTO || form == TT_K1_ROW_SLICES || form == TT_K1_COLUMN_SLICES, TT_ERR_UNSUPPORTED);
+  TT_REQUIRE(form != TT_K1_COLUMN_SLICES || colsliced_supported(D, S), TT_ERR_UNSUPPORTED);
   TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x0fffffffLL, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
@@ -1025,18 +962,18 @@ int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, cons
   if (N == 0) return TT_OK;
   float* ws = static_cast<float*>(workspace);
   const int md = mask ? mask_dtype : TT_I32;
-  if (ids_dtype == TT_I32 && md == TT_I32) return launch_sliced<int32_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st, text_rows, n_store);
-  if (ids_dtype == TT_I32 && md == TT_I64) return launch_sliced<int32_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st, text_rows, n_store);
-  if (ids_dtype == TT_I64 && md == TT_I32) return launch_sliced<int64_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st, text_rows, n_store);
-  return launch_sliced<int64_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st, text_rows, n_store);
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_sliced<int32_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, form, st, text_rows, n_store);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_sliced<int32_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, form, st, text_rows, n_store);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_sliced<int64_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, form, st, text_rows, n_store);
+  return launch_sliced<int64_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, form, st, text_rows, n_store);
 }
 
 extern "C" int tt_gather_pool_norm_sliced_f32(const float* table, const void* ids, int ids_dtype, const void* mask,
                                               int mask_dtype, const int32_t* lens, float* out, int64_t N, int S, int D,
                                               int64_t V, int32_t* oob_flag, void* workspace, size_t workspace_bytes,
-                                              tt_stream_t stream) {
+                                              int form, tt_stream_t stream) {
   return tt_k1_sliced_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, workspace,
-                             workspace_bytes, 0, static_cast<hipStream_t>(stream), nullptr, 0);
+                             workspace_bytes, 0, form, static_cast<hipStream_t>(stream), nullptr, 0);
 }
 
 extern "C" size_t tt_gather_pool_stream_workspace_bytes(void) { return sizeof(StreamCtl); }
@@ -1046,18 +983,17 @@ extern "C" int tt_k1_stream_supported(int D, const float* table, const float* ou
 }
 
 // The streaming form pays where the gather is HBM-bound: a table several times the 256 MiB Infinity Cache.
+// A pure function of the shape (tt_tuning.k1_form = TT_K1_STREAM forces it).
 extern "C" int tt_k1_prefers_stream(int64_t V, int D, int64_t N, int S) {
   if (D < 4 || (D % 4) != 0 || D > 1024 || S < 1 || V < 1 || N < 1) return 0;
-  if (const char* v = getenv("TT_K1_STREAM"))  // A/B override
-    if (*v) return *v != '0';
   return (double)V * D * 4.0 >= 400e6 && (double)N * S >= 1048576.0;
 }
 
 // internal (engine.hip) + public: the streaming form.  Same contract as tt_gather_pool_norm_f32.
 int tt_k1_stream_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
-                        void* workspace, size_t workspace_bytes, int per_cu, unsigned lds_total, hipStream_t st,
-                        const int32_t* text_rows, int64_t n_store) {
+                        void* workspace, size_t workspace_bytes, int per_cu, const tt_tuning* tuning,
+                        unsigned lds_total, hipStream_t st, const int32_t* text_rows, int64_t n_store) {
   TT_REQUIRE(table && ids && out && workspace, TT_ERR_NULL_POINTER);
   TT_REQUIRE(!text_rows || n_store >= 1, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x3fffffffLL, TT_ERR_BAD_SHAPE);
@@ -1068,35 +1004,47 @@ int tt_k1_stream_launch(const float* table, const void* ids, int ids_dtype, cons
   TT_REQUIRE(workspace_bytes >= sizeof(StreamCtl), TT_ERR_WORKSPACE);
   if (N == 0) return TT_OK;
   const int md = mask ? mask_dtype : TT_I32;
-  if (ids_dtype == TT_I32 && md == TT_I32) return launch_stream<int32_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, lds_total, st, text_rows, n_store);
-  if (ids_dtype == TT_I32 && md == TT_I64) return launch_stream<int32_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, lds_total, st, text_rows, n_store);
-  if (ids_dtype == TT_I64 && md == TT_I32) return launch_stream<int64_t, int32_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, lds_total, st, text_rows, n_store);
-  return launch_stream<int64_t, int64_t>(table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, lds_total, st, text_rows, n_store);
+  const int rows = tuning ? tuning->k1_stream_rows : 0, offer = tuning ? tuning->k1_stream_offer : 0;
+  const int linger = tuning ? tuning->k1_stream_linger : 0;
+#define TT_STREAM_ARGS table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, rows, offer, linger, lds_total, st, text_rows, n_store
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_stream<int32_t, int32_t>(TT_STREAM_ARGS);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_stream<int32_t, int64_t>(TT_STREAM_ARGS);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_stream<int64_t, int32_t>(TT_STREAM_ARGS);
+  return launch_stream<int64_t, int64_t>(TT_STREAM_ARGS);
+#undef TT_STREAM_ARGS
 }
 
 extern "C" int tt_gather_pool_norm_stream_f32(const float* table, const void* ids, int ids_dtype, const void* mask,
                                               int mask_dtype, const int32_t* lens, float* out, int64_t N, int S, int D,
                                               int64_t V, int32_t* oob_flag, void* workspace, size_t workspace_bytes,
-                                              int workgroups_per_cu, tt_stream_t stream) {
+                                              int workgroups_per_cu, const tt_tuning* tuning, tt_stream_t stream) {
   return tt_k1_stream_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, workspace,
-                             workspace_bytes, workgroups_per_cu, 0, static_cast<hipStream_t>(stream), nullptr, 0);
+                             workspace_bytes, workgroups_per_cu, tuning, 0, static_cast<hipStream_t>(stream), nullptr, 0);
 }
 
 // Diagnostic: what the last streaming launch that used `workspace` did — workgroups admitted, compute units that
-// hosted at least one, the largest count registered on one CU (admitted + turned away).  Synchronises `stream`.
+// hosted at least one, the largest number of candidates that registered on one CU (admitted + turned away) and the
+// number the launch meant to keep.  Synchronises `stream`.
 extern "C" int tt_gather_pool_stream_census(const void* workspace, int32_t* admitted, int32_t* cus_used,
-                                            int32_t* max_registered, tt_stream_t stream) {
+                                            int32_t* max_registered, int32_t* planned, tt_stream_t stream) {
   TT_REQUIRE(workspace, TT_ERR_NULL_POINTER);
-  static StreamCtl host;  // 16 KB: not on the stack
-  TT_HIP(hipMemcpyAsync(&host, workspace, sizeof(StreamCtl), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
-  TT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  StreamCtl* host = new (std::nothrow) StreamCtl;  // 16 KB: neither on the stack nor shared between callers
+  TT_REQUIRE(host, TT_ERR_WORKSPACE);
+  hipError_t err = hipMemcpyAsync(host, workspace, sizeof(StreamCtl), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+  if (err == hipSuccess) err = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+  if (err != hipSuccess) {
+    delete host;
+    return (int)err;
+  }
   int used = 0, mx = 0;
   for (int i = 0; i < kCuSlots; ++i) {
-    used += host.cu[i] > 0;
-    mx = host.cu[i] > mx ? host.cu[i] : mx;
+    used += host->cu[i] > 0;
+    mx = host->cu[i] > mx ? host->cu[i] : mx;
   }
-  if (admitted) *admitted = host.admitted;
+  if (admitted) *admitted = host->admitted < host->target ? host->admitted : host->target;
   if (cus_used) *cus_used = used;
   if (max_registered) *max_registered = mx;
+  if (planned) *planned = host->target;
+  delete host;
   return TT_OK;
 }

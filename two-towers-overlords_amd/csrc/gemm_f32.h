@@ -56,31 +56,24 @@ struct Batch {
   // only): tiles that re-read the same operand block run on ONE XCD, back to back, so the block crosses the fabric
   // once instead of once per tile.  kNT / kNN: the n-tiles of a row panel; kTN: all tiles of one split-K slab.
   // Worth it where the fabric is the shared bottleneck (beside the streaming gather); 0 = plain 3-D grid.
-  int wave_prio;   // A/B (TT_GEMM_PRIO): s_setprio of the kernel's waves (0 = leave it)
   HingeEpi hinge;  // kHinge only
   int xcd_order;
+  // kTN only: stage both (K-strided) operands through a register transpose into K-contiguous LDS images, so that a
+  // fragment is one ds_read_b128 instead of four ds_read_b32 (same products in the same order: bitwise the same C;
+  // the bias-gradient column sums are added in another order)
+  int tn_transpose;
   int gx, gy, gz;         // tile grid (filled by the launcher when xcd_order is set)
 };
 
-// TT_BF3 (read once): 0 exact-fp32 MFMA (default); 1..3 the split-bf16 experiment (gemm_f32.hip).
-int bf3_mode();
-
 // Static LDS of one workgroup of the (layout, wm, wn) kernel the launcher would pick, in bytes.
-size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk = 32);
+size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk = 32, bool tn_transpose = false);
 
 // Launches one grouped GEMM.  wm/wn pick the block tile: (64*wm) x (64*wn).
-// bk: K-step, 32 or 16 (16 only changes the 128x128 kNT / kNN tiles: 40 KB of LDS instead of 72).
+// bk: K-step, 32 or 16 (16 only changes the 128x128 tiles: 40 KB of LDS instead of 72).
 int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st, int bk = 32);
 
 // One launch for an independent (kTN split-K, kStore) + (kNN, kReluMask) pair; falls back to two
 // launches for shapes the vector path does not cover.
 int launch_tn_nn_pair(const Batch& tn, const Batch& nn, int wm, int wn, hipStream_t st);
-
-// 96x96 tiles on v_mfma_f32_16x16x4_f32 (gemm16.hip): kNT with kBias / kBiasRelu and kNN with kReluMask, no split-K.
-// For output shapes that 64x64 tiles cut badly — [6144 x 384] is 576 tiles of 64x64 (2.25 per CU) but exactly 256
-// of 96x96.  Same numerics (k-ordered fp32 fmaf chains).
-bool gemm16_supported(Layout layout, Epilogue epi, const Batch& b);
-size_t gemm16_lds_bytes();
-int launch16(Layout layout, Epilogue epi, const Batch& b, hipStream_t st);
 
 }  // namespace ttg

@@ -14,13 +14,14 @@
 // the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots); a
 // K-strided operand ([K][cols] in memory: W2 in NN, dOut/H/X in TN) sits in a
 // [32][cols] image and is read with conflict-free ds_read_b32 (lanes =
-// consecutive columns).
+// consecutive columns).  kTN (both operands K-strided: the weight gradients) may instead transpose on the way in
+// (TNT: a thread loads four consecutive k of ONE column with dword loads, coalesced across lanes, and writes them
+// as one 16-byte chunk of a K-contiguous [cols][32+4] image), so that its fragments are one ds_read_b128 as well.
 //
 // Numerics: each C element is a k-ordered fmaf chain in fp32 (what the MFMA
 // computes, bitwise), K-steps in ascending order; split-K (kTN) partials go to
 // separate slabs that are summed in fixed order later => run-to-run bitwise
 // reproducible, no float atomics.
-#include <cstdlib>
 #include <type_traits>
 #include "gemm_f32.h"
 
@@ -132,76 +133,16 @@ __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, 
   return make_float4(p[0], p[R], p[2 * R], p[3 * R]);
 }
 
-// ---- split-bf16 products (PREC = 1; TT_BF3=1, an opt-in experiment, never the default) -------------------------------
-// An fp32 value x is split exactly into three bf16 terms, x = hi + mid + lo (hi = bf16(x), mid = bf16(x - hi),
-// lo = bf16(x - hi - mid): each remainder is exact in fp32, the 24-bit significand is three 8-bit pieces), and a product
-// a * b is taken as the six bf16 products whose weight is >= 2^-16 of it: hi*hi + hi*mid + mid*hi + hi*lo + mid*mid + lo*hi
-// (bf16 x bf16 is exact in the MFMA's fp32 accumulator; the three dropped terms are <= 2^-23 |a b|, one fp32 ulp).
-// v_mfma_f32_32x32x16_bf16 runs 16x the FLOP per cycle of the fp32 MFMA, so six of them cost 3/8 of the cycles.  Operands
-// stay fp32 in memory and in LDS (same staging, same images); the split happens on the fragments, in registers.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-// Staged bf16 planes (PREC = 2, see TileCfg): a plane holds [R rows or columns][16 k] bf16 = 32 bytes per row, no padding.
-//  * K-contiguous operand (written 16 rows x 32 bytes per wave store): row r at 32 r, its two 16-byte halves (k 0..7 /
-//    k 8..15) swapped when (r >> 3) & 1 — so the 16 lanes of a ds_read_b128 group (rows r0..r0+15, same half) hit 16
-//    distinct 16-byte slots of the 256-byte bank row;
-//  * K-strided operand (written one k-quad of 64 consecutive columns per wave store): quad-major, [4 quads][R][8 bytes],
-//    so both the 8-byte stores and the two 8-byte reads of a fragment (quads 2h, 2h + 1) are contiguous across lanes.
-constexpr int kPlaneRowBytes = 32;
-__device__ __forceinline__ int plane_kc_half(int row, int half) { return (half ^ ((row >> 3) & 1)) << 4; }
-
-// four consecutive-k values of one row -> their hi / mid / lo bf16 quadruples (8 bytes each)
-__device__ __forceinline__ void split_bf3_quad(const float4& v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const __bf16 a = (__bf16)x[j];
-    const float r1 = x[j] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
-    hi[j] = a;
-    mid[j] = b;
-    lo[j] = (__bf16)r2;
-  }
-}
-// stage an [R][16] tile as three bf16 planes.  KC: the registers came from gload_kc (chunk f = row * 4 + q); otherwise
-// from gload_kt (chunk f = q * R + row).
-template <int R, bool KC>
-__device__ __forceinline__ void sstore_planes(const float4 (&v)[R * 16 / 4 / kThreads], float* __restrict__ T, int tid) {
-  char* __restrict__ base = reinterpret_cast<char*>(T);
-#pragma unroll
-  for (int i = 0; i < R * 16 / 4 / kThreads; ++i) {
-    const int f = tid + i * kThreads;
-    const int row = KC ? f >> 2 : f % R, kq = KC ? f & 3 : f / R;
-    bf16x4 hi, mid, lo;
-    split_bf3_quad(v[i], hi, mid, lo);
-    const int at = KC ? row * kPlaneRowBytes + plane_kc_half(row, kq >> 1) + 8 * (kq & 1) : (kq * R + row) * 8;
-    *reinterpret_cast<bf16x4*>(base + 0 * R * kPlaneRowBytes + at) = hi;
-    *reinterpret_cast<bf16x4*>(base + 1 * R * kPlaneRowBytes + at) = mid;
-    *reinterpret_cast<bf16x4*>(base + 2 * R * kPlaneRowBytes + at) = lo;
-  }
-}
-// one lane's fragment (its row, k = 8 h + 0..7) of plane p
-template <int R, bool KC>
-__device__ __forceinline__ bf16x8 frag_plane(const char* __restrict__ base, int p, int row, int h) {
-  if constexpr (KC) {
-    return *reinterpret_cast<const bf16x8*>(base + (p * R + row) * kPlaneRowBytes + plane_kc_half(row, h));
-  } else {
-    const bf16x4 a = *reinterpret_cast<const bf16x4*>(base + p * R * kPlaneRowBytes + ((2 * h) * R + row) * 8);
-    const bf16x4 b = *reinterpret_cast<const bf16x4*>(base + p * R * kPlaneRowBytes + ((2 * h + 1) * R + row) * 8);
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-  }
-}
-// K-strided operand for the staged planes: tile [16][R cols], element (k, col) at P[(k0+k)*ld + r0+col].  A thread takes
-// FOUR CONSECUTIVE k of ONE column (dword loads, coalesced across lanes = consecutive columns), i.e. the transposition
-// happens in the register file and the planes are written exactly as for a K-contiguous operand.  A thread's column is
-// tid % R in every chunk (kThreads % R == 0), which the kTN column sums rely on.
-template <int R, bool FULL>
-__device__ __forceinline__ void gload_kt(float4 (&v)[R * 16 / 4 / kThreads], const float* __restrict__ P,
+// K-strided operand, transposed in the register file (kTN with TNT): tile [BK][R cols], element (k, col) at
+// P[(k0+k)*ld + r0+col].  A thread takes FOUR CONSECUTIVE k of ONE column (dword loads, coalesced across lanes =
+// consecutive columns); the chunk is then stored like a K-contiguous operand's (sstore_kt -> [R][BK+4] image).
+// A thread's column is tid % R in every chunk (kThreads % R == 0), which the kTN column sums rely on.
+template <int R, int BK, bool FULL>
+__device__ __forceinline__ void gload_kt(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
                                          int ld, int r0, int rmax, int k0, int kend, int tid) {
   static_assert(kThreads % R == 0, "one column per thread");
 #pragma unroll
-  for (int i = 0; i < R * 16 / 4 / kThreads; ++i) {
+  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
     const int f = tid + i * kThreads;
     const int col = f % R, kq = f / R;
     const int gr = r0 + col, gk = k0 + 4 * kq;
@@ -221,32 +162,27 @@ __device__ __forceinline__ void gload_kt(float4 (&v)[R * 16 / 4 / kThreads], con
     }
   }
 }
-
-__device__ __forceinline__ void split_bf3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+template <int R, int BK>
+__device__ __forceinline__ void sstore_kt(const float4 (&v)[R * BK / 4 / kThreads], float* __restrict__ T, int tid) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 a = (__bf16)x[j];
-    const float r1 = x[j] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
-    hi[j] = a;
-    mid[j] = b;
-    lo[j] = (__bf16)r2;
+  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
+    const int col = f % R, kq = f / R;
+    // lanes = consecutive columns, 36- (or 20-) word rows: the 8 lanes of a 128-byte ds_write_b128 phase start
+    // 4 banks apart, so the write is conflict-free like the reads
+    *reinterpret_cast<float4*>(T + col * (BK + 4) + kq * 4) = v[i];
   }
 }
 
-// PREC = 2 (K-step 16 only): the split is done ONCE per workgroup when a tile is staged — three bf16 planes (hi, mid,
-// lo) per operand in LDS, 32 bytes per row and plane (layouts above: 48 KB for a 128x128 tile's two buffers, 24 KB for
-// 64x64) — so a fragment is three 16-byte LDS reads and no arithmetic, whatever the operand's layout in memory
-// (K-strided operands are transposed on their way in, gload_kt).
-template <int LAYOUT, int WM, int WN, int BK = 32, int PREC = 0>
+// TNT (kTN only): both operands staged through gload_kt / sstore_kt into K-contiguous images.
+template <int LAYOUT, int WM, int WN, int BK = 32, bool TNT = false>
 struct TileCfg {
+  static_assert(!TNT || LAYOUT == kTN, "register-transposed staging is for kTN");
   static constexpr int BM = 64 * WM, BN = 64 * WN, BKP = BK + 4;
-  static constexpr bool A_KC = (LAYOUT != kTN);
-  static constexpr bool B_KC = (LAYOUT == kNT);
-  static_assert(PREC != 2 || BK == 16, "staged bf16 planes: K-step 16");
-  static constexpr int A_TILE = PREC == 2 ? BM * 3 * kPlaneRowBytes / 4 : (A_KC ? BM * BKP : BK * BM);
-  static constexpr int B_TILE = PREC == 2 ? BN * 3 * kPlaneRowBytes / 4 : (B_KC ? BN * BKP : BK * BN);
+  static constexpr bool A_KC = (LAYOUT != kTN) || TNT;   // K-contiguous LDS image
+  static constexpr bool B_KC = (LAYOUT == kNT) || TNT;
+  static constexpr int A_TILE = A_KC ? BM * BKP : BK * BM;
+  static constexpr int B_TILE = B_KC ? BN * BKP : BK * BN;
   static constexpr int CP = BN + 4;  // padded row of the epilogue's C tile
   // the C tile leaves through LDS in EP passes of BM / EP rows (one pass per wave row), so that it needs no more
   // LDS than the operand buffers do when those are small (BK = 16)
@@ -256,13 +192,13 @@ struct TileCfg {
 };
 
 // One workgroup's tile: (bx, by) tile coordinates, bz = group * nsplit + split.
-template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32, int PREC = 0>
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32, bool TNT = false>
 __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ lds, int bx, int by, int bz) {
-  using Cfg = TileCfg<LAYOUT, WM, WN, BK, PREC>;
+  using Cfg = TileCfg<LAYOUT, WM, WN, BK, TNT>;
   constexpr int BM = 64 * WM, BN = 64 * WN;
   [[maybe_unused]] constexpr int BKP = Cfg::BKP;
-  constexpr bool A_KC = (LAYOUT != kTN);
-  constexpr bool B_KC = (LAYOUT == kNT);
+  constexpr bool A_KC = Cfg::A_KC;
+  constexpr bool B_KC = Cfg::B_KC;
   constexpr int A_TILE = Cfg::A_TILE;
   constexpr int B_TILE = Cfg::B_TILE;
   constexpr int NVA = BM * BK / 4 / kThreads, NVB = BN * BK / 4 / kThreads;
@@ -270,9 +206,6 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
 
   constexpr int CP = Cfg::CP;  // padded row of the epilogue's C tile
 
-  if (b.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
-  else if (b.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
-  else if (b.wave_prio == 3) __builtin_amdgcn_s_setprio(3);
   const int grp = bz / b.nsplit;
   const int split = bz - grp * b.nsplit;
   // Copy the problem descriptor out of the kernarg segment once: stores to C could
@@ -321,20 +254,23 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   const bool full = VEC && (m0 + BM <= M) && (n0 + BN <= N) && ((kend - kbeg) % BK == 0);
   auto gload = [&](float4 (&ra)[NVA], float4 (&rb)[NVB], int k0, auto full_tag) {
     constexpr bool F = decltype(full_tag)::value;
-    if constexpr (A_KC) gload_kc<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
-    else if constexpr (PREC == 2) gload_kt<BM, F>(ra, gA, lda, m0, M, k0, kend, tid);
-    else gload_ks<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
-    if constexpr (B_KC) gload_kc<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
-    else if constexpr (PREC == 2) gload_kt<BN, F>(rb, gB, ldb, n0, N, k0, kend, tid);
-    else gload_ks<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    if constexpr (TNT) {
+      gload_kt<BM, BK, F>(ra, gA, lda, m0, M, k0, kend, tid);
+      gload_kt<BN, BK, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    } else {
+      if constexpr (A_KC) gload_kc<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+      else gload_ks<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+      if constexpr (B_KC) gload_kc<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+      else gload_ks<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    }
   };
   auto sstore = [&](const float4 (&ra)[NVA], const float4 (&rb)[NVB], int buf) {
     float* As = lds + buf * (A_TILE + B_TILE);
     float* Bs = As + A_TILE;
-    if constexpr (PREC == 2) {
-      sstore_planes<BM, A_KC>(ra, As, tid);
-      sstore_planes<BN, B_KC>(rb, Bs, tid);
-      if (do_colsum) {  // kTN: this thread's A chunks are all of column tid % BM (gload_kt)
+    if constexpr (TNT) {
+      sstore_kt<BM, BK>(ra, As, tid);
+      sstore_kt<BN, BK>(rb, Bs, tid);
+      if (do_colsum) {  // this thread's A chunks are all of column tid % BM (gload_kt); k ascending within the thread
 #pragma unroll
         for (int i = 0; i < NVA; ++i) csum += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
       }
@@ -346,83 +282,6 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   auto compute = [&](int buf) {
     const float* __restrict__ As = lds + buf * (A_TILE + B_TILE);
     const float* __restrict__ Bs = As + A_TILE;
-    if constexpr (PREC == 2) {
-      // one 16-wide K chunk per step; lane (r, h) reads k = 8 h + 0..7 of its row from each plane: no arithmetic here
-      const char* __restrict__ Ab = reinterpret_cast<const char*>(As);
-      const char* __restrict__ Bb = reinterpret_cast<const char*>(Bs);
-      bf16x8 ah[WM], am[WM], al[WM], bh[WN], bm[WN], bl[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const int row = (wrow * WM + i) * 32 + r;
-        ah[i] = frag_plane<BM, A_KC>(Ab, 0, row, h);
-        am[i] = frag_plane<BM, A_KC>(Ab, 1, row, h);
-        al[i] = frag_plane<BM, A_KC>(Ab, 2, row, h);
-      }
-#pragma unroll
-      for (int i = 0; i < WN; ++i) {
-        const int col = (wcol * WN + i) * 32 + r;
-        bh[i] = frag_plane<BN, B_KC>(Bb, 0, col, h);
-        bm[i] = frag_plane<BN, B_KC>(Bb, 1, col, h);
-        bl[i] = frag_plane<BN, B_KC>(Bb, 2, col, h);
-      }
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int jj = 0; jj < WN; ++jj) {  // smallest terms first
-          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
-          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
-          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[jj], acc[i][jj], 0, 0, 0);
-          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[jj], acc[i][jj], 0, 0, 0);
-          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[jj], acc[i][jj], 0, 0, 0);
-          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
-        }
-    } else if constexpr (PREC == 1) {
-      // 16-wide K chunks; lane (r, h) holds k = 16 c + 8 h + 0..7 of its row / column
-#pragma unroll
-      for (int c = 0; c < BK / 16; ++c) {
-        bf16x8 ah[WM], am[WM], al[WM], bh[WN], bm[WN], bl[WN];
-        const int k8 = 16 * c + 8 * h;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-          const int row = (wrow * WM + i) * 32 + r;
-          float x[8];
-          if (A_KC) {
-            const float4 v0 = *reinterpret_cast<const float4*>(As + row * BKP + k8);
-            const float4 v1 = *reinterpret_cast<const float4*>(As + row * BKP + k8 + 4);
-            x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = As[(k8 + j) * BM + row];
-          }
-          split_bf3(x, ah[i], am[i], al[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < WN; ++i) {
-          const int col = (wcol * WN + i) * 32 + r;
-          float x[8];
-          if (B_KC) {
-            const float4 v0 = *reinterpret_cast<const float4*>(Bs + col * BKP + k8);
-            const float4 v1 = *reinterpret_cast<const float4*>(Bs + col * BKP + k8 + 4);
-            x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = Bs[(k8 + j) * BN + col];
-          }
-          split_bf3(x, bh[i], bm[i], bl[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int jj = 0; jj < WN; ++jj) {  // smallest terms first
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jj], acc[i][jj], 0, 0, 0);
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jj], acc[i][jj], 0, 0, 0);
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[jj], acc[i][jj], 0, 0, 0);
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[jj], acc[i][jj], 0, 0, 0);
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[jj], acc[i][jj], 0, 0, 0);
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jj], acc[i][jj], 0, 0, 0);
-          }
-      }
-    } else {
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
       float4 fa[WM], fb[WN];
@@ -446,8 +305,7 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
           acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[jj].w, acc[i][jj], 0, 0, 0);
         }
     }
-    }
-    if constexpr (PREC != 2) {
+    if constexpr (LAYOUT == kTN && !TNT) {
       if (do_colsum && tid < BM) {
 #pragma unroll
         for (int k = 0; k < BK; ++k) csum += As[k * BM + tid];
@@ -497,7 +355,7 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   };
   if (VEC && full) kloop(std::true_type{});
   else kloop(std::false_type{});
-  if constexpr (PREC == 2 && LAYOUT == kTN) {
+  if constexpr (TNT) {
     if (do_colsum) {  // kThreads / BM threads hold partial sums of each column: add them in thread order (LDS is free here)
       lds[tid] = csum;
       __syncthreads();
@@ -680,47 +538,25 @@ __device__ __forceinline__ bool tile_coords(const Batch& b, int& bx, int& by, in
   return true;
 }
 
-template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32>
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32, bool TNT = false>
 __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, BK>::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, BK, TNT>::LDS_FLOATS];
   int bx, by, bz;
   if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
-  gemm_body<LAYOUT, EPI, WM, WN, VEC, BK>(b, lds, bx, by, bz);
-}
-
-// Split-bf16 variant (PREC = 1) of the vector-path tiles: TT_BF3=1 only.
-template <int LAYOUT, int EPI, int WM, int WN, int BK>
-__global__ __launch_bounds__(kThreads) void gemm_bf3_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, BK>::LDS_FLOATS];
-  int bx, by, bz;
-  if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
-  gemm_body<LAYOUT, EPI, WM, WN, true, BK, 1>(b, lds, bx, by, bz);
-}
-
-// Split-bf16 with the split at staging time (PREC = 2), K-step 16.  TT_BF3=2.
-// (128x128: at most 168 registers, like the K-step-16 fp32 tile, so that two of them and the streaming gather's waves
-// stay resident together)
-template <int LAYOUT, int EPI, int WM, int WN>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WM * WN == 4 ? 3 : 1, 8)))
-void gemm_bf3s_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, 16, 2>::LDS_FLOATS];
-  int bx, by, bz;
-  if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
-  gemm_body<LAYOUT, EPI, WM, WN, true, 16, 2>(b, lds, bx, by, bz);
+  gemm_body<LAYOUT, EPI, WM, WN, VEC, BK, TNT>(b, lds, bx, by, bz);
 }
 
 // The BK = 16 tile shares a CU with the streaming gather's workgroup (gather_pool.hip): three waves per SIMD's worth
 // of registers (<= 168) leave room for two of these workgroups plus the gather's 4 waves of up to 176.
-#ifndef TT_BK16_WAVES
-#define TT_BK16_WAVES 3  // build-time A/B: 4 = 128 registers (a few dwords of scratch outside the K loop)
-#endif
-template <int LAYOUT, int EPI, int WM, int WN>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TT_BK16_WAVES, 8)))
+// (A 128-register build — a few dwords of scratch outside the K loop — changed nothing at configs[3]: 6.14-6.31 vs
+// 6.13-6.31 ms, profiles/r03_c4_128_register_tiles_ab.txt.)
+template <int LAYOUT, int EPI, int WM, int WN, bool TNT = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 8)))
 void gemm_f32_bk16_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, 16>::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, 16, TNT>::LDS_FLOATS];
   int bx, by, bz;
   if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
-  gemm_body<LAYOUT, EPI, WM, WN, true, 16>(b, lds, bx, by, bz);
+  gemm_body<LAYOUT, EPI, WM, WN, true, 16, TNT>(b, lds, bx, by, bz);
 }
 
 // Two independent GEMMs of the projection backward in ONE launch: the split-K dW2/db2 (kTN,
@@ -733,9 +569,9 @@ struct PairGeom {
   int tn_head, nn_blocks;       // workgroup order: TN [0, tn_head), all NN, the remaining TN (longest K loops first)
 };
 
-template <int WM, int WN>
+template <int WM, int WN, bool TNT>
 __global__ __launch_bounds__(kThreads) void gemm_tn_nn_kernel(const Batch bt, const Batch bn, const PairGeom g) {
-  constexpr int LT = TileCfg<kTN, 1, 1>::LDS_FLOATS, LN = TileCfg<kNN, WM, WN>::LDS_FLOATS;
+  constexpr int LT = TileCfg<kTN, 1, 1, 32, TNT>::LDS_FLOATS, LN = TileCfg<kNN, WM, WN>::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LT > LN ? LT : LN];
   int id = blockIdx.x;
   const bool is_tn = id < g.tn_head || id >= g.tn_head + g.nn_blocks;
@@ -743,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_nn_kernel(const Batch bt, co
     if (id >= g.tn_head) id -= g.nn_blocks;
     const int per_z = g.tn_gx * g.tn_gy;
     const int z = id / per_z, rem = id - z * per_z;
-    gemm_body<kTN, kStore, 1, 1, true>(bt, lds, rem % g.tn_gx, rem / g.tn_gx, z);
+    gemm_body<kTN, kStore, 1, 1, true, 32, TNT>(bt, lds, rem % g.tn_gx, rem / g.tn_gx, z);
   } else {
     id -= g.tn_head;
     const int per_z = g.nn_gx * g.nn_gy;
@@ -762,11 +598,24 @@ bool problem_vec_ok(const Problem& p) {
   return p.M % 4 == 0 && p.N % 4 == 0 && p.M >= 4 && p.N >= 4 && p.K >= 1;  // kTN: both K-strided
 }
 
+// kTN tiles exist in two staging forms (template TNT); every other layout has one.
+template <int LAYOUT, int EPI, int WM, int WN, int BK>
+void launch_tile(const Batch& b, dim3 grid, hipStream_t st) {
+  const dim3 block(kThreads);
+  if constexpr (LAYOUT == kTN) {
+    if (b.tn_transpose) {
+      if constexpr (BK == 16) hipLaunchKernelGGL((gemm_f32_bk16_kernel<LAYOUT, EPI, WM, WN, true>), grid, block, 0, st, b);
+      else hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, WM, WN, true, 32, true>), grid, block, 0, st, b);
+      return;
+    }
+  }
+  if constexpr (BK == 16) hipLaunchKernelGGL((gemm_f32_bk16_kernel<LAYOUT, EPI, WM, WN>), grid, block, 0, st, b);
+  else hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, WM, WN, true>), grid, block, 0, st, b);
+}
+
 template <int LAYOUT, int EPI>
 int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
   Batch b = b_in;
-  static const int gemm_prio = getenv("TT_GEMM_PRIO") ? atoi(getenv("TT_GEMM_PRIO")) : 0;  // A/B
-  b.wave_prio = gemm_prio;
   int maxM = 0, maxN = 0;
   for (int i = 0; i < b.count; ++i) {
     maxM = b.p[i].M > maxM ? b.p[i].M : maxM;
@@ -787,30 +636,11 @@ int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
     if (total > 0x7fffffffLL) b.xcd_order = 0;
     else grid = dim3((unsigned)total, 1, 1);
   }
-  const int mode = ttg::bf3_mode();  // split-bf16 products: opt-in experiment
-  const bool bf3 = mode >= 1;
-  // mode 2: split at staging time; mode 3 (A/B): that for kNT only, kNN / kTN split on the fragments as in mode 1
-  if (vec && (mode == 2 || (mode == 3 && LAYOUT == kNT))) {
-    if (wm == 1) hipLaunchKernelGGL((gemm_bf3s_kernel<LAYOUT, EPI, 1, 1>), grid, block, 0, st, b);
-    else if (wn == 1) hipLaunchKernelGGL((gemm_bf3s_kernel<LAYOUT, EPI, 2, 1>), grid, block, 0, st, b);
-    else hipLaunchKernelGGL((gemm_bf3s_kernel<LAYOUT, EPI, 2, 2>), grid, block, 0, st, b);
-    TT_CHECK_LAUNCH();
-    return TT_OK;
-  }
-  if (vec && bf3) {  // every vector-path tile has its split-bf16 twin: one arithmetic for the whole run
-    if (wm == 1) hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 1, 1, 32>), grid, block, 0, st, b);
-    else if (wn == 1) hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 2, 1, 32>), grid, block, 0, st, b);
-    else if (bk == 16) hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 2, 2, 16>), grid, block, 0, st, b);
-    else hipLaunchKernelGGL((gemm_bf3_kernel<LAYOUT, EPI, 2, 2, 32>), grid, block, 0, st, b);
-    TT_CHECK_LAUNCH();
-    return TT_OK;
-  }
   if (!vec) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1, false>), dim3((maxN + 63) / 64, (maxM + 63) / 64, b.count * b.nsplit), block, 0, st, b);
-  else if (wm == 1 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1, true>), grid, block, 0, st, b);
-  else if (wm == 2 && wn == 1) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 2, 1, true>), grid, block, 0, st, b);
-  else if (wm == 2 && wn == 2 && bk == 16)  // the tile that shares a CU with the streaming gather
-    hipLaunchKernelGGL((gemm_f32_bk16_kernel<LAYOUT, EPI, 2, 2>), grid, block, 0, st, b);
-  else if (wm == 2 && wn == 2) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 2, 2, true>), grid, block, 0, st, b);
+  else if (wm == 1 && wn == 1) launch_tile<LAYOUT, EPI, 1, 1, 32>(b, grid, st);
+  else if (wm == 2 && wn == 1) launch_tile<LAYOUT, EPI, 2, 1, 32>(b, grid, st);
+  else if (wm == 2 && wn == 2 && bk == 16) launch_tile<LAYOUT, EPI, 2, 2, 16>(b, grid, st);  // shares a CU with the streaming gather
+  else if (wm == 2 && wn == 2) launch_tile<LAYOUT, EPI, 2, 2, 32>(b, grid, st);
   else return TT_ERR_UNSUPPORTED;
   TT_CHECK_LAUNCH();
   return TT_OK;
@@ -822,8 +652,7 @@ int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStrea
   bool vec = true;
   for (int i = 0; i < bt.count; ++i) vec = vec && (bt.p[i].M == 0 || problem_vec_ok<kTN>(bt.p[i]));
   for (int i = 0; i < bn.count; ++i) vec = vec && (bn.p[i].M == 0 || problem_vec_ok<kNN>(bn.p[i]));
-  static const bool bf3 = getenv("TT_BF3") && getenv("TT_BF3")[0] >= '1';  // the pair kernel has no split-bf16 twin
-  if (!vec || bf3 || !((wm == 1 && wn == 1) || (wm == 2 && wn == 1))) {  // odd shapes: two ordinary launches
+  if (!vec || !((wm == 1 && wn == 1) || (wm == 2 && wn == 1))) {  // odd shapes: two ordinary launches
     int rc = launch(kTN, kStore, bt, 1, 1, st);
     if (rc != TT_OK) return rc;
     return launch(kNN, kReluMask, bn, wm, wn, st);
@@ -843,50 +672,33 @@ int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStrea
   if (total > 0x7fffffffLL) return TT_ERR_BAD_SHAPE;
   g.nn_blocks = (int)nn_total;
   // TN problems arrive longest-K first (proj.hip): the first problem's workgroups lead, the NN tiles (K = P) follow,
-  // shorter TN problems close the grid.  TT_PAIR_ORDER=0: all TN first (A/B).
-  static const bool mid = !(getenv("TT_PAIR_ORDER") && getenv("TT_PAIR_ORDER")[0] == '0');
-  g.tn_head = (mid && bt.count > 1 && bt.p[0].K > bt.p[1].K) ? g.tn_gx * g.tn_gy * bt.nsplit : g.tn_blocks;
+  // shorter TN problems close the grid (measured against "all TN first" in round 1: 198 -> 196 us per step).
+  g.tn_head = (bt.count > 1 && bt.p[0].K > bt.p[1].K) ? g.tn_gx * g.tn_gy * bt.nsplit : g.tn_blocks;
   const dim3 grid((unsigned)total), block(kThreads);
-  static const int gemm_prio = getenv("TT_GEMM_PRIO") ? atoi(getenv("TT_GEMM_PRIO")) : 0;  // A/B
-  Batch bt2 = bt, bn2 = bn;
-  bt2.wave_prio = bn2.wave_prio = gemm_prio;
-  if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1>), grid, block, 0, st, bt2, bn2, g);
-  else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1>), grid, block, 0, st, bt2, bn2, g);
+  if (bt.tn_transpose) {
+    if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1, true>), grid, block, 0, st, bt, bn, g);
+    else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1, true>), grid, block, 0, st, bt, bn, g);
+  } else {
+    if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1, false>), grid, block, 0, st, bt, bn, g);
+    else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1, false>), grid, block, 0, st, bt, bn, g);
+  }
   TT_CHECK_LAUNCH();
   return TT_OK;
 }
 
-template <int WM, int WN>
-static size_t lds_of(Layout layout) {
-  const int f = layout == kNT ? TileCfg<kNT, WM, WN>::LDS_FLOATS
-                              : layout == kNN ? TileCfg<kNN, WM, WN>::LDS_FLOATS : TileCfg<kTN, WM, WN>::LDS_FLOATS;
+template <int WM, int WN, int BK>
+static size_t lds_of(Layout layout, bool tnt) {
+  const int f = layout == kNT ? TileCfg<kNT, WM, WN, BK>::LDS_FLOATS
+                              : layout == kNN ? TileCfg<kNN, WM, WN, BK>::LDS_FLOATS
+                                              : tnt ? TileCfg<kTN, WM, WN, BK, true>::LDS_FLOATS : TileCfg<kTN, WM, WN, BK>::LDS_FLOATS;
   return (size_t)f * sizeof(float);
 }
 
-int bf3_mode() {
-  static const int mode = getenv("TT_BF3") ? atoi(getenv("TT_BF3")) : 0;
-  return mode;
-}
-
-template <int WM, int WN>
-static size_t lds_of_staged(Layout layout) {
-  const int f = layout == kNT ? TileCfg<kNT, WM, WN, 16, 2>::LDS_FLOATS
-                              : layout == kNN ? TileCfg<kNN, WM, WN, 16, 2>::LDS_FLOATS : TileCfg<kTN, WM, WN, 16, 2>::LDS_FLOATS;
-  return (size_t)f * sizeof(float);
-}
-
-size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk) {
-  if (bf3_mode() == 2 || (bf3_mode() == 3 && layout == kNT)) {  // the staged split-bf16 tiles (vector path)
-    if (wm == 2 && wn == 2) return lds_of_staged<2, 2>(layout);
-    if (wm == 2 && wn == 1) return lds_of_staged<2, 1>(layout);
-    return lds_of_staged<1, 1>(layout);
-  }
-  if (wm == 2 && wn == 2 && bk == 16)
-    return (size_t)(layout == kNT ? TileCfg<kNT, 2, 2, 16>::LDS_FLOATS
-                                  : layout == kNN ? TileCfg<kNN, 2, 2, 16>::LDS_FLOATS : TileCfg<kTN, 2, 2, 16>::LDS_FLOATS) * sizeof(float);
-  if (wm == 2 && wn == 2) return lds_of<2, 2>(layout);
-  if (wm == 2 && wn == 1) return lds_of<2, 1>(layout);
-  return lds_of<1, 1>(layout);
+size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk, bool tn_transpose) {
+  if (wm == 2 && wn == 2 && bk == 16) return lds_of<2, 2, 16>(layout, tn_transpose);
+  if (wm == 2 && wn == 2) return lds_of<2, 2, 32>(layout, tn_transpose);
+  if (wm == 2 && wn == 1) return lds_of<2, 1, 32>(layout, tn_transpose);
+  return lds_of<1, 1, 32>(layout, tn_transpose);
 }
 
 int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st, int bk) {

@@ -130,15 +130,10 @@ static int grad_splits(long long rows, int P, long long K) {
   while (s > 1 && K / s < 256) --s;  // keep at least 8 K-steps per split
   return s;
 }
-// block tile of the S product, in units of 64.  64x64 everywhere: measured against 128x128 tiles (TT_INBATCH_TILE=2, A/B;
-// vector path and >= 2048 tiles only) it is never slower and 3-4 % of the step faster at B = 4096 / 8192 beside the
-// gathers (profiles/r03_inbatch_tile_ab.txt) — with K = P = 384 a 128x128 tile is 12 K-steps between a prologue and a
-// 64 KB hinge epilogue, and only two of them fit a CU.
-static int s_tile(long long Bq, long long Bd, int P) {
-  static const char* const v = getenv("TT_INBATCH_TILE");
-  if (v && v[0] == '2') return (P % 4 == 0 && P >= 4 && ((Bq + 63) / 64) * ((Bd + 63) / 64) >= 2048) ? 2 : 1;
-  return 1;
-}
+// block tile of the S product, in units of 64.  64x64 everywhere: measured against 128x128 tiles in round 3 it is never
+// slower and 3-4 % of the step faster at B = 4096 / 8192 beside the gathers (profiles/r03_inbatch_tile_ab.txt) — with
+// K = P = 384 a 128x128 tile is 12 K-steps between a prologue and a 64 KB hinge epilogue, and only two of them fit a CU.
+static int s_tile(long long, long long, int) { return 1; }
 static int col_tiles(long long Bq, long long Bd, int P) {  // column tiles of the S product: row stride of the partials
   const int t = s_tile(Bq, Bd, P);
   return (int)((Bd + 64 * t - 1) / (64 * t));

@@ -22,33 +22,44 @@ struct Tower {
   int M;
 };
 
-// k_per_split for `M` rows over `nsplit` slabs (multiple of 32, >= 32)
 // Block-tile policy of the [rows x P] projection GEMMs: stand-alone choice; 128x64 where 64x64 would do (half the
 // weight re-reads: beside a capped K1); 64x64 below the 128x128 threshold (beside a K1 reserved just above that
 // tile's LDS, engine.hip).
 // kTileStream: beside the streaming gather of an HBM-resident table (gather_pool.hip): 128x128 tiles with K-step 16.
 enum TilePolicy : int { kTileAuto = 0, kTileLowTraffic = 1, kTileSmall = 2, kTileStream = 3 };
+// How a grouped projection call is tiled: the policy that pairs it with whatever shares the chip (the engine's
+// business) and the caller's explicit choices (tt_tuning, 0 = auto), which win over the policy.
+struct Plan {
+  int policy = kTileAuto;
+  tt_tuning t{};
+};
+inline Plan plan_of(const tt_tuning* t, int policy = kTileAuto) {
+  Plan p;
+  p.policy = policy;
+  if (t) p.t = *t;
+  return p;
+}
+// k_per_split for `M` rows over `nsplit` slabs (multiple of 32, >= 32)
 int k_per_split(int M, int nsplit);
 // split count used for a standalone backward over M rows
 int choose_nsplit(long long M);
 // Largest static LDS (bytes) of a workgroup of the projection kernels forward()/backward_*() launch for
-// `rows` rows in total with the given tile policy — what a gather workgroup's LDS reservation is sized against.
-size_t chain_lds_bytes(long long rows, int P, int policy);
+// `rows` rows in total with the given plan — what a gather workgroup's LDS reservation is sized against.
+size_t chain_lds_bytes(long long rows, int P, const Plan& plan);
 
-// low_traffic: prefer 128x64 block tiles (half the weight re-reads) — for when the GEMMs share
-// the chip with the gather kernel, whose bandwidth their operand traffic eats into.
-int forward(const Tower* t, int count, int D, int P, hipStream_t st, int policy = kTileAuto);
+int forward(const Tower* t, int count, int D, int P, hipStream_t st, const Plan& plan = Plan{});
 // writes nsplit partial slabs of (dW1, db1, dW2, db2) per tower; dH is scratch
-int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st);
+int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
+             const Plan& plan = Plan{});
 // The three launches of `backward`, separately (dW2/db2 is independent of the dH -> dW1/db1
 // chain, so a caller may run it on another stream):
 int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
-                 int policy = kTileAuto);
-int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, int policy = kTileAuto);
+                 const Plan& plan = Plan{});
+int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, const Plan& plan = Plan{});
 // dW2/db2 and dH as ONE launch (they are independent of each other)
 int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
-                    int policy = kTileAuto);
+                    const Plan& plan = Plan{});
 int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
-                 int policy = kTileAuto);
+                 const Plan& plan = Plan{});
 
 }  // namespace ttp

@@ -1,4 +1,3 @@
-#include <cstdlib>
 // K2 — per-tower projection Linear(D,P) -> ReLU -> Linear(P,P) and its parameter
 // gradients, as grouped exact-fp32 MFMA GEMMs (both towers in one launch).
 // Replaces backend/model.py:33-38,59 and the part of loss.backward()
@@ -20,90 +19,66 @@ int choose_nsplit(long long M) {
   return (int)s;
 }
 
-// block tile for an [M x N] output: fill >= ~2 waves of the 256 CUs where possible
-// 96x96 tiles (gemm16.hip) for a grouped [rows x N] forward product: TT_G16=1 (A/B runs) where the tile-count model
-// says they need at least 10 % fewer tile-rounds x tile area than the current tiles; TT_G16_FORCE=1: every shape.
-// NOT selected by default.  At BASELINE.json configs[1] the two towers' 2048 + 4096 rows make 260 tiles of 96x96 (not
-// the 256 a single [6144 x 384] matrix would), and forced it measured slower: cache-fed 132 vs 129 us, one stream
-// 253 vs 235 us, beside the gathers 233 vs 194 us (profiles/r03_gemm16_ab.txt).
-static bool prefer_tile96(const ttg::Batch& b, int policy, int wm, int wn) {
-  static const char* const v = getenv("TT_G16");
-  if (!(v && v[0] == '1')) return false;
-  (void)policy;
-  const long long cus = 256;
-  long long t_cur = 0, t_96 = 0;
-  for (int i = 0; i < b.count; ++i) {
-    const long long M = b.p[i].M, N = b.p[i].N;
-    t_cur += ((M + 64 * wm - 1) / (64 * wm)) * ((N + 64 * wn - 1) / (64 * wn));
-    t_96 += ((M + 95) / 96) * ((N + 95) / 96);
-  }
-  const long long cost_cur = ((t_cur + cus - 1) / cus) * (64LL * wm) * (64LL * wn);
-  const long long cost_96 = ((t_96 + cus - 1) / cus) * 96LL * 96LL;
-  static const bool force = getenv("TT_G16_FORCE") != nullptr;  // every shape (parity tests)
-  return force || cost_96 * 10 <= cost_cur * 9;  // at least 10 % fewer tile-rounds x area
-}
-
-static int launch_rows(ttg::Layout layout, ttg::Epilogue epi, const ttg::Batch& b, int wm, int wn, int bk, int policy,
-                       hipStream_t st) {
-  if (ttg::gemm16_supported(layout, epi, b) && prefer_tile96(b, policy, wm, wn)) return ttg::launch16(layout, epi, b, st);
-  return ttg::launch(layout, epi, b, wm, wn, st, bk);
-}
-
 // XCD-aware workgroup order for the projection GEMMs (gemm_f32.h): on beside the streaming gather, where every
-// re-read of an operand block that misses the XCD's L2 competes with the gather for the fabric; TT_XCD=0|1 (A/B).
-static int xcd_order_for(int policy) {
-  static const char* const v = getenv("TT_XCD");
-  if (v && *v) return *v != '0';
-  return policy == kTileStream;
+// re-read of an operand block that misses the XCD's L2 competes with the gather for the fabric.
+static int xcd_order_for(const Plan& pl) {
+  if (pl.t.xcd_order != 0) return pl.t.xcd_order > 0;
+  return pl.policy == kTileStream;
+}
+
+// kTN staging through a register transpose (gemm_f32.h, Batch::tn_transpose).
+static int tn_transpose_for(const Plan& pl) {
+  if (pl.t.tn_transpose != 0) return pl.t.tn_transpose > 0;
+  return 0;
 }
 
 // Tile of the split-K weight-gradient GEMMs: 64x64 (many short workgroups; pairs with the gather's LDS reservation at
 // BERT sizes), or — beside the streaming gather — 128x128 with K-step 16: a quarter of the operand re-reads.
-static void pick_tn_tile(int M, int N, int policy, int& wm, int& wn, int& bk) {
-  static const char* const v = getenv("TT_TN_TILE");  // A/B: "11" / "22"
+static void pick_tn_tile(int M, int N, const Plan& pl, int& wm, int& wn, int& bk) {
   wm = wn = 1; bk = 32;
-  const bool big = (v && *v) ? v[0] == '2' : policy == kTileStream;
+  const bool big = pl.t.tn_tile ? pl.t.tn_tile == 22 : pl.policy == kTileStream;
   if (big && M >= 256 && N >= 256) { wm = wn = 2; bk = 16; }
 }
 
-static void pick_tile(long long total_rows, int N, int& wm, int& wn, int& bk, int policy = kTileAuto) {
-  const bool low_traffic = policy == kTileLowTraffic;
-  static const char* const bk_env = getenv("TT_BK");  // A/B: "16" / "32" K-step of the 128x128 tiles
+// Block tile for a grouped [rows x N] product.  (96x96 tiles on v_mfma_f32_16x16x4_f32 — 256 tiles for a single
+// [6144 x 384] matrix where 64x64 gives 576 = 2.25 per CU — were built in round 3, parity-green, and measured slower at
+// BASELINE.json configs[1]: the two towers' 2048 + 4096 rows make 260 such tiles, cache-fed 132 vs 129 us, one stream
+// 253 vs 235 us, beside the gathers 233 vs 194 us; profiles/r03_gemm16_ab.txt.  Removed in round 4.)
+static void pick_tile(long long total_rows, int N, int& wm, int& wn, int& bk, const Plan& pl) {
+  const bool low_traffic = pl.policy == kTileLowTraffic;
   bk = 32;
-  static const char* const tile_env = getenv("TT_TILE");  // read once (A/B: "11", "21", "22")
-  if (const char* v = tile_env) {
-    if (v[0] == '1' || v[0] == '2') {
-      wm = v[0] - '0'; wn = (v[1] == '2') ? 2 : 1; if (wm == 1) wn = 1;
-      if (bk_env && wm == 2 && wn == 2) bk = atoi(bk_env) == 16 ? 16 : 32;
-      return;
-    }
+  if (pl.t.proj_tile == 11 || pl.t.proj_tile == 21 || pl.t.proj_tile == 22) {
+    wm = pl.t.proj_tile / 10; wn = pl.t.proj_tile % 10;
+    if (wm == 2 && wn == 2 && pl.t.proj_bk == 16) bk = 16;
+    return;
   }
   const long long tiles64 = ((total_rows + 63) / 64) * ((N + 63) / 64);
   if (tiles64 >= 2048 && N >= 128) {
     wm = 2; wn = 2;
     // beside the streaming gather: K-step 16 (40 KB of LDS, <= 168 registers), two tiles + the gather's waves per CU
-    bk = policy == kTileStream ? 16 : 32;
-    if (bk_env) bk = atoi(bk_env) == 16 ? 16 : 32;
+    bk = pl.policy == kTileStream ? 16 : 32;
+    if (pl.t.proj_bk == 16 || pl.t.proj_bk == 32) bk = pl.t.proj_bk;
   }
-  else if (policy == kTileSmall) { wm = 1; wn = 1; }
+  else if (pl.policy == kTileSmall) { wm = 1; wn = 1; }
   else if (tiles64 >= 1024 || (low_traffic && tiles64 >= 512)) { wm = 2; wn = 1; }
   else { wm = 1; wn = 1; }
 }
 
-size_t chain_lds_bytes(long long rows, int P, int policy) {
+size_t chain_lds_bytes(long long rows, int P, const Plan& pl) {
   int wm, wn, bk;
-  pick_tile(rows, P, wm, wn, bk, policy);
+  pick_tile(rows, P, wm, wn, bk, pl);
   size_t m = ttg::tile_lds_bytes(ttg::kNT, wm, wn, bk);
-  const size_t nn = ttg::tile_lds_bytes(ttg::kNN, wm, wn, bk), tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1);
+  const size_t nn = ttg::tile_lds_bytes(ttg::kNN, wm, wn, bk);
+  const size_t tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1, 32, tn_transpose_for(pl) != 0);
   m = nn > m ? nn : m;
   return tn > m ? tn : m;
 }
 
-int forward(const Tower* t, int count, int D, int P, hipStream_t st, int policy) {
+int forward(const Tower* t, int count, int D, int P, hipStream_t st, const Plan& pl) {
   ttg::Batch b1{}, b2{};
   b1.count = b2.count = count;
   b1.nsplit = b2.nsplit = 1;
-  b1.xcd_order = b2.xcd_order = xcd_order_for(policy);
+  b1.xcd_order = b2.xcd_order = xcd_order_for(pl);
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -115,25 +90,25 @@ int forward(const Tower* t, int count, int D, int P, hipStream_t st, int policy)
     q.M = t[i].M; q.N = P; q.K = P; q.lda = P; q.ldb = P; q.ldc = P;
   }
   int wm, wn, bk;
-  pick_tile(rows, P, wm, wn, bk, policy);
-  int rc = launch_rows(ttg::kNT, ttg::kBiasRelu, b1, wm, wn, bk, policy, st);
+  pick_tile(rows, P, wm, wn, bk, pl);
+  int rc = ttg::launch(ttg::kNT, ttg::kBiasRelu, b1, wm, wn, st, bk);
   if (rc != TT_OK) return rc;
-  return launch_rows(ttg::kNT, ttg::kBias, b2, wm, wn, bk, policy, st);
+  return ttg::launch(ttg::kNT, ttg::kBias, b2, wm, wn, st, bk);
 }
 
 // Weight-gradient launches put the towers with more rows (longer K loops) first: workgroups are placed in
 // index order, so the short ones then fill in behind the long ones instead of the other way round.
 static int tn_slot(const Tower* t, int count, int i) {
-  static const bool lpt = !(getenv("TT_TN_LPT") && getenv("TT_TN_LPT")[0] == '0');
-  if (!lpt || count != 2) return i;
+  if (count != 2) return i;
   return (t[1].M > t[0].M) ? 1 - i : i;
 }
 
-int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st, int policy) {
+int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st, const Plan& pl) {
   ttg::Batch g2{};
   g2.count = count;
   g2.nsplit = nsplit;
-  g2.xcd_order = xcd_order_for(policy);
+  g2.xcd_order = xcd_order_for(pl);
+  g2.tn_transpose = tn_transpose_for(pl);
   g2.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW2[i,j] = sum_m dOut[m,i] H[m,j];  db2[i] = sum_m dOut[m,i]
@@ -142,15 +117,15 @@ int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long 
     a.M = P; a.N = P; a.K = t[i].M; a.lda = P; a.ldb = P; a.ldc = P; a.k_per_split = k_per_split(t[i].M, nsplit);
   }
   int wm, wn, bk;
-  pick_tn_tile(P, P, policy, wm, wn, bk);
+  pick_tn_tile(P, P, pl, wm, wn, bk);
   return ttg::launch(ttg::kTN, ttg::kStore, g2, wm, wn, st, bk);
 }
 
-int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, int policy) {
+int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, const Plan& pl) {
   ttg::Batch gh{};
   gh.count = count;
   gh.nsplit = 1;
-  gh.xcd_order = xcd_order_for(policy);
+  gh.xcd_order = xcd_order_for(pl);
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -160,18 +135,19 @@ int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, int pol
     h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
   }
   int wm, wn, bk;
-  pick_tile(rows, P, wm, wn, bk, policy);
-  return launch_rows(ttg::kNN, ttg::kReluMask, gh, wm, wn, bk, policy, st);
+  pick_tile(rows, P, wm, wn, bk, pl);
+  return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st, bk);
 }
 
 int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st,
-                    int policy) {
+                    const Plan& pl) {
   ttg::Batch g2{}, gh{};
   g2.count = gh.count = count;
   g2.nsplit = nsplit;
   g2.slab_stride = slab_stride;
   gh.nsplit = 1;
-  g2.xcd_order = gh.xcd_order = xcd_order_for(policy);
+  g2.xcd_order = gh.xcd_order = xcd_order_for(pl);
+  g2.tn_transpose = tn_transpose_for(pl);
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -183,17 +159,10 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
     h.M = t[i].M; h.N = P; h.K = P; h.lda = P; h.ldb = P; h.ldc = P; h.ldaux = P;
   }
   int wm, wn, bk;
-  pick_tile(rows, P, wm, wn, bk, policy);
-  if (ttg::gemm16_supported(ttg::kNN, ttg::kReluMask, gh) && prefer_tile96(gh, policy, wm, wn)) {
-    int tm, tn, tbk;
-    pick_tn_tile(P, P, policy, tm, tn, tbk);
-    int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, tm, tn, st, tbk);
-    if (rc != TT_OK) return rc;
-    return ttg::launch16(ttg::kNN, ttg::kReluMask, gh, st);
-  }
-  if (wm == 2 && wn == 2) {  // the fused kernel carries 64x64 and 128x64 NN tiles only
-    int tm, tn, tbk;
-    pick_tn_tile(P, P, policy, tm, tn, tbk);
+  pick_tile(rows, P, wm, wn, bk, pl);
+  int tm, tn, tbk;
+  pick_tn_tile(P, P, pl, tm, tn, tbk);
+  if ((wm == 2 && wn == 2) || tm != 1) {  // the fused kernel carries 64x64 TN tiles beside 64x64 / 128x64 NN tiles only
     int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, tm, tn, st, tbk);
     if (rc != TT_OK) return rc;
     return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st, bk);
@@ -201,11 +170,12 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
   return ttg::launch_tn_nn_pair(g2, gh, wm, wn, st);
 }
 
-int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st, int policy) {
+int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st, const Plan& pl) {
   ttg::Batch g1{};
   g1.count = count;
   g1.nsplit = nsplit;
-  g1.xcd_order = xcd_order_for(policy);
+  g1.xcd_order = xcd_order_for(pl);
+  g1.tn_transpose = tn_transpose_for(pl);
   g1.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW1[i,j] = sum_m dH[m,i] X[m,j];  db1[i] = sum_m dH[m,i]
@@ -214,29 +184,29 @@ int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long 
     c.M = P; c.N = D; c.K = t[i].M; c.lda = P; c.ldb = D; c.ldc = D; c.k_per_split = k_per_split(t[i].M, nsplit);
   }
   int wm, wn, bk;
-  pick_tn_tile(P, D, policy, wm, wn, bk);
+  pick_tn_tile(P, D, pl, wm, wn, bk);
   return ttg::launch(ttg::kTN, ttg::kStore, g1, wm, wn, st, bk);
 }
 
-int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st) {
-  int rc = backward_dw2(t, count, D, P, nsplit, slab_stride, st);
+int backward(const Tower* t, int count, int D, int P, int nsplit, long long slab_stride, hipStream_t st, const Plan& pl) {
+  int rc = backward_dw2(t, count, D, P, nsplit, slab_stride, st, pl);
   if (rc != TT_OK) return rc;
-  rc = backward_dh(t, count, D, P, st);
+  rc = backward_dh(t, count, D, P, st, pl);
   if (rc != TT_OK) return rc;
-  return backward_dw1(t, count, D, P, nsplit, slab_stride, st);
+  return backward_dw1(t, count, D, P, nsplit, slab_stride, st, pl);
 }
 
 }  // namespace ttp
 
 extern "C" int tt_proj_fwd_f32(const float* X, const float* W1, const float* b1, const float* W2,
                                const float* b2, float* H, float* Out, int64_t M, int D, int P,
-                               tt_stream_t stream) {
+                               const tt_tuning* tuning, tt_stream_t stream) {
   TT_REQUIRE(X && W1 && b1 && W2 && b2 && H && Out, TT_ERR_NULL_POINTER);
   TT_REQUIRE(M >= 0 && M <= 0x7fffffffLL && D >= 1 && P >= 1, TT_ERR_BAD_SHAPE);
   if (M == 0) return TT_OK;
   ttp::Tower t{};
   t.X = X; t.W1 = W1; t.b1 = b1; t.W2 = W2; t.b2 = b2; t.H = H; t.Out = Out; t.M = (int)M;
-  return ttp::forward(&t, 1, D, P, static_cast<hipStream_t>(stream));
+  return ttp::forward(&t, 1, D, P, static_cast<hipStream_t>(stream), ttp::plan_of(tuning));
 }
 
 static int64_t tower_floats(int D, int P) { return (int64_t)P * D + P + (int64_t)P * P + P; }
@@ -250,7 +220,7 @@ extern "C" size_t tt_proj_bwd_workspace_bytes(int64_t M, int D, int P) {
 extern "C" int tt_proj_bwd_f32(const float* dOut, const float* X, const float* H, const float* W2,
                                float* dW1, float* db1, float* dW2, float* db2, void* workspace,
                                size_t workspace_bytes, int accumulate, int64_t M, int D, int P,
-                               tt_stream_t stream) {
+                               const tt_tuning* tuning, tt_stream_t stream) {
   TT_REQUIRE(dOut && X && H && W2 && dW1 && db1 && dW2 && db2 && workspace, TT_ERR_NULL_POINTER);
   TT_REQUIRE(M >= 1 && M <= 0x7fffffffLL && D >= 1 && P >= 1, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(workspace_bytes >= tt_proj_bwd_workspace_bytes(M, D, P), TT_ERR_WORKSPACE);
@@ -267,7 +237,7 @@ extern "C" int tt_proj_bwd_f32(const float* dOut, const float* X, const float* H
   t.gb1 = slabs + (int64_t)P * D;
   t.gW2 = t.gb1 + P;
   t.gb2 = t.gW2 + (int64_t)P * P;
-  int rc = ttp::backward(&t, 1, D, P, ns, stride, st);
+  int rc = ttp::backward(&t, 1, D, P, ns, stride, st, ttp::plan_of(tuning));
   if (rc != TT_OK) return rc;
   rc = tt_reduce_slabs_f32(t.gW1, ns, stride, dW1, (int64_t)P * D, accumulate, stream);
   if (rc != TT_OK) return rc;

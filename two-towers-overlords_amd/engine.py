@@ -34,7 +34,7 @@ def flat_param_slices(D: int, P: int):
 
 class HotPathEngine:
     def __init__(self, table: torch.Tensor, projection_dim: int, max_batch: int, max_seq_len: int,
-                 k1_blocks_per_cu: int = 0):
+                 k1_blocks_per_cu: int = 0, tuning=None):
         _req(table, "table", torch.float32, 2)
         self.device = table.device
         self.table = table
@@ -55,6 +55,16 @@ class HotPathEngine:
         self.n_params = int(lib.tt_engine_param_count(h))
         self.n_slabs = int(lib.tt_engine_grad_slabs(h))
         self.params = self.exp_avg = self.exp_avg_sq = None
+        self.tuning = None
+        if tuning:
+            self.set_tuning(tuning)
+
+    def set_tuning(self, tuning) -> None:
+        """Bind a tt_tuning (dict of field -> value, or _lib.TTTuning; None / {} = all auto) to THIS engine: K1 form,
+        streaming-gather residency, projection tiles, backward schedule ...  Speed only (include/tt_hotpath.h)."""
+        t = _lib.make_tuning(tuning or {})
+        call("tt_engine_set_tuning", self._h, C.byref(t))
+        self.tuning = {k: getattr(t, k) for k in _lib.TUNING_FIELDS if getattr(t, k)}
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -180,11 +190,11 @@ class HotPathEngine:
         call("tt_engine_reduce_grads", self._h, out.data_ptr(), int(accumulate), self._stream())
 
     def k1_census(self, slot: int):
-        """(workgroups admitted, compute units used, most workgroups registered on one CU) of the streaming gather last
-        launched into `slot`; zeros when the engine does not stream this table.  Synchronises the current stream."""
-        a, c, m = C.c_int32(), C.c_int32(), C.c_int32()
-        call("tt_engine_k1_census", self._h, int(slot), C.byref(a), C.byref(c), C.byref(m), self._stream())
-        return a.value, c.value, m.value
+        """(workgroups admitted, compute units used, most candidates registered on one CU, workgroups planned) of the
+        streaming gather last launched into `slot`; zeros when that gather did not stream.  Synchronises the current stream."""
+        a, c, m, p = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        call("tt_engine_k1_census", self._h, int(slot), C.byref(a), C.byref(c), C.byref(m), C.byref(p), self._stream())
+        return a.value, c.value, m.value, p.value
 
     def reduce_grads_range(self, out: torch.Tensor, offset: int, count: int, accumulate: bool = False) -> None:
         """out[offset : offset + count] (+)= slab sum of those parameters only (`out` is the whole flat bucket)."""

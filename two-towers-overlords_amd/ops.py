@@ -86,14 +86,22 @@ def gather_pool_norm(
     check_ids: bool = False,
     sliced: Optional[bool] = None,
     stream_form: Optional[int] = None,
+    form: Optional[str] = None,
+    tuning=None,
 ) -> torch.Tensor:
     """K1: normalize(mean_pool(table[input_ids], attention_mask)) -> [N, D].
     Replaces backend/model.py:51-56 (`embed` mode).  check_ids=True synchronises
     and raises if any unmasked id was outside [0, V).  sliced: force the per-text (False) or the
     XCD-sliced (True, tt_gather_pool_norm_sliced_f32) form; None picks the faster one for the
-    shape (tt_k1_prefers_sliced).  Same result to fp32 summation order.  stream_form=n: the streaming
-    form (tt_gather_pool_norm_stream_f32: persistent workgroups, at most n per compute unit; bitwise the
-    per-text result) — what the engine uses for tables that stream from HBM."""
+    shape (tt_k1_prefers_sliced).  form: "rows" / "columns" picks the slicing of the sliced form (default: the
+    measured rule, tt_k1_sliced_form; either implies sliced=True), "per_text" = sliced=False.  Same result to fp32
+    summation order.  stream_form=n: the streaming form (tt_gather_pool_norm_stream_f32: persistent workgroups, at
+    most n per compute unit; bitwise the per-text result; `tuning`: k1_stream_rows / _offer / _linger) — what the
+    engine uses for tables that stream from HBM."""
+    if form is not None:
+        if form not in ("per_text", "rows", "columns"):
+            raise ValueError("form: 'per_text', 'rows' or 'columns'")
+        sliced = form != "per_text"
     _req(table, "table", torch.float32, 2)
     _req(input_ids, "input_ids", ndim=2)
     iw = _int_tensor(input_ids, "input_ids")
@@ -114,7 +122,8 @@ def gather_pool_norm(
             nbytes = int(_lib.load().tt_gather_pool_stream_workspace_bytes())
             ws = _scratch(table.device, nbytes)  # queue head + per-CU registry; stream-ordered reuse
             call("tt_gather_pool_norm_stream_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw,
-                 _ptr(lens), out.data_ptr(), N, S, D, V, _ptr(flag), ws.data_ptr(), nbytes, int(stream_form), _stream())
+                 _ptr(lens), out.data_ptr(), N, S, D, V, _ptr(flag), ws.data_ptr(), nbytes, int(stream_form),
+                 _lib.tuning_ref(tuning), _stream())
         else:
             if sliced is None:
                 sliced = bool(_lib.load().tt_k1_prefers_sliced(V, D, N, S)) and table.data_ptr() % 16 == 0
@@ -122,7 +131,8 @@ def gather_pool_norm(
                 nbytes = int(_lib.load().tt_gather_pool_sliced_workspace_bytes(N, D))
                 ws = _scratch(table.device, nbytes)
                 call("tt_gather_pool_norm_sliced_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw,
-                     _ptr(lens), out.data_ptr(), N, S, D, V, _ptr(flag), ws.data_ptr(), nbytes, _stream())
+                     _ptr(lens), out.data_ptr(), N, S, D, V, _ptr(flag), ws.data_ptr(), nbytes,
+                     _lib.K1_FORMS[form] if form in ("rows", "columns") else _lib.TT_K1_AUTO, _stream())
             else:
                 call("tt_gather_pool_norm_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw, _ptr(lens),
                      out.data_ptr(), N, S, D, V, _ptr(flag), _stream())
@@ -163,9 +173,9 @@ def embed_gather(table: torch.Tensor, input_ids: torch.Tensor, check_ids: bool =
     return out
 
 
-def proj_fwd(x, w1, b1, w2, b2) -> Tuple[torch.Tensor, torch.Tensor]:
+def proj_fwd(x, w1, b1, w2, b2, tuning=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """K2 forward: returns (out, h) with h = relu(x w1^T + b1), out = h w2^T + b2.
-    Replaces backend/model.py:33-38,59."""
+    Replaces backend/model.py:33-38,59.  `tuning` (dict / TTTuning): proj_tile, proj_bk, xcd_order."""
     _req(x, "x", torch.float32, 2)
     M, D = x.shape
     P = w1.shape[0]
@@ -177,12 +187,13 @@ def proj_fwd(x, w1, b1, w2, b2) -> Tuple[torch.Tensor, torch.Tensor]:
     out = torch.empty((M, P), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         call("tt_proj_fwd_f32", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-             h.data_ptr(), out.data_ptr(), M, D, P, _stream())
+             h.data_ptr(), out.data_ptr(), M, D, P, _lib.tuning_ref(tuning), _stream())
     return out, h
 
 
-def proj_bwd(d_out, x, h, w2) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """K2 backward for the parameters: returns (dW1, db1, dW2, db2)."""
+def proj_bwd(d_out, x, h, w2, tuning=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """K2 backward for the parameters: returns (dW1, db1, dW2, db2).  `tuning`: proj_tile, proj_bk, tn_tile,
+    tn_transpose, xcd_order."""
     _req(d_out, "d_out", torch.float32, 2)
     _req(x, "x", torch.float32, 2)
     _req(h, "h", torch.float32, 2)
@@ -204,7 +215,8 @@ def proj_bwd(d_out, x, h, w2) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor,
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         call("tt_proj_bwd_f32", d_out.data_ptr(), x.data_ptr(), h.data_ptr(), w2.data_ptr(), dW1.data_ptr(),
-             db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), ws.data_ptr(), nbytes, 0, M, D, P, _stream())
+             db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), ws.data_ptr(), nbytes, 0, M, D, P, _lib.tuning_ref(tuning),
+             _stream())
     return dW1, db1, dW2, db2
 
 

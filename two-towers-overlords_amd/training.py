@@ -16,7 +16,6 @@ from __future__ import annotations
 
 import collections
 import gc
-import os
 import random
 import dataclasses
 import math
@@ -196,7 +195,8 @@ class TripletTrainer:
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
                  process_group=None, engine=None, overlap_streams: Optional[bool] = None,
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
-                 freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: Optional[bool] = None):
+                 freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: bool = False,
+                 gather_under_exchange: bool = True, tuning: Optional[dict] = None):
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -228,8 +228,10 @@ class TripletTrainer:
             overlap_streams = self.device.type == "cuda" and engine is None
         if k1_blocks_per_cu is None:
             k1_blocks_per_cu = _lib.TT_K1_SHARE_AUTO if overlap_streams else 0
+        # `tuning`: tt_tuning fields for THIS trainer's engine (include/tt_hotpath.h; K1 form, tiles, ...): per handle,
+        # nothing process-wide — two trainers in one process may differ
         self.engine = engine if engine is not None else HotPathEngine(table.contiguous(), self.P, max_batch, max_seq_len,
-                                                                      k1_blocks_per_cu=k1_blocks_per_cu)
+                                                                      k1_blocks_per_cu=k1_blocks_per_cu, tuning=tuning)
         self.engine_k1_cap = int(k1_blocks_per_cu or 0)
         n = self.engine.n_params
         self.flat = torch.cat([t.reshape(-1).float() for t in tensors]).to(self.device).contiguous()
@@ -249,14 +251,12 @@ class TripletTrainer:
         if self.world > 1 and exchange is False:
             raise ValueError("exchange=False with more than one replica: the gradients must be summed over the ranks")
         self._exchange = (self.world > 1) if exchange is None else bool(exchange)
-        self._gather_under_exchange = os.environ.get("TT_GATHER_UNDER_EXCHANGE", "1") != "0"  # A/B knob
+        self._gather_under_exchange = bool(gather_under_exchange)  # False: the next gather goes ahead of the projection kernels (A/B)
         self.bucket = torch.empty_like(self.flat) if (self._exchange or self.accumulation_steps > 1) else None
-        # TT_DP_SPLIT=1 / split_exchange=True: the exchange in two parts — the second-layer gradients (dW2, db2 of both
+        # split_exchange=True: the exchange in two parts — the second-layer gradients (dW2, db2 of both
         # towers: complete before the dH -> dW1 chain starts) are reduced and all-reduced on a second stream UNDER that
         # chain, only the first-layer gradients travel after it (see _split_step).  Same sums per element, so with two
-        # replicas bitwise the one-bucket step; an A/B knob until RCCL hardware says which is faster.
-        if split_exchange is None:
-            split_exchange = os.environ.get("TT_DP_SPLIT", "0") == "1"
+        # replicas bitwise the one-bucket step; off by default until RCCL hardware says which is faster.
         self._split = bool(split_exchange) and self._exchange and hasattr(self.engine, "reduce_grads_range")
         if self._split:
             tn = self.engine.n_params // 2                      # floats per tower: W1 | b1 | W2 | b2
@@ -604,7 +604,7 @@ class TripletTrainer:
         return self.calibration
 
     def _split_step(self, local_B: int, first_micro: bool, do_step: bool, issue_next) -> None:
-        """Slab reduce + exchange + Adam with the bucket cut in two (TT_DP_SPLIT=1).  `early` = dW2 / db2 of both
+        """Slab reduce + exchange + Adam with the bucket cut in two (split_exchange=True).  `early` = dW2 / db2 of both
         towers: their slabs are complete when the engine records `_ev_dw2` (inside fwd_bwd, before dH -> dW1), so a
         second stream reduces and all-reduces them while the caller's stream is still computing dW1 / db1; `late` =
         dW1 / db1, reduced and exchanged on the caller's stream after that chain, as the whole bucket is otherwise."""
@@ -645,21 +645,11 @@ class TripletTrainer:
             eng.adam(self.step_count, self.lr, bucket, self.betas[0], self.betas[1], self.eps)
 
     def _all_reduce_parts(self, parts) -> None:
-        """ONE collective launch over several views of the flat bucket (RCCL: a coalesced group)."""
-        views = [self.bucket[off: off + n] for off, n in parts]
-        if dist.get_backend(self.pg) == "nccl":
-            with dist._coalescing_manager(group=self.pg, device=self.device, async_ops=False):
-                for v in views:
-                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg)
-        elif self.device.type == "cpu":
-            import warnings
-
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")  # gloo (CPU rehearsal) has no coalescing manager; this call is its equivalent
-                dist.all_reduce_coalesced(views, op=dist.ReduceOp.SUM, group=self.pg)
-        else:  # gloo with device tensors (ranks sharing a GPU in tests): no coalesced form, one collective per view
-            for v in views:
-                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg)
+        """The views of one part of the flat bucket (W2 | b2 of each tower, or W1 | b1 of each), summed over the
+        replicas: one public `dist.all_reduce` per view, issued back to back on the current stream (the early part's
+        stream is off the critical chain; per-element sums do not depend on how the bucket is cut)."""
+        for off, n in parts:
+            dist.all_reduce(self.bucket[off: off + n], op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
 
     def _all_reduce(self, bucket: torch.Tensor) -> None:
         """The step's one gradient exchange: sum of the flat bucket over the replicas (RCCL over xGMI on GPUs).

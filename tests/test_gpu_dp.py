@@ -55,19 +55,17 @@ def _worker(rank, world, port, q):
         raise
 
 
+def _ranks(worker, world, args=(), salt=0):
+    """Every multi-process test of this file goes through tests/mp_util.run_ranks: the result queue is read with a
+    timeout and ranks still alive after it are killed, so a rank that dies or hangs in native code / a collective
+    fails ITS test instead of stalling the pytest session."""
+    from mp_util import free_port, run_ranks
+
+    return run_ranks(worker, world, args, timeout=420, join=60, port=free_port(29300, 2500, salt))
+
+
 def test_two_ranks_equal_one_rank_and_oracle():
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = 29600 + os.getpid() % 1000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = q.get()
-    for p in procs:
-        p.join(180)
-    assert out[0] == "ok", out[1]
-    assert all(p.exitcode == 0 for p in procs)
-    _, avg2, params2 = out
+    _, avg2, params2 = _ranks(_worker, 2, salt=1)
 
     table, params, batches, _ = _setup()
     st = orc.AdamState(lr=1e-3)
@@ -143,17 +141,7 @@ def test_inbatch_negatives_trainer_vs_oracle(world, Bg):
     """In-batch-negatives loss through the trainer: one rank, and two ranks exchanging document
     embeddings + query ids (all-gather) and the documents' gradient (all-reduce) — equal shards
     and uneven ones (63 = 32 + 31: zero-padded exchange blocks) — against the oracle's autograd."""
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = 29700 + os.getpid() % 1000 + world + Bg
-    procs = [ctx.Process(target=_inbatch_worker, args=(r, world, port, Bg, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    out = q.get()
-    for p in procs:
-        p.join(180)
-    assert out[0] == "ok", out[1]
-    _, avg, params = out
+    _, avg, params = _ranks(_inbatch_worker, world, (Bg,), salt=2 + world + Bg)
     ref_avg, ref_params = _inbatch_reference(Bg)
     assert abs(avg - ref_avg) <= 1e-5
     from conftest import assert_params_close
@@ -211,26 +199,16 @@ def test_run_training_two_ranks_equal_one_rank(cache):
     """run_training launched on two ranks (global batches built identically from a broadcast seed, each rank trains its
     contiguous shard, replicas start from rank 0's projections) ends with the parameters of the one-rank run that
     starts from the same projections."""
-    ctx = mp.get_context("spawn")
     res = {}
     for world in (1, 2):
-        q = ctx.SimpleQueue()
-        port = 29800 + os.getpid() % 1000 + world + (10 if cache else 0)
-        procs = [ctx.Process(target=_rt_worker, args=(r, world, port, cache, q)) for r in range(world)]
-        for p in procs:
-            p.start()
-        out = q.get()
-        for p in procs:
-            p.join(180)
-        assert out[0] == "ok", out[1]
-        res[world] = out[1]
+        res[world] = _ranks(_rt_worker, world, (cache,), salt=40 + world + (10 if cache else 0))[1]
     from conftest import assert_params_close
 
     # both runs start from rank 0's torch.manual_seed(100) initialisation and see the same triplets
     assert_params_close(res[2], res[1], 1e-2, 2 * 5, tight=5e-5)
 
 
-def _rccl_one_rank_worker(port, q):
+def _rccl_one_rank_worker(rank, world, port, q):
     try:
         from two_towers_overlords_amd.training import TripletTrainer
 
@@ -260,17 +238,11 @@ def test_data_parallel_step_over_rccl_single_rank_is_the_single_replica_step():
     stream, the next gather enqueued right before it -> Adam from the bucket) on a ONE-rank NCCL(RCCL) group, where the
     exchange is an identity: bitwise the single-replica step.  Exercises the real RCCL backend and its stream ordering
     against the engine's raw-stream launches (the multi-rank arithmetic is covered over gloo above)."""
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    p = ctx.Process(target=_rccl_one_rank_worker, args=(29900 + os.getpid() % 1000, q))
-    p.start()
-    out = q.get()
-    p.join(180)
-    assert out[0] == "ok", out[1]
+    out = _ranks(_rccl_one_rank_worker, 1, salt=77)
     (l0, f0), (l1, f1), (l2, f2) = out[1]
     assert l0 == l1 == l2
     assert np.array_equal(f0, f1)
-    assert np.array_equal(f0, f2)  # the two-part exchange (TT_DP_SPLIT): coalesced RCCL groups on a second stream
+    assert np.array_equal(f0, f2)  # the two-part exchange (split_exchange=True): its early part on a second stream
 
 
 # --------------------------------------------------------------------------- two-part exchange, two ranks
@@ -305,25 +277,7 @@ def _split_worker(rank, world, port, backend, q):
 
 
 def _run_split(backend):
-    import queue as _queue
-
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29300 + os.getpid() % 500 + (17 if backend == "nccl" else 0)
-    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, backend, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    try:
-        out = q.get(timeout=420)  # a rank that hangs in a collective must fail the test, not the whole session
-    except _queue.Empty:
-        out = ("error", f"no result from the {backend} ranks within 420 s", None)
-    for p in procs:
-        p.join(60)
-        if p.is_alive():
-            p.kill()
-    assert out[0] == "ok", out[1]
-    assert all(p.exitcode == 0 for p in procs)
-    return out[1]
+    return _ranks(_split_worker, 2, (backend,), salt=90 + (17 if backend == "nccl" else 0))[1]
 
 
 def _check_split(res):
@@ -338,7 +292,7 @@ def _check_split(res):
 
 
 def test_split_exchange_two_ranks_is_bitwise_the_one_bucket_exchange():
-    """TT_DP_SPLIT's two-part exchange with the real HIP engine (dW2 / db2 reduced and exchanged on a second stream
+    """split_exchange=True: the two-part exchange with the real HIP engine (dW2 / db2 reduced and exchanged on a second stream
     behind the engine's `dw2` event while dH -> dW1 still run), two ranks sharing the box's GPU over gloo."""
     _check_split(_run_split("gloo"))
 

@@ -234,6 +234,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object (the same measurement at configs[3], V=250k d=768 S=256 B=16384: "
                          "the one configuration whose table streams from HBM; ~10 s extra on the default run)")
+    ap.add_argument("--path", default="engine", choices=["engine", "module"],
+                    help="engine (headline): TripletTrainer on the fused engine.  module: the drop-in surface a user of the "
+                         "reference gets by swapping the imports (INTEGRATION.md section 1) — training.train_epoch over "
+                         "TwoTowersModel.encode_* (autograd Functions over the same kernels), TripletLoss, FusedAdam, "
+                         "per-batch loss.item() like backend/training.py:53 — on pre-tokenised int64 (input_ids, "
+                         "attention_mask) batches; reported under its own metric name")
     ap.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
                     help="a tt_tuning field for this run's engine (include/tt_hotpath.h), e.g. --tune k1_form=stream "
                          "--tune proj_tile=22; repeatable.  Speed only; recorded in config.tuning")
@@ -268,6 +274,11 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    if args.path == "module":
+        if world > 1:
+            sys.exit("--path module is a single-process measurement")
+        print(json.dumps(run_module_path(args, device)))
+        return
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
                     and not args.zipf and not args.ragged and not args.tuning and not args.dp_split)
@@ -314,6 +325,56 @@ def self_launch(args) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool's host driver
     env.setdefault("OMP_NUM_THREADS", "4")
     return subprocess.run(cmd, env=env).returncode
+
+
+def run_module_path(args, device) -> dict:
+    """The reference-signature loop (two-towers-overlords_amd/training.py::train_epoch, backend/training.py:26-63) on the
+    mirrored nn.Modules: K batches after W warm-up batches, timed from the first batch's enqueue to the epoch's return
+    (every batch ends in loss.item(), so the host is in step with the GPU)."""
+    import contextlib
+
+    import two_towers_overlords_amd as pkg
+    from two_towers_overlords_amd.model import EmbeddingOnlyEncoder, TripletLoss, TwoTowersModel
+    from two_towers_overlords_amd.training import FusedAdam, train_epoch
+
+    pkg.load()
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    V, D, P, B, S = cfg["V"], cfg["D"], cfg["P"], cfg["B"], cfg["S"]
+    gt = torch.Generator().manual_seed(1)
+    table = torch.randn(V, D, generator=gt) * 0.02
+    torch.manual_seed(2)
+    model = TwoTowersModel(projection_dim=P, tokenizer=lambda *a, **k: None, pretrained_model=EmbeddingOnlyEncoder(table),
+                           encoder_mode="embed").to(device)
+    crit = TripletLoss(margin=0.3)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    ids = make_ids(V, B, S, 8, seed=1234, device=device, zipf=args.zipf)
+    ones = torch.ones(B, S, dtype=torch.int64, device=device)
+    # what the tokenizer hands over (backend/model.py:43-48): int64 input_ids and attention_mask per encode call
+    distinct = [tuple((b[r].long(), ones) for r in range(3)) for b in ids]
+    seq = lambda n: [distinct[i % len(distinct)] for i in range(n)]
+    with contextlib.redirect_stdout(sys.stderr):  # train_epoch prints every 10th batch's loss, like the reference
+        train_epoch(model, seq(args.warmup), crit, opt, log_wandb=False)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        avg = train_epoch(model, seq(args.steps), crit, opt, log_wandb=False)
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+    return {
+        "metric": "triplets/sec, drop-in MODULE path: training.train_epoch over TwoTowersModel.encode_* + TripletLoss + "
+                  "FusedAdam (autograd Functions over the same HIP kernels, per-batch loss.item()); NOT the BASELINE metric",
+        "value": args.steps * B / elapsed, "unit": "triplets/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["label"], "path": "module", "encoder_mode": "embed", "vocab": V, "embed_dim": D,
+                   "proj_dim": P, "seq_len": S, "batch_per_gpu": B, "global_batch": B,
+                   "ids": "int64 input_ids + int64 attention_mask [B,S] per encode call, " + ("zipf" if args.zipf else "uniform")
+                          + ", full length", "parallelism": "dp1",
+                   "launches_per_step": "K1 x2 (queries; positives+negatives in one document-tower call), projection fwd x2, "
+                                        "triplet fwd+bwd, projection bwd x2 (+ slab reductions), 1 multi-tensor Adam"},
+        "roofline": None, "avg_loss": avg,
+    }
 
 
 def secondary_c4(args, world, rank, device) -> dict:

@@ -247,6 +247,16 @@ int tt_triplet_fwd_bwd_f32(const float* q, const float* p, const float* n, float
                            float* pos_dist, float* neg_dist, float* hinge_rows,
                            float* dq, float* dp, float* dn, tt_stream_t stream);
 
+/*
+ * dist[b] = 1 - cosine_similarity(x[b,:], y[b,:])  (eps 1e-8) — `TripletLoss.cosine_distance`, backend/model.py:132-135 —
+ * and its backward: dx, dy = grad_dist[b] * d dist[b] / d{x, y}[b,:] (torch's autograd through
+ * `1 - F.cosine_similarity(x, y, dim=1)`, including its behaviour for rows with |x| < eps), so that a caller may build
+ * its own loss from the distances like it can with the reference's plain-torch method.   x, y [B,P]; dist, grad_dist [B].
+ */
+int tt_cosine_distance_f32(const float* x, const float* y, int64_t B, int P, float* dist, tt_stream_t stream);
+int tt_cosine_distance_bwd_f32(const float* x, const float* y, const float* grad_dist, int64_t B, int P,
+                               float* dx, float* dy, tt_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* K4 — Adam                                                                   */
 /* ------------------------------------------------------------------------- */
@@ -264,6 +274,22 @@ int tt_triplet_fwd_bwd_f32(const float* q, const float* p, const float* n, float
 int tt_adam_f32(float* params, const float* grads, int nslabs, int64_t slab_stride,
                 float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
                 double beta2, double eps, int64_t step, float grad_scale, tt_stream_t stream);
+
+/*
+ * The same step over SEPARATE tensors in one launch (16 tensors per launch; more are taken in chunks) — what
+ * `optimizer.step()` (backend/training.py:51) does for the 8 trainable tensors of model.parameters()
+ * (backend/training.py:436) when they are ordinary nn.Parameters with autograd-produced .grad tensors rather than
+ * views of one flat buffer.  `tensors`: HOST array; every device pointer 16-byte aligned; all tensors take step `step`.
+ */
+typedef struct {
+  float* param;        /* [n] updated in place */
+  const float* grad;   /* [n] */
+  float* exp_avg;      /* [n] */
+  float* exp_avg_sq;   /* [n] */
+  int64_t n;
+} tt_adam_tensor;
+int tt_adam_multi_f32(const tt_adam_tensor* tensors, int count, double lr, double beta1, double beta2,
+                      double eps, int64_t step, tt_stream_t stream);
 
 /* grad_out[i] (+)= sum_z slabs[z*slab_stride+i] — sums split-K partial gradient slabs. */
 int tt_reduce_slabs_f32(const float* slabs, int nslabs, int64_t slab_stride, float* out,

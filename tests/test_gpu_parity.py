@@ -301,6 +301,70 @@ def test_adam_vs_torch(tt):
     close(v, st["exp_avg_sq"], atol=1e-7)
 
 
+def test_adam_multi_tensor_one_launch_vs_torch(tt):
+    """tt_adam_multi_f32: separate tensors (sizes that are not multiples of 4 or of a workgroup's 1024 elements, one
+    element, more tensors than one launch takes) updated like torch.optim.Adam updates its parameter list."""
+    ops, _ = tt
+    gen = torch.Generator().manual_seed(8)
+    sizes = [147456, 384, 1, 1023, 1025, 4099, 7] + [33 + 4 * i for i in range(12)]  # 19 tensors: two launches
+    refs = [torch.nn.Parameter(torch.randn(n, generator=gen)) for n in sizes]
+    opt = torch.optim.Adam(refs, lr=1e-3)
+    ps = [r.detach().clone().cuda() for r in refs]
+    ms, vs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+    for step in range(1, 6):
+        gs = [torch.randn(n, generator=gen) * (10.0 ** -(step % 4)) for n in sizes]
+        for r, g in zip(refs, gs):
+            r.grad = g.clone()
+        opt.step()
+        ops.adam_step_multi([(p, g.cuda(), m, v) for p, g, m, v in zip(ps, gs, ms, vs)], step, 1e-3)
+    for r, p, m, v in zip(refs, ps, ms, vs):
+        close(p, r.detach(), atol=1e-6)
+        close(m, opt.state[r]["exp_avg"], atol=1e-7)
+        close(v, opt.state[r]["exp_avg_sq"], atol=1e-7)
+    # and bitwise the flat kernel on the same data
+    p1, p2 = torch.randn(5001, generator=gen).cuda(), None
+    p2 = p1.clone()
+    g = torch.randn(5001, generator=gen).cuda()
+    m1, v1, m2, v2 = (torch.zeros(5001).cuda() for _ in range(4))
+    ops.adam_step_flat(p1, g, m1, v1, 3, 1e-3)
+    ops.adam_step_multi([(p2, g, m2, v2)], 3, 1e-3)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+
+
+def test_cosine_distance_is_differentiable_like_the_reference(tt):
+    """`TripletLoss.cosine_distance` is plain autograd-able torch in the reference (backend/model.py:132-135): a loss
+    assembled from it by the caller — here the triplet loss itself, as model.py:137-145 assembles it — must give the
+    reference's value and gradients (golden loss_edges.npz: zero rows, rows below the cosine eps, inactive hinges)."""
+    from two_towers_overlords_amd.model import TripletLoss
+
+    g = load_golden("loss_edges.npz")
+    crit = TripletLoss(margin=float(g["margin"]))
+    q, p, n = (dev(g[k]).requires_grad_(True) for k in "qpn")
+    pd, nd = crit.cosine_distance(q, p), crit.cosine_distance(q, n)
+    close(pd, g["pos_dist"])
+    close(nd, g["neg_dist"])
+    loss = torch.relu(pd - nd + crit.margin).mean()
+    assert abs(loss.item() - float(g["loss"])) <= TOL
+    loss.backward()
+    for a, k in ((q.grad, "dq"), (p.grad, "dp"), (n.grad, "dn")):
+        a_, d_ = a.cpu().numpy(), g[k]
+        scale = np.maximum(1.0, np.abs(d_).max(axis=1, keepdims=True))
+        assert (np.abs(a_ - d_) / scale).max() <= TOL
+    # random shapes against torch's own autograd
+    gen = torch.Generator().manual_seed(12)
+    for B, P in ((33, 40), (5, 1000), (129, 512), (7, 1)):
+        x, y = torch.randn(B, P, generator=gen), torch.randn(B, P, generator=gen)
+        w = torch.randn(B, generator=gen)
+        xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        ((1 - torch.nn.functional.cosine_similarity(xr, yr, dim=1)) * w).sum().backward()
+        xd, yd = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+        d = crit.cosine_distance(xd, yd)
+        (d * w.cuda()).sum().backward()
+        close(d.detach(), 1 - torch.nn.functional.cosine_similarity(x, y, dim=1))
+        close(xd.grad, xr.grad, rel_to_max=True)
+        close(yd.grad, yr.grad, rel_to_max=True)
+
+
 # --------------------------------------------------------------------------- engine: full batch body
 def _flat(params):
     return torch.cat([params[k].reshape(-1) for k in orc.PARAM_KEYS])

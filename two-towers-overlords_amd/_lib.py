@@ -48,6 +48,13 @@ class TTEngineConfig(C.Structure):
     ]
 
 
+class TTAdamTensor(C.Structure):
+    """tt_adam_tensor: one tensor of a multi-tensor Adam launch (device pointers as integers)."""
+
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64)]
+
+
 class TTTuning(C.Structure):
     """tt_tuning (include/tt_hotpath.h): every field 0 = auto.  Speed only, never results."""
 
@@ -117,6 +124,9 @@ SIGNATURES = {
     "tt_proj_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, _i, _tp, _vp]),
     "tt_triplet_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _f, _f, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_adam_f32": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i64, _d, _d, _d, _d, _i64, _f, _vp]),
+    "tt_adam_multi_f32": (_i, [C.POINTER(TTAdamTensor), _i, _d, _d, _d, _d, _i64, _vp]),
+    "tt_cosine_distance_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "tt_cosine_distance_bwd_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "tt_reduce_slabs_f32": (_i, [_vp, _i, _i64, _vp, _i64, _i, _vp]),
     "tt_inbatch_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "tt_inbatch_triplet_fwd_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i64, _i64, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),

@@ -311,6 +311,99 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, c
   }
 }
 
+// Multi-tensor Adam: ONE launch over up to kAdamMaxTensors separate tensors (the reference's optimizer walks the 8
+// trainable tensors of model.parameters(), backend/training.py:436).  A workgroup finds its tensor by
+// scanning the per-tensor first-block table (kernel argument), then does adam_kernel's work on its 1024 elements.
+constexpr int kAdamMaxTensors = 16;
+struct AdamMulti {
+  float* p[kAdamMaxTensors];
+  const float* g[kAdamMaxTensors];
+  float* m[kAdamMaxTensors];
+  float* v[kAdamMaxTensors];
+  long long n[kAdamMaxTensors];
+  int first_block[kAdamMaxTensors + 1];  // first_block[count] = grid size
+  int count;
+};
+
+__global__ __launch_bounds__(kThreads) void adam_multi_kernel(const AdamMulti a, float one_minus_b1, float b2,
+                                                              float one_minus_b2, float step_size, float bc2_sqrt,
+                                                              float eps) {
+  int t = 0;
+#pragma unroll
+  for (int i = 1; i < kAdamMaxTensors; ++i)
+    if (i < a.count && (int)blockIdx.x >= a.first_block[i]) t = i;
+  float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t];
+  float* __restrict__ v = a.v[t];
+  const long long n = a.n[t];
+  const long long i4 = ((long long)((int)blockIdx.x - a.first_block[t]) * kThreads + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 3 < n) {
+    const float4 gs = *reinterpret_cast<const float4*>(g + i4);
+    float4 pp = *reinterpret_cast<float4*>(p + i4);
+    float4 mm = *reinterpret_cast<float4*>(m + i4);
+    float4 vv = *reinterpret_cast<float4*>(v + i4);
+    const float* ge = &gs.x; float* pe = &pp.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) adam_elem(pe[e], me[e], ve[e], ge[e], one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps);
+    *reinterpret_cast<float4*>(p + i4) = pp;
+    *reinterpret_cast<float4*>(m + i4) = mm;
+    *reinterpret_cast<float4*>(v + i4) = vv;
+  } else {
+    for (long long i = i4; i < n; ++i) adam_elem(p[i], m[i], v[i], g[i], one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps);
+  }
+}
+
+// 1 - F.cosine_similarity(x, y, dim=1) per row and its gradient (backend/model.py:132-135), one wave per row, the
+// op order and the closed-form gradient of triplet_kernel (both operands divided by max(|.|, 1e-8), then dotted;
+// d cos(a,b)/da = (v - u cos r)/c with r = c/|a| for |a| > 0, else 0).  g == nullptr: forward only.
+template <int NC>
+__global__ __launch_bounds__(kThreads) void cosine_distance_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                   const float* __restrict__ g, long long B, int P,
+                                                                   float* __restrict__ dist, float* __restrict__ dx,
+                                                                   float* __restrict__ dy) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const long long row = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float eps = 1e-8f;
+  const long long o = row * (long long)P;
+  float xa[NC], xb[NC];
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * TT_WAVE + lane;
+    const bool ok = col < P;
+    xa[c] = ok ? x[o + col] : 0.f;
+    xb[c] = ok ? y[o + col] : 0.f;
+    sa = fmaf(xa[c], xa[c], sa);
+    sb = fmaf(xb[c], xb[c], sb);
+  }
+  const float na = sqrtf(tt_wave_sum(sa)), nb = sqrtf(tt_wave_sum(sb));
+  const float ca = fmaxf(na, eps), cb = fmaxf(nb, eps);
+  float d = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    xa[c] = xa[c] / ca;
+    xb[c] = xb[c] / cb;
+    d = fmaf(xa[c], xb[c], d);
+  }
+  const float cs = tt_wave_sum(d);
+  if (lane == 0 && dist) dist[row] = 1.f - cs;
+  if (!g) return;
+  const float gr = -g[row];  // d(1 - cos) = -d cos
+  const float ra = na > 0.f ? ca / na : 0.f, rb = nb > 0.f ? cb / nb : 0.f;
+  const float ka = cs * ra, kb = cs * rb;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = c * TT_WAVE + lane;
+    if (col < P) {
+      dx[o + col] = gr * ((xb[c] - xa[c] * ka) / ca);
+      dy[o + col] = gr * ((xa[c] - xb[c] * kb) / cb);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs,
                                                                 long long slab_stride,
                                                                 float* __restrict__ out, long long n,
@@ -450,4 +543,74 @@ extern "C" int tt_reduce_slabs_f32(const float* slabs, int nslabs, int64_t slab_
                      (long long)slab_stride, out, (long long)n, accumulate);
   TT_CHECK_LAUNCH();
   return TT_OK;
+}
+
+extern "C" int tt_adam_multi_f32(const tt_adam_tensor* tensors, int count, double lr, double beta1, double beta2,
+                                 double eps, int64_t step, tt_stream_t stream) {
+  TT_REQUIRE(count >= 0 && step >= 1, TT_ERR_BAD_SHAPE);
+  if (count == 0) return TT_OK;
+  TT_REQUIRE(tensors, TT_ERR_NULL_POINTER);
+  for (int i = 0; i < count; ++i) {
+    const tt_adam_tensor& t = tensors[i];
+    TT_REQUIRE(t.n >= 0, TT_ERR_BAD_SHAPE);
+    if (t.n == 0) continue;
+    TT_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq, TT_ERR_NULL_POINTER);
+    TT_REQUIRE(tt_aligned16(t.param) && tt_aligned16(t.grad) && tt_aligned16(t.exp_avg) && tt_aligned16(t.exp_avg_sq),
+               TT_ERR_ALIGNMENT);
+  }
+  const double bc1 = 1.0 - pow(beta1, (double)step);   // in double on the host, as torch does for a python-float step
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  for (int base = 0; base < count; base += kAdamMaxTensors) {
+    AdamMulti a{};
+    long long blocks = 0;
+    for (int i = base; i < count && a.count < kAdamMaxTensors; ++i) {
+      const tt_adam_tensor& t = tensors[i];
+      if (t.n == 0) continue;
+      const int k = a.count++;
+      a.p[k] = t.param; a.g[k] = t.grad; a.m[k] = t.exp_avg; a.v[k] = t.exp_avg_sq; a.n[k] = t.n;
+      a.first_block[k] = (int)blocks;
+      blocks += ((t.n + 3) / 4 + kThreads - 1) / kThreads;
+      TT_REQUIRE(blocks <= 0x7fffffffLL, TT_ERR_BAD_SHAPE);
+    }
+    if (a.count == 0) continue;
+    a.first_block[a.count] = (int)blocks;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps);
+    TT_CHECK_LAUNCH();
+  }
+  return TT_OK;
+}
+
+static int launch_cosine_distance(const float* x, const float* y, const float* g, int64_t B, int P, float* dist, float* dx,
+                                  float* dy, hipStream_t st) {
+  const dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
+  const int nc = (P + TT_WAVE - 1) / TT_WAVE;
+#define TT_COSD(NC) hipLaunchKernelGGL((cosine_distance_kernel<NC>), grid, block, 0, st, x, y, g, (long long)B, P, dist, dx, dy)
+  if (nc <= 1) TT_COSD(1);
+  else if (nc <= 2) TT_COSD(2);
+  else if (nc <= 4) TT_COSD(4);
+  else if (nc <= 6) TT_COSD(6);
+  else if (nc <= 8) TT_COSD(8);
+  else if (nc <= 12) TT_COSD(12);
+  else if (nc <= 16) TT_COSD(16);
+  else return TT_ERR_UNSUPPORTED;  // P > 1024
+#undef TT_COSD
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
+extern "C" int tt_cosine_distance_f32(const float* x, const float* y, int64_t B, int P, float* dist, tt_stream_t stream) {
+  TT_REQUIRE(x && y && dist, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(B >= 0 && P >= 1 && P <= 1024, TT_ERR_BAD_SHAPE);
+  if (B == 0) return TT_OK;
+  return launch_cosine_distance(x, y, nullptr, B, P, dist, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tt_cosine_distance_bwd_f32(const float* x, const float* y, const float* grad_dist, int64_t B, int P,
+                                          float* dx, float* dy, tt_stream_t stream) {
+  TT_REQUIRE(x && y && grad_dist && dx && dy, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(B >= 0 && P >= 1 && P <= 1024, TT_ERR_BAD_SHAPE);
+  if (B == 0) return TT_OK;
+  return launch_cosine_distance(x, y, grad_dist, B, P, nullptr, dx, dy, static_cast<hipStream_t>(stream));
 }

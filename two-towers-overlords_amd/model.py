@@ -67,6 +67,22 @@ class _TripletLossFn(torch.autograd.Function):
         return g * dq, g * dp, g * dn, None
 
 
+class _CosineDistanceFn(torch.autograd.Function):
+    """1 - F.cosine_similarity(x, y, dim=1) (backend/model.py:132-135) with torch's gradient, on the device."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
+        ctx.save_for_backward(x, y)
+        return ops.cosine_distance(x, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        dx, dy = ops.cosine_distance_bwd(x, y, g.contiguous())
+        return dx, dy
+
+
 class AveragePoolingTower(nn.Module):
     """Frozen token embeddings -> masked average pool -> L2 normalise -> trainable
     projection.  Mirrors backend/model.py:13-72.
@@ -237,12 +253,9 @@ class TripletLoss(nn.Module):
         self.margin = margin
 
     def cosine_distance(self, x: Tensor, y: Tensor) -> Tensor:
-        """1 - cosine_similarity(x, y, dim=1) (model.py:132-135).  Evaluation helper:
-        not differentiable here (the differentiable use is inside `forward`)."""
-        if x.requires_grad or y.requires_grad:
-            x, y = x.detach(), y.detach()
-        _, pos_dist, _, _, _, _ = ops.triplet_fwd_bwd(x.contiguous(), y.contiguous(), y.contiguous(), 0.0, need_grad=False)
-        return pos_dist
+        """1 - cosine_similarity(x, y, dim=1) (model.py:132-135); differentiable like the reference's plain-torch
+        method, so a caller may build its own loss from it (`forward` fuses the whole triplet loss instead)."""
+        return _CosineDistanceFn.apply(x, y)
 
     def forward(self, anchor: Tensor, positive: Tensor, negative: Tensor) -> Tensor:
         return _TripletLossFn.apply(anchor, positive, negative, self.margin)

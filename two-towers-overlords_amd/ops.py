@@ -259,6 +259,53 @@ def adam_step_flat(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, bet
              lr, beta1, beta2, eps, step, grad_scale, _stream())
 
 
+def adam_step_multi(tensors, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8) -> None:
+    """K4 over separate tensors in ONE launch (tt_adam_multi_f32): `tensors` = [(param, grad, exp_avg, exp_avg_sq), ...],
+    each a contiguous fp32 GPU tensor of the same numel; all take optimizer step `step` (1-based)."""
+    if not tensors:
+        return
+    arr = (_lib.TTAdamTensor * len(tensors))()
+    dev = tensors[0][0].device
+    for i, quad in enumerate(tensors):
+        n = quad[0].numel()
+        for t, name in zip(quad, ("param", "grad", "exp_avg", "exp_avg_sq")):
+            _req(t, name, torch.float32)
+            if t.numel() != n or t.device != dev:
+                raise ValueError(f"{name} of tensor {i}: expected {n} elements on {dev}")
+        arr[i].param, arr[i].grad, arr[i].exp_avg, arr[i].exp_avg_sq = (t.data_ptr() for t in quad)
+        arr[i].n = n
+    with torch.cuda.device(dev):
+        call("tt_adam_multi_f32", arr, len(tensors), lr, beta1, beta2, eps, int(step), _stream())
+
+
+def cosine_distance(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """1 - cosine_similarity(x, y, dim=1) -> [B] (backend/model.py:132-135), forward only."""
+    _req(x, "x", torch.float32, 2)
+    _req(y, "y", torch.float32, 2)
+    if x.shape != y.shape or x.device != y.device:
+        raise ValueError("cosine_distance: x and y must have the same [B, P] shape and device")
+    B, P = x.shape
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        call("tt_cosine_distance_f32", x.data_ptr(), y.data_ptr(), B, P, out.data_ptr(), _stream())
+    return out
+
+
+def cosine_distance_bwd(x: torch.Tensor, y: torch.Tensor, grad_dist: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dx, dy) = grad_dist[b] * d(1 - cos(x_b, y_b)) / d{x_b, y_b}."""
+    _req(x, "x", torch.float32, 2)
+    _req(y, "y", torch.float32, 2)
+    _req(grad_dist, "grad_dist", torch.float32, 1)
+    B, P = x.shape
+    if tuple(y.shape) != (B, P) or grad_dist.shape[0] != B:
+        raise ValueError("cosine_distance_bwd: inconsistent shapes")
+    dx, dy = torch.empty_like(x), torch.empty_like(y)
+    with torch.cuda.device(x.device):
+        call("tt_cosine_distance_bwd_f32", x.data_ptr(), y.data_ptr(), grad_dist.data_ptr(), B, P, dx.data_ptr(), dy.data_ptr(),
+             _stream())
+    return dx, dy
+
+
 def cosine_scores(q: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
     """out[i, j] = cosine_similarity(q[i], d[j]) for all pairs -> [Q, N] (MFMA GEMM on unit rows).
     Replaces the per-query `torch.cosine_similarity(query_embed.cpu(), doc_embeds.cpu(), dim=1)`

@@ -42,9 +42,10 @@ except Exception:  # pragma: no cover
 # --------------------------------------------------------------------------- #
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr) with the defaults the reference uses
-    (backend/training.py:436: betas (0.9, 0.999), eps 1e-8, no weight decay), each
-    parameter updated by the K4 kernel.  Parameters without a gradient are skipped,
-    as torch does for the frozen encoder."""
+    (backend/training.py:436: betas (0.9, 0.999), eps 1e-8, no weight decay): ONE K4
+    launch per step for all parameters that share a step count (tt_adam_multi_f32 —
+    the eight trainable tensors of the two towers).  Parameters without
+    a gradient are skipped, as torch does for the frozen encoder."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
@@ -54,6 +55,7 @@ class FusedAdam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            by_step = {}  # parameters whose step counts differ (one had no gradient for a while) go in separate launches
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -63,8 +65,11 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                ops.adam_step_flat(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1),
-                                   st["exp_avg_sq"].view(-1), st["step"], group["lr"], b1, b2, group["eps"])
+                if not p.data.is_contiguous():
+                    raise ValueError("FusedAdam: parameters must be contiguous")
+                by_step.setdefault(st["step"], []).append((p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"]))
+            for step, quads in by_step.items():
+                ops.adam_step_multi(quads, step, group["lr"], b1, b2, group["eps"])
         return loss
 
 
@@ -72,12 +77,35 @@ class FusedAdam(torch.optim.Optimizer):
 # Reference-signature loops (module path)
 # --------------------------------------------------------------------------- #
 def _encode3(model, queries, positives, negatives):
-    """The three encodes of backend/training.py:40-42, in that order.  Batches may
-    be the reference's string lists or pre-tokenised (input_ids, attention_mask) pairs."""
+    """The three encodes of backend/training.py:40-42.  Batches may be the reference's string lists or pre-tokenised
+    (input_ids, attention_mask) pairs.  The positives and the negatives both go through the DOCUMENT tower, so they are
+    encoded in one call — one gather+pool launch and one projection instead of two of each, and one backward through the
+    tower (its gradient is the sum over both row blocks either way) — and split afterwards; padding a shorter block
+    with masked-out zeros changes nothing (masked tokens are never read)."""
     if isinstance(queries, (list, tuple)) and len(queries) and isinstance(queries[0], str):
-        return model.encode_queries(queries), model.encode_documents(positives), model.encode_documents(negatives)
-    return (model.encode_query_ids(*queries), model.encode_document_ids(*positives),
-            model.encode_document_ids(*negatives))
+        docs = model.encode_documents(list(positives) + list(negatives))
+        positive_embeds, negative_embeds = torch.split(docs, [len(positives), len(negatives)])
+        return model.encode_queries(queries), positive_embeds, negative_embeds
+    (ip, mp), (i_n, mn) = _ids_mask(positives), _ids_mask(negatives)
+    if ip.dim() != 2 or ip.dtype != i_n.dtype or (mp is not None and mn is not None and mp.dtype != mn.dtype):
+        return (model.encode_query_ids(*queries), model.encode_document_ids(*positives), model.encode_document_ids(*negatives))
+    S = max(ip.shape[1], i_n.shape[1])
+    if mp is None and mn is None and ip.shape[1] == i_n.shape[1]:
+        ids, mask = torch.cat([ip, i_n]), None
+    else:
+        pad = lambda t, fill: t if t.shape[1] == S else torch.nn.functional.pad(t, (0, S - t.shape[1]), value=fill)
+        ones = lambda i, m: torch.ones_like(i) if m is None else m
+        ids = torch.cat([pad(ip, 0), pad(i_n, 0)])
+        mask = torch.cat([pad(ones(ip, mp), 0), pad(ones(i_n, mn), 0)])
+    docs = model.encode_document_ids(ids, mask)
+    positive_embeds, negative_embeds = torch.split(docs, [ip.shape[0], i_n.shape[0]])
+    return model.encode_query_ids(*queries), positive_embeds, negative_embeds
+
+
+def _ids_mask(pair):
+    if isinstance(pair, torch.Tensor):
+        return pair, None
+    return (pair[0], pair[1] if len(pair) > 1 else None)
 
 
 def train_epoch(model: TwoTowersModel, dataloader, criterion: TripletLoss, optimizer: torch.optim.Optimizer,

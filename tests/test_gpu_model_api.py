@@ -104,42 +104,47 @@ def test_train_epoch_module_path_matches_reference(name, opt):
         assert_params_close(sd[k].cpu().numpy(), g["final/" + k], lr, len(texts))
 
 
-def test_train_epoch_on_pretokenised_batches_one_document_call_one_adam_launch(monkeypatch):
-    """The module path on (input_ids, attention_mask) batches: positives and negatives go through the document tower
-    in ONE call (the negatives' block arrives 5 columns wider here: padded with masked-out zeros, which changes
-    nothing), `FusedAdam.step` is ONE multi-tensor launch for the eight tensors, and the epoch is the reference's."""
+def test_train_epoch_on_pretokenised_batches_one_gather_one_adam_launch(monkeypatch):
+    """The module path on (input_ids, attention_mask) batches: both towers gather from the SAME frozen table here, so
+    queries, positives and negatives are pooled by ONE gather+pool call (the negatives' block arrives 5 columns wider:
+    padded with masked-out zeros, which changes nothing) and the positives + negatives take ONE pass through the
+    document tower's projection; `FusedAdam.step` is ONE multi-tensor launch for the eight tensors; the epoch is the
+    reference's.  With towers that hold separate tables the queries keep their own gather (second half)."""
     from two_towers_overlords_amd import ops
-    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.model import EmbeddingOnlyEncoder, TripletLoss
     from two_towers_overlords_amd.training import FusedAdam, train_epoch
 
     g = load_golden("step_mid.npz")
-    m, _ = build_model(g)
     nb, lr = int(g["n_batches"]), float(g["lr"])
     pad = lambda t: torch.nn.functional.pad(t, (0, 5))
     batches = [((T(g[f"batch{i}/ids_q"]).cuda(), T(g[f"batch{i}/mask_q"]).cuda()),
                 (T(g[f"batch{i}/ids_p"]).cuda(), T(g[f"batch{i}/mask_p"]).cuda()),
                 (pad(T(g[f"batch{i}/ids_n"])).cuda(), pad(T(g[f"batch{i}/mask_n"])).cuda())) for i in range(nb)]
-    calls = {"doc": 0, "adam": 0, "tensors": 0}
-    doc_ids = m.document_tower.encode_ids
-    multi = ops.adam_step_multi
+    gather, multi = ops.gather_pool_norm, ops.adam_step_multi
+    for separate_tables, gathers_per_batch in ((False, 1), (True, 2)):
+        m, _ = build_model(g)
+        if separate_tables:  # the reference's layout: one private frozen model per tower (backend/model.py:84-85)
+            m.document_tower.pretrained_model = EmbeddingOnlyEncoder(T(g["table"]).clone()).cuda()
+        calls = {"gather": 0, "adam": 0, "tensors": 0}
 
-    def count_doc(*a, **kw):
-        calls["doc"] += 1
-        return doc_ids(*a, **kw)
+        def count_gather(*a, **kw):
+            calls["gather"] += 1
+            return gather(*a, **kw)
 
-    def count_adam(quads, *a, **kw):
-        calls["adam"] += 1
-        calls["tensors"] += len(quads)
-        return multi(quads, *a, **kw)
+        def count_adam(quads, *a, **kw):
+            calls["adam"] += 1
+            calls["tensors"] += len(quads)
+            return multi(quads, *a, **kw)
 
-    monkeypatch.setattr(m.document_tower, "encode_ids", count_doc)
-    monkeypatch.setattr(ops, "adam_step_multi", count_adam)
-    avg = train_epoch(m, batches, TripletLoss(margin=float(g["margin"])), FusedAdam(m.parameters(), lr=lr), log_wandb=False)
-    assert calls == {"doc": nb, "adam": nb, "tensors": 8 * nb}
-    assert abs(avg - float(g["epoch/avg_loss"])) <= TOL
-    sd = m.state_dict()
-    for k in orc.PARAM_KEYS:
-        assert_params_close(sd[k].cpu().numpy(), g["final/" + k], lr, nb)
+        monkeypatch.setattr(ops, "gather_pool_norm", count_gather)
+        monkeypatch.setattr(ops, "adam_step_multi", count_adam)
+        opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=lr)
+        avg = train_epoch(m, batches, TripletLoss(margin=float(g["margin"])), opt, log_wandb=False)
+        assert calls == {"gather": gathers_per_batch * nb, "adam": nb, "tensors": 8 * nb}
+        assert abs(avg - float(g["epoch/avg_loss"])) <= TOL
+        sd = m.state_dict()
+        for k in orc.PARAM_KEYS:
+            assert_params_close(sd[k].cpu().numpy(), g["final/" + k], lr, nb)
 
 
 @pytest.mark.parametrize("overlap", [False, True])

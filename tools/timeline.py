@@ -6,13 +6,29 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-short = lambda n: ("K1 gather" if "pool_sliced" in n else "K1 combine" if "pool_combine" in n else "K1 stream" if "pool_norm_stream" in n else "K1 per-text" if "pool_norm" in n else
-                   "dW2+dH (TN+NN)" if "gemm_tn_nn" in n else "adam" if "adam_kernel" in n else "triplet+mean" if "triplet_kernel" in n and "true" in n else
-                   "triplet" if "triplet_kernel" in n else "loss mean" if "loss_mean" in n else
-                   ("gemm TN" if "<2," in n.split("gemm_f32_kernel")[-1][:4] else "gemm NN" if "<1," in n.split("gemm_f32_kernel")[-1][:4] else "gemm NT") if "gemm_f32_kernel" in n else n[:30])
+def short(n):
+    tail = n.split("gemm_f32")[-1]
+    if "pool_colsliced" in n: return "K1 gather (columns)"
+    if "pool_colnorm" in n: return "K1 norm"
+    if "pool_sliced" in n: return "K1 gather (rows)"
+    if "pool_combine" in n: return "K1 combine"
+    if "pool_norm_stream" in n: return "K1 stream"
+    if "pool_norm" in n: return "K1 per-text"
+    if "gemm_tn_nn" in n: return "dW2+dH (TN+NN)"
+    if "adam_multi" in n: return "adam (multi)"
+    if "adam_kernel" in n: return "adam"
+    if "triplet_kernel" in n: return "triplet+mean" if "true" in n else "triplet"
+    if "loss_mean" in n: return "loss mean"
+    if "reduce_slabs" in n: return "reduce slabs"
+    if "gemm_f32" in n:
+        lay = tail.split("<")[1][:1] if "<" in tail else "?"
+        return {"0": "gemm NT", "1": "gemm NN", "2": "gemm TN"}.get(lay, "gemm") + (" bk16" if "bk16" in n else "")
+    return n[:30]
+
+
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], short(r["Kernel_Name"])) for r in rows]
 ks.sort()
-adam = [i for i, k in enumerate(ks) if k[3] == "adam"]
+adam = [i for i, k in enumerate(ks) if k[3].startswith("adam")]
 if len(adam) < first + nsteps + 1:
     first = max(0, len(adam) - nsteps - 1)
 lo, hi = ks[adam[first]][1], ks[adam[first + nsteps]][1]

@@ -239,6 +239,9 @@ extern "C" int tt_proj_bwd_f32(const float* dOut, const float* X, const float* H
   t.gb2 = t.gW2 + (int64_t)P * P;
   int rc = ttp::backward(&t, 1, D, P, ns, stride, st, ttp::plan_of(tuning));
   if (rc != TT_OK) return rc;
+  // outputs laid out like a tower's slab (dW1 | db1 | dW2 | db2 contiguous): one reduction launch instead of four
+  if (db1 == dW1 + (int64_t)P * D && dW2 == db1 + P && db2 == dW2 + (int64_t)P * P)
+    return tt_reduce_slabs_f32(t.gW1, ns, stride, dW1, tower_floats(D, P), accumulate, stream);
   rc = tt_reduce_slabs_f32(t.gW1, ns, stride, dW1, (int64_t)P * D, accumulate, stream);
   if (rc != TT_OK) return rc;
   rc = tt_reduce_slabs_f32(t.gb1, ns, stride, db1, P, accumulate, stream);

@@ -58,13 +58,14 @@ class _TripletLossFn(torch.autograd.Function):
         loss, _, _, dq, dp, dn = ops.triplet_fwd_bwd(
             anchor.contiguous(), positive.contiguous(), negative.contiguous(), float(margin)
         )
-        ctx.save_for_backward(dq, dp, dn)
+        ctx.save_for_backward(dq._base)  # dq, dp, dn are the three rows of ONE [3, B, P] buffer
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        dq, dp, dn = ctx.saved_tensors
-        return g * dq, g * dp, g * dn, None
+        (d,) = ctx.saved_tensors
+        gd = g * d  # one launch for the three gradients
+        return gd[0], gd[1], gd[2], None
 
 
 class _CosineDistanceFn(torch.autograd.Function):
@@ -148,10 +149,13 @@ class AveragePoolingTower(nn.Module):
     # -- the reference entry point ------------------------------------------------
     def forward(self, texts: list[str]) -> Tensor:
         """model.py:40-60: tokenize, move to the model's device, pool, project."""
+        return self.encode_tokens(self.tokenize(texts))
+
+    def tokenize(self, texts: list[str]) -> dict:
+        """model.py:43-48: the tokenizer call and the `.to(device)` of its tensors."""
         tokens = self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=512)
         device = _module_device(self.pretrained_model)
-        tokens = {k: v.to(device) for k, v in tokens.items()}
-        return self.encode_tokens(tokens)
+        return {k: v.to(device) for k, v in tokens.items()}
 
     # -- tensor-level entry points (additive) -------------------------------------
     def embedding_table(self) -> Tensor:
@@ -173,7 +177,10 @@ class AveragePoolingTower(nn.Module):
             return ops.pool_norm_dense(hidden, None if mask is None else mask.contiguous())
 
     def encode_tokens(self, tokens: dict) -> Tensor:
-        pooled = self.pool_tokens(tokens)
+        return self.project(self.pool_tokens(tokens))
+
+    def project(self, pooled: Tensor) -> Tensor:
+        """model.py:59: the trainable Linear -> ReLU -> Linear on pooled, normalised rows [B, D]."""
         p = self.projection
         return _ProjectionFn.apply(pooled, p[0].weight, p[0].bias, p[2].weight, p[2].bias)
 

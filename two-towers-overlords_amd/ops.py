@@ -203,10 +203,12 @@ def proj_bwd(d_out, x, h, w2, tuning=None) -> Tuple[torch.Tensor, torch.Tensor, 
     if tuple(x.shape) != (M, D) or tuple(h.shape) != (M, P) or tuple(w2.shape) != (P, P):
         raise ValueError("proj_bwd: inconsistent shapes")
     dev = x.device
-    dW1 = torch.empty((P, D), dtype=torch.float32, device=dev)
-    db1 = torch.empty((P,), dtype=torch.float32, device=dev)
-    dW2 = torch.empty((P, P), dtype=torch.float32, device=dev)
-    db2 = torch.empty((P,), dtype=torch.float32, device=dev)
+    # one buffer in the tower's flat layout (dW1 | db1 | dW2 | db2): the slab sums then leave in ONE launch
+    flat = torch.empty(P * D + P + P * P + P, dtype=torch.float32, device=dev)
+    dW1 = flat[: P * D].view(P, D)
+    db1 = flat[P * D: P * D + P]
+    dW2 = flat[P * D + P: P * D + P + P * P].view(P, P)
+    db2 = flat[P * D + P + P * P:]
     if M == 0:
         for t in (dW1, db1, dW2, db2):
             t.zero_()
@@ -238,7 +240,7 @@ def triplet_fwd_bwd(q, p, n, margin: float, grad_scale: Optional[float] = None, 
     hinge = torch.empty(B, dtype=torch.float32, device=dev)
     dq = dp = dn = None
     if need_grad:
-        dq, dp, dn = (torch.empty_like(q) for _ in range(3))
+        dq, dp, dn = torch.empty((3, B, P), dtype=torch.float32, device=dev).unbind(0)  # one buffer: see _TripletLossFn
     gs = (1.0 / B) if grad_scale is None else grad_scale
     with torch.cuda.device(dev):
         call("tt_triplet_fwd_bwd_f32", q.data_ptr(), p.data_ptr(), n.data_ptr(), margin, gs, B, P, loss.data_ptr(),

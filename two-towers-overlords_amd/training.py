@@ -83,23 +83,42 @@ def _encode3(model, queries, positives, negatives):
     tower (its gradient is the sum over both row blocks either way) — and split afterwards; padding a shorter block
     with masked-out zeros changes nothing (masked tokens are never read)."""
     if isinstance(queries, (list, tuple)) and len(queries) and isinstance(queries[0], str):
-        docs = model.encode_documents(list(positives) + list(negatives))
-        positive_embeds, negative_embeds = torch.split(docs, [len(positives), len(negatives)])
-        return model.encode_queries(queries), positive_embeds, negative_embeds
+        dt = model.document_tower
+        if getattr(dt, "encoder_mode", None) != "embed":  # `bert` mode: the encoder wants every tokenizer field; two calls
+            return model.encode_queries(queries), model.encode_documents(positives), model.encode_documents(negatives)
+        tp, tn = dt.tokenize(positives), dt.tokenize(negatives)  # the reference's two tokenizer calls (model.py:43-48)
+        query_embeds = model.encode_queries(queries)
+        _, p_emb, n_emb = _encode3(model, None, (tp["input_ids"], tp.get("attention_mask")),
+                                   (tn["input_ids"], tn.get("attention_mask")))
+        return query_embeds, p_emb, n_emb
     (ip, mp), (i_n, mn) = _ids_mask(positives), _ids_mask(negatives)
+    enc_q = (lambda: None) if queries is None else (lambda: model.encode_query_ids(*queries))
     if ip.dim() != 2 or ip.dtype != i_n.dtype or (mp is not None and mn is not None and mp.dtype != mn.dtype):
-        return (model.encode_query_ids(*queries), model.encode_document_ids(*positives), model.encode_document_ids(*negatives))
-    S = max(ip.shape[1], i_n.shape[1])
-    if mp is None and mn is None and ip.shape[1] == i_n.shape[1]:
-        ids, mask = torch.cat([ip, i_n]), None
+        return (enc_q(), model.encode_document_ids(ip, mp), model.encode_document_ids(i_n, mn))
+    blocks = [(ip, mp), (i_n, mn)]
+    qt, dt = model.query_tower, model.document_tower
+    if (queries is not None and getattr(qt, "encoder_mode", None) == "embed" == getattr(dt, "encoder_mode", None)
+            and qt.embedding_table().data_ptr() == dt.embedding_table().data_ptr()):
+        iq, mq = _ids_mask(queries)
+        if iq.dim() == 2 and iq.dtype == ip.dtype and (mq is None or mp is None or mq.dtype == mp.dtype):
+            blocks.insert(0, (iq, mq))  # both towers gather from the SAME frozen table: one gather+pool for all three roles
+    S = max(i.shape[1] for i, _ in blocks)
+    if all(m is None for _, m in blocks) and all(i.shape[1] == S for i, _ in blocks):
+        ids, mask = torch.cat([i for i, _ in blocks]), None
     else:
         pad = lambda t, fill: t if t.shape[1] == S else torch.nn.functional.pad(t, (0, S - t.shape[1]), value=fill)
-        ones = lambda i, m: torch.ones_like(i) if m is None else m
-        ids = torch.cat([pad(ip, 0), pad(i_n, 0)])
-        mask = torch.cat([pad(ones(ip, mp), 0), pad(ones(i_n, mn), 0)])
-    docs = model.encode_document_ids(ids, mask)
+        ids = torch.cat([pad(i, 0) for i, _ in blocks])
+        mask = torch.cat([pad(torch.ones_like(i) if m is None else m, 0) for i, m in blocks])
+    if len(blocks) == 3:
+        pooled = dt.pool_tokens({"input_ids": ids} if mask is None else {"input_ids": ids, "attention_mask": mask})
+        nq = blocks[0][0].shape[0]
+        query_embeds = qt.project(pooled[:nq])
+        docs = dt.project(pooled[nq:])
+    else:
+        query_embeds = enc_q()
+        docs = model.encode_document_ids(ids, mask)
     positive_embeds, negative_embeds = torch.split(docs, [ip.shape[0], i_n.shape[0]])
-    return model.encode_query_ids(*queries), positive_embeds, negative_embeds
+    return query_embeds, positive_embeds, negative_embeds
 
 
 def _ids_mask(pair):
@@ -113,18 +132,26 @@ def train_epoch(model: TwoTowersModel, dataloader, criterion: TripletLoss, optim
     """Train for one epoch.  Mirrors backend/training.py:26-63 line for line."""
     total_loss = 0.0
     num_batches = 0
+    pending = []  # device-side losses not yet read: `loss.item()` (training.py:53) stalls the host on every batch, so the
+    #               values are read when something needs them — the every-10th-batch print, wandb, the return — in order
     for queries, positives, negatives in dataloader:
         optimizer.zero_grad()
         query_embeds, positive_embeds, negative_embeds = _encode3(model, queries, positives, negatives)
         loss = criterion(query_embeds, positive_embeds, negative_embeds)
         loss.backward()
         optimizer.step()
-        total_loss += loss.item()
+        pending.append(loss.detach())
         num_batches += 1
         if log_wandb and _HAVE_WANDB:
             wandb.log({"batch_loss": loss.item(), "batch": num_batches})
         if num_batches % 10 == 0:
+            for v in torch.stack(pending).tolist():  # the same float additions, in the same order, as a per-batch .item()
+                total_loss += v
+            pending.clear()
             print(f"Batch {num_batches}, Loss: {loss.item():.4f}")
+    if pending:
+        for v in torch.stack(pending).tolist():
+            total_loss += v
     return total_loss / num_batches
 
 

@@ -55,6 +55,10 @@ CONFIGS = {
     "c4": dict(V=250000, D=768, P=768, B=16384, S=256, label="configs[3]: synthetic V=250k d=768 proj 768 batch 16384/GPU seq 256 (HBM stress)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+# MI355X_MICROARCH.md "Indexed rows: gather into LDS": rows shared by every workgroup and served by the XCD's L2 are
+# gathered at 66-73 GB/s per CU = 16.8-18.8 TB/s chip-wide — the ceiling that binds a gather whose table is cache-resident
+L2_SHARED_ROWS_GBS = (16800.0, 18800.0)
+CONFIG0 = dict(V=30522, D=384, P=64, B=256, S=128)  # BASELINE.json configs[0]: --batch-size 256 --projection-dim 64 (reference README.md:64-75)
 
 
 def k1_algorithmic_bytes(n_texts, S, D):
@@ -75,7 +79,7 @@ def make_ids(V, B, S, n_batches, seed, device, zipf=False):
     return out
 
 
-def cpu_baseline(cfg, budget_s=20.0):
+def cpu_baseline(cfg, budget_s=20.0, max_batches=64):
     """Oracle train_epoch (torch-CPU restatement of backend/training.py:26-63) on all host cores."""
     from oracle import two_towers_oracle as orc
 
@@ -100,7 +104,7 @@ def cpu_baseline(cfg, budget_s=20.0):
         orc.train_epoch(table, [batch], params, st, 0.3, doc_table=doc_table)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 64:
+        if el > budget_s or n >= max_batches:
             break
     return {
         "value": n * B / el, "unit": "triplets/s", "cores": cores, "kind": "port",
@@ -243,12 +247,17 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
                     help="a tt_tuning field for this run's engine (include/tt_hotpath.h), e.g. --tune k1_form=stream "
                          "--tune proj_tile=22; repeatable.  Speed only; recorded in config.tuning")
+    ap.add_argument("--event-scope", type=int, default=None, choices=[1, 2, 3],
+                    help="release scope of the events that order the gather stream and the caller's stream, and the engine's "
+                         "two streams (1 no system-scope fence [default], 2 device-scope release, 3 HIP's default events)")
     ap.add_argument("--dp-split", action="store_true",
                     help="data-parallel step with the exchange in two parts (TripletTrainer(split_exchange=True))")
     ap.add_argument("--no-cpu-baseline-bert", action="store_true",
                     help="skip `cpu_baseline_bert` (the reference's executed CPU path: frozen MiniLM-shaped encoder, ~10 s)")
     args = ap.parse_args()
     args.tuning = {}
+    if args.event_scope:
+        args.tuning["event_scope"] = args.event_scope
     for kv in args.tune:
         k, _, v = kv.partition("=")
         args.tuning[k] = v if not v.lstrip("-").isdigit() else int(v)
@@ -295,6 +304,12 @@ def main():
                 result["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         if args.cpu_baseline_later and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(CONFIGS[args.config])
+        if not args.no_cpu_baseline:  # the reference's own CPU-runnable case (BASELINE.json configs[0]: B = 256, P = 64)
+            try:
+                result["cpu_baseline_configs0"] = cpu_baseline(CONFIG0, budget_s=6.0, max_batches=400)
+            except Exception as e:
+                result["cpu_baseline_configs0"] = {"value": None, "unit": "triplets/s", "kind": "port",
+                                                   "sample": f"not measured: {type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and not args.no_cpu_baseline_bert:
             try:
                 result["cpu_baseline_bert"] = cpu_baseline_bert(CONFIGS[args.config])
@@ -650,6 +665,7 @@ def run_config(args, world, rank, device) -> dict:
                    "backend": (args.backend if world > 1 else None), "ids": "int32 [3,B,S], "
                    + ("zipf" if args.zipf else "uniform") + (", ragged lengths" if args.ragged else ", full length"), "parallelism": f"dp{world}", "inputs": args.inputs,
                    "k1_only": bool(args.k1_only), "tuning": (trainer.engine.tuning or None),
+                   "event_scope": getattr(trainer, "event_scope", None),
                    "gather_overlap": ("side stream, " + ("K1's LDS reservation paired with the projection tile (auto)"
                                                        if trainer.engine_k1_cap < 0 else
                                                        "K1 capped at %d workgroups/CU" % trainer.engine_k1_cap))
@@ -674,7 +690,17 @@ def run_config(args, world, rank, device) -> dict:
                      "served_from": ("XCD L2 + Infinity Cache (the table fits the 256 MiB Infinity Cache)"
                                      if V * D * 4 <= 200e6 else "HBM (the table exceeds the Infinity Cache)"),
                      "alone": {"avg_launch_ms": iso_ms, "achieved": alg / (iso_ms * 1e-3) / 1e9,
-                               "frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                               "frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     # the bound that BINDS: HBM where the table streams from it; for a cache-resident table the rate at
+                     # which rows shared by all workgroups come out of the XCDs' L2s (the guide's gather table)
+                     "binding": ({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                  "alone_frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                 if V * D * 4 > 200e6 else
+                                 {"bound": "l2_shared_rows", "peak": list(L2_SHARED_ROWS_GBS), "unit": "GB/s",
+                                  "source": "MI355X_MICROARCH.md, 'Indexed rows: gather into LDS': 66-73 GB/s per CU",
+                                  "frac": [achieved / L2_SHARED_ROWS_GBS[1], achieved / L2_SHARED_ROWS_GBS[0]],
+                                  "alone_frac": [alg / (iso_ms * 1e-3) / 1e9 / L2_SHARED_ROWS_GBS[1],
+                                                 alg / (iso_ms * 1e-3) / 1e9 / L2_SHARED_ROWS_GBS[0]]})},
         "avg_loss": loss_avg,
         "calibration": trainer.calibration,
     }

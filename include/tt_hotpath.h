@@ -85,7 +85,10 @@ typedef struct {
   int32_t k1_stream_linger;/* streaming K1: ~microseconds a turned-away candidate lingers before it leaves (auto: 0) */
   int32_t tn_transpose;    /* weight-gradient GEMMs: stage the K-strided operands through a register transpose into
                               K-contiguous LDS images (one ds_read_b128 per fragment): 1 on, -1 off */
-  int32_t reserved[4];     /* must be 0 */
+  int32_t event_scope;     /* engine: release scope of the events that order its two streams: 1 no system-scope fence
+                              (hipEventDisableSystemFence; auto), 2 device-scope release (hipEventReleaseToDevice),
+                              3 HIP's default (system-scope fence when the event is recorded) */
+  int32_t reserved[3];     /* must be 0 */
 } tt_tuning;
 
 int tt_abi_version(void);
@@ -519,6 +522,20 @@ int tt_engine_reduce_grads_range(tt_engine* e, float* grad_out, int64_t offset, 
  */
 typedef void* tt_event_t; /* hipEvent_t */
 int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event);
+
+/*
+ * Events that order streams of ONE device against each other — what the host side needs around tt_engine_pool* on a
+ * side stream: "the gather may overwrite this slot once phase B of three batches ago has finished", "phase B may read
+ * the slot once the gather has finished".  A default hipEvent performs a system-scope release (cache write-back)
+ * when it is recorded, which the kernel behind it on the same stream waits for; same-device ordering needs no more than
+ * device scope.  scope: 0 default, 1 hipEventDisableSystemFence, 2 hipEventReleaseToDevice.  Timing is disabled.
+ * tt_event_done: 1 = everything recorded before the event has completed, 0 = not yet.
+ */
+int tt_event_create(int scope, tt_event_t* out);
+int tt_event_destroy(tt_event_t event);
+int tt_event_record(tt_event_t event, tt_stream_t stream);
+int tt_stream_wait_event(tt_stream_t stream, tt_event_t event);
+int tt_event_done(tt_event_t event);
 
 /*
  * Phase C: Adam over the bound flat buffers.  grads == NULL: consume the

@@ -125,7 +125,8 @@ def _slicing(cols: str, D: int) -> str:
 
 
 @pytest.mark.parametrize("D,S,V,N", [(384, 128, 30522, 301), (768, 256, 5000, 67), (64, 7, 100, 5), (1024, 33, 777, 9),
-                                     (384, 512, 30522, 13), (8, 300, 40, 3), (128, 64, 5, 6), (384, 128, 30522, 5000)])
+                                     (384, 512, 30522, 13), (8, 300, 40, 3), (128, 64, 5, 6), (384, 128, 30522, 5000),
+                                     (64, 40, 120000, 700)])  # a 15 MB column slice: chip-wide slice-major unit order
 @pytest.mark.parametrize("cols", ["0", "1"], ids=["row-slices", "column-slices"])
 def test_pool_sliced_vs_oracle_shapes(tt, D, S, V, N, cols):
     """XCD-sliced K1 (tt_gather_pool_norm_sliced_f32), both of its forms (slices of rows: ids % 8; slices of 32 columns,

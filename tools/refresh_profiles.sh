@@ -1,53 +1,71 @@
 #!/bin/bash
-# Runs the bench modes reported in DESIGN.md §5 on one box and writes the JSON lines + rocprofv3 kernel stats
-# to gpurun_out/refresh/ (copy into profiles/ afterwards).   usage: tools/refresh_profiles.sh [rNN]
-set -e
-r=${1:-r03}
+# Runs the bench modes reported in DESIGN.md section 5 on ONE box and writes the JSON lines, rocprofv3 kernel stats,
+# timelines, MFMA utilisation and K1 fabric-traffic (PMC) summaries to gpurun_out/refresh/ (copied into profiles/ afterwards).
+#   usage: tools/refresh_profiles.sh [rNN]         (every variant is a bench argument: nothing reads the environment)
+r=${1:-r04}
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/refresh; mkdir -p $out
 cd $root
-python bench.py > $out/${r}_bench_c2_default.json
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $out/${r}_bench_c2_default_k20_w5.json
-python bench.py --no-cpu-baseline --no-secondary --no-overlap > $out/${r}_bench_c2_no_overlap.json
-python bench.py --no-cpu-baseline --no-secondary --ragged > $out/${r}_bench_c2_ragged.json
-python bench.py --no-cpu-baseline --no-secondary --inputs index > $out/${r}_bench_c2_inputs_index.json
-python bench.py --no-cpu-baseline --no-secondary --inputs cache > $out/${r}_bench_c2_inputs_cache.json
-python bench.py --no-cpu-baseline --no-secondary --e2e --steps 1000 > $out/${r}_bench_c2_e2e_epoch1000.json
-python bench.py --no-cpu-baseline --no-secondary --loss inbatch > $out/${r}_bench_c2_inbatch_b2048.json
-python bench.py --no-cpu-baseline --no-secondary --loss inbatch --batch 4096 > $out/${r}_bench_inbatch_b4096.json
-python bench.py --no-cpu-baseline --config c3 > $out/${r}_bench_c3_share.json
-python bench.py --no-cpu-baseline --config c4 --steps 40 --warmup 8 > $out/${r}_bench_c4_full.json
-python bench.py --no-cpu-baseline --config c4 --steps 20 --warmup 4 --no-overlap > $out/${r}_bench_c4_no_overlap.json
-python bench.py --no-cpu-baseline --config c4 --steps 12 --warmup 4 --inputs index > $out/${r}_bench_c4_inputs_index.json
-TT_K1_STREAM=0 TT_BK=32 TT_XCD=0 TT_TN_TILE=11 python bench.py --no-cpu-baseline --config c4 --steps 20 --warmup 4 > $out/${r}_bench_c4_round2_kernels.json
+B="python bench.py --no-cpu-baseline --no-secondary"
+python bench.py > $out/${r}_bench_c2_default.json 2> $out/${r}_bench_c2_default.err || exit 1
+$B --steps 20 --warmup 5 > $out/${r}_bench_c2_default_k20_w5.json
+$B --no-overlap > $out/${r}_bench_c2_no_overlap.json
+$B --ragged > $out/${r}_bench_c2_ragged.json
+$B --zipf > $out/${r}_bench_c2_zipf.json
+$B --inputs index > $out/${r}_bench_c2_inputs_index.json
+$B --inputs cache > $out/${r}_bench_c2_inputs_cache.json
+$B --e2e --steps 1000 > $out/${r}_bench_c2_e2e_epoch1000.json
+$B --path module --steps 200 > $out/${r}_bench_c2_module_path.json
+$B --loss inbatch > $out/${r}_bench_c2_inbatch_b2048.json
+$B --loss inbatch --batch 4096 > $out/${r}_bench_inbatch_b4096.json
+$B --loss inbatch --batch 512 > $out/${r}_bench_inbatch_b512_share.json
+$B --config c3 > $out/${r}_bench_c3_share.json
+$B --config c4 --steps 40 --warmup 8 > $out/${r}_bench_c4_full.json
+$B --config c4 --steps 20 --warmup 4 --no-overlap > $out/${r}_bench_c4_no_overlap.json
+$B --config c4 --steps 12 --warmup 4 --inputs index > $out/${r}_bench_c4_inputs_index.json
+echo "benches done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c2 -o ks -- python3 $root/bench.py --no-cpu-baseline --no-secondary > /dev/null 2>&1
-cp $(find $out/prof_c2 -name "*kernel_stats.csv" | head -1) $out/${r}_bench_c2_default_kernel_stats.csv
-python3 $root/tools/timeline.py $(find $out/prof_c2 -name "*kernel_trace.csv" | head -1) 120 2 > $out/${r}_timeline_c2_default.txt || true
-rm -rf $out/prof_c2
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c4 -o ks -- python3 $root/bench.py --no-cpu-baseline --config c4 --steps 20 --warmup 4 > /dev/null 2>&1
-cp $(find $out/prof_c4 -name "*kernel_stats.csv" | head -1) $out/${r}_bench_c4_full_kernel_stats.csv
-python3 $root/tools/timeline.py $(find $out/prof_c4 -name "*kernel_trace.csv" | head -1) 12 2 > $out/${r}_timeline_c4_full.txt || true
-rm -rf $out/prof_c4
-# MFMA utilisation of the projection kernels, configs[1] and configs[3] (one-stream runs: counter collection serialises kernels anyway)
-for cfg in c2 c4; do
-  steps=40; [ $cfg = c4 ] && steps=6
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_$cfg -o p -- python3 $root/bench.py --no-cpu-baseline --no-secondary --no-calibrate --config $cfg --steps $steps --warmup 2 > /dev/null 2>&1
-  python3 - $out/pmc_$cfg $cfg <<'PY' >> $out/${r}_k2_mfma_util.txt
-import csv, glob, sys, collections
+prof() { tag=$1; first=$2; shift 2
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -o ks -- python3 $root/bench.py --no-cpu-baseline --no-secondary "$@" > /dev/null 2>&1
+  cp $(find $out/prof_$tag -name "*kernel_stats.csv" | head -1) $out/${r}_bench_${tag}_kernel_stats.csv
+  python3 $root/tools/timeline.py $(find $out/prof_$tag -name "*kernel_trace.csv" | head -1) $first 2 > $out/${r}_timeline_${tag}.txt || true
+  rm -rf $out/prof_$tag; }
+prof c2_default 120
+prof c3_share 120 --config c3
+prof c4_full 12 --config c4 --steps 20 --warmup 4
+prof c2_module_path 60 --path module --steps 100
+echo "kernel traces done"
+# MFMA utilisation of the projection kernels (one-stream runs: counter collection serialises kernels anyway)
+rm -f $out/${r}_k2_mfma_util.txt
+mfma() { tag=$1; label=$2; shift 2
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_$tag -o p -- python3 $root/bench.py --no-cpu-baseline --no-secondary --no-calibrate --no-overlap "$@" > /dev/null 2>&1 || return 1
+  python3 - $out/pmc_$tag "$label" <<'PY' >> $out/${r}_k2_mfma_util.txt
+import csv, glob, re, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
         if "gemm" in n:
-            import re
-            m = re.search(r"(gemm\w+_kernel<[^>]*>)", n)
-            acc[m.group(1) if m else n[:80]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-print("==", sys.argv[2], "(SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs), second half of the launches)")
-for k, c in acc.items():
+            mt = re.search(r"(gemm\w*_kernel<[^>]*>)", n)
+            acc[mt.group(1) if mt else n[:80]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+print("==", sys.argv[2], "(template args: layout 0 NT / 1 NN / 2 TN, epilogue, tile wm, wn, [vector path], [K-step], [transposed TN staging])")
+for k, c in sorted(acc.items()):
     m = {n: sum(v[len(v) // 2:]) / max(len(v[len(v) // 2:]), 1) for n, v in c.items()}
-    print(f"{k:62s} mfma_util {m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / max(m.get('GRBM_GUI_ACTIVE', 0) / 8, 1):5.3f}")
+    print(f"{k:56s} mfma_util {m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / max(m.get('GRBM_GUI_ACTIVE', 0) / 8, 1):5.3f}   launches {len(c.get('GRBM_GUI_ACTIVE', []))}")
 PY
-  rm -rf $out/pmc_$cfg
-done
+  rm -rf $out/pmc_$tag; }
+mfma c2 "configs[1] B=2048 D=P=384 (one stream)" --steps 40 --warmup 2
+mfma c2tnt "configs[1] with the weight gradients staged through a register transpose (--tune tn_transpose=1)" --steps 40 --warmup 2 --tune tn_transpose=1
+mfma c2fork "configs[1], fork backward (TN and NN as separate launches)" --steps 40 --warmup 2 --tune backward=fork
+mfma c2forktnt "configs[1], fork backward, transposed TN staging" --steps 40 --warmup 2 --tune backward=fork --tune tn_transpose=1
+mfma c3 "configs[2] one GPU's share B=1024 P=512 (one stream)" --config c3 --steps 40 --warmup 2
+mfma c4bk16 "configs[3] with the tiles used beside the streaming gather (K-step 16, 128x128 TN, XCD order)" --config c4 --steps 6 --warmup 2 --tune proj_tile=22 --tune proj_bk=16 --tune tn_tile=22 --tune xcd_order=1
 cat $out/${r}_k2_mfma_util.txt
+# K1 fabric-side traffic: FETCH_SIZE / WRITE_SIZE in separate passes of bench.py --k1-only
+traffic() { cfg=$1; alg=$2; kern=$3; shift 3
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$cfg -o f -- python3 $root/bench.py --config $cfg --k1-only --no-cpu-baseline --no-secondary --steps 8 --warmup 2 "$@" > /dev/null 2>&1 || return 1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$cfg -o w -- python3 $root/bench.py --config $cfg --k1-only --no-cpu-baseline --no-secondary --steps 8 --warmup 2 "$@" > /dev/null 2>&1 || return 1
+  python3 $root/tools/pmc_traffic.py $out/pmc_fetch_$cfg $out/pmc_write_$cfg $out/${r}_k1_traffic_$cfg.json $alg $kern
+  rm -rf $out/pmc_fetch_$cfg $out/pmc_write_$cfg; }
+traffic c2 1220542464 pool_colsliced_kernel,pool_colnorm_kernel
+traffic c4 38856032256 pool_norm_stream_kernel --tune k1_form=stream
 echo refreshed

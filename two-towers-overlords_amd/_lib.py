@@ -71,7 +71,8 @@ class TTTuning(C.Structure):
         ("backward", C.c_int32),
         ("k1_stream_linger", C.c_int32),
         ("tn_transpose", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("event_scope", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -155,6 +156,11 @@ SIGNATURES = {
     "tt_engine_k1_census": (_i, [_vp, _i, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "tt_engine_reduce_grads_range": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "tt_engine_set_dw2_event": (_i, [_vp, _vp]),
+    "tt_event_create": (_i, [_i, C.POINTER(_vp)]),
+    "tt_event_destroy": (_i, [_vp]),
+    "tt_event_record": (_i, [_vp, _vp]),
+    "tt_stream_wait_event": (_i, [_vp, _vp]),
+    "tt_event_done": (_i, [_vp]),
     "tt_engine_adam": (_i, [_vp, _vp, _d, _d, _d, _d, _i64, _vp]),
     "tt_engine_adam_auto": (_i, [_vp, _vp, _d, _d, _d, _d, _vp]),
     "tt_engine_set_step": (_i, [_vp, _i64, _vp]),
@@ -215,3 +221,38 @@ def check(fn: str, rc: int) -> None:
 
 def call(fn: str, *args) -> None:
     check(fn, getattr(load(), fn)(*args))
+
+
+class StreamEvent:
+    """A HIP event for ordering streams of ONE device against each other (tt_event_* in include/tt_hotpath.h); scope 1
+    (default here): no system-scope fence when it is recorded.  Streams are torch.cuda.Stream objects."""
+
+    def __init__(self, scope: int = 1):
+        h = C.c_void_p()
+        call("tt_event_create", int(scope), C.byref(h))
+        self._h = h
+        self.recorded = False
+
+    def record(self, stream) -> None:
+        call("tt_event_record", self._h, stream.cuda_stream)
+        self.recorded = True
+
+    def wait(self, stream) -> None:
+        """`stream` waits for the work recorded before this event."""
+        if self.recorded:
+            call("tt_stream_wait_event", stream.cuda_stream, self._h)
+
+    def query(self) -> bool:
+        if not self.recorded:
+            return True
+        r = load().tt_event_done(self._h)
+        if r < 0:
+            check("tt_event_done", r)
+        return r == 1
+
+    def __del__(self):
+        try:
+            if self._h and _lib is not None:
+                _lib.tt_event_destroy(self._h)
+        except Exception:
+            pass

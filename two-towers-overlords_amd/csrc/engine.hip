@@ -19,6 +19,7 @@ int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, cons
                         void* workspace, size_t workspace_bytes, unsigned lds_total, int form, hipStream_t st,
                         const int32_t* text_rows, int64_t n_store);
 int tt_k1_sliced_supported(int S, int D, const float* table, const float* out);
+size_t tt_k1_colsliced_workspace_bytes(int64_t N, int D);
 int tt_k1_stream_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
                         void* workspace, size_t workspace_bytes, int per_cu, const tt_tuning* tuning,
@@ -80,7 +81,7 @@ struct tt_engine {
   float* dev_scal;      // {step_size, bc2_sqrt} of the current device step
   // second stream: dW2/db2 run there, under the dH -> dW1/db1 chain (see backward_chain)
   hipStream_t aux;
-  hipEvent_t ev_fork, ev_join;
+  hipEvent_t ev_fork[3], ev_join[3];  // [tt_tuning.event_scope]: default / no system fence / device-scope release
   bool gathers_share_chip;  // tt_engine_set_sharing: token-id gathers are running beside phase B
   int bwd_mode;             // tt_engine_set_backward: TT_BWD_AUTO / TT_BWD_FORK / TT_BWD_FUSED
   hipEvent_t ev_dw2;        // tt_engine_set_dw2_event: recorded once the dW2 / db2 slabs are complete (may be null)
@@ -110,7 +111,7 @@ void carve(tt_engine* e, char* base, size_t* total) {
   // force that form on any table — whenever they are small (<= 64 MB per slot)
   const size_t sliced_bytes = tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D);
   e->k1_partial_bytes = (tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, (int64_t)1 << 40, 128) || sliced_bytes <= (64u << 20))
-                            ? sliced_bytes : 0;
+                            ? sliced_bytes : tt_k1_colsliced_workspace_bytes((int64_t)rows, e->cfg.D);  // (the column form's is tiny)
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i)
     e->k1_partial[i] = e->k1_partial_bytes ? c.take<float>(e->k1_partial_bytes / sizeof(float)) : nullptr;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->k1_stream_ctl[i] = c.take<char>(tt_gather_pool_stream_workspace_bytes());
@@ -181,14 +182,26 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
   carve(e, e->arena, &total);
   // the fork/join stream is optional: without it the backward is one chain on the caller's stream
   if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) e->aux = nullptr;
-  if (e->aux && (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                 hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)) {
-    (void)hipStreamDestroy(e->aux);
-    e->aux = nullptr;
+  for (int k = 0; k < 3 && e->aux; ++k) {
+    const unsigned flags = tt_event_flags(k);
+    if (hipEventCreateWithFlags(&e->ev_fork[k], flags) != hipSuccess) {
+      e->ev_fork[k] = nullptr;
+    } else if (hipEventCreateWithFlags(&e->ev_join[k], flags) != hipSuccess) {
+      (void)hipEventDestroy(e->ev_fork[k]);
+      e->ev_fork[k] = nullptr;
+    }
+    if (!e->ev_fork[k]) {  // without its events the second stream is of no use: one chain on the caller's stream
+      for (int j = 0; j < k; ++j) {
+        (void)hipEventDestroy(e->ev_fork[j]);
+        (void)hipEventDestroy(e->ev_join[j]);
+      }
+      (void)hipStreamDestroy(e->aux);
+      e->aux = nullptr;
+    }
   }
   e->gathers_share_chip = true;
   e->shared = cfg->k1_blocks_per_cu != 0;
-  e->tile_above = cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO && e->k1_partial_bytes != 0 &&
+  e->tile_above = cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO && e->k1_partial_bytes >= tt_gather_pool_sliced_workspace_bytes(3 * (int64_t)cfg->max_B, cfg->D) &&
                   tt_k1_prefers_sliced(cfg->V, cfg->D, 3 * (int64_t)cfg->max_B, cfg->max_S);
   e->cap = cfg->k1_blocks_per_cu > 0 ? cfg->k1_blocks_per_cu : (cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO ? 2 : 0);
   e->magic = kMagic;
@@ -200,8 +213,10 @@ extern "C" int tt_engine_destroy(tt_engine* e) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   if (e->aux) {
     (void)hipStreamSynchronize(e->aux);
-    (void)hipEventDestroy(e->ev_fork);
-    (void)hipEventDestroy(e->ev_join);
+    for (int k = 0; k < 3; ++k) {
+      (void)hipEventDestroy(e->ev_fork[k]);
+      (void)hipEventDestroy(e->ev_join[k]);
+    }
     (void)hipStreamDestroy(e->aux);
   }
   e->magic = 0;
@@ -285,15 +300,16 @@ static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, con
   // which form: the tuning's, else the measured rule for the shape
   int form = tn.k1_form;
   if (form == TT_K1_STREAM && !tt_k1_stream_supported(e->cfg.D, e->table, e->pooled[slot])) form = TT_K1_AUTO;
+  const size_t rows_ws = tt_gather_pool_sliced_workspace_bytes(N, e->cfg.D), cols_ws = tt_k1_colsliced_workspace_bytes(N, e->cfg.D);
   if ((form == TT_K1_ROW_SLICES || form == TT_K1_COLUMN_SLICES) &&
-      !(e->k1_partial_bytes && tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]) &&
-        (form == TT_K1_ROW_SLICES || (e->cfg.D % 32 == 0 && e->cfg.D / 32 <= 32))))
+      !(tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]) &&
+        (form == TT_K1_ROW_SLICES ? e->k1_partial_bytes >= rows_ws : (cols_ws != 0 && e->k1_partial_bytes >= cols_ws))))
     form = TT_K1_AUTO;
   if (form == TT_K1_AUTO) {
     if (auto_share && tt_k1_prefers_stream(e->cfg.V, e->cfg.D, N, S) &&
         tt_k1_stream_supported(e->cfg.D, e->table, e->pooled[slot]))
       form = TT_K1_STREAM;  // beside the projection chain when the table really comes from HBM (gather_pool.hip)
-    else if (e->k1_partial_bytes && tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, N, S) &&
+    else if (e->k1_partial_bytes >= rows_ws && tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, N, S) &&
              tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]))
       form = tt_k1_sliced_form(e->cfg.V, e->cfg.D, S);  // table several times an XCD's L2 (tt_k1_prefers_sliced)
     else
@@ -410,8 +426,11 @@ static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_r
     if (e->ev_dw2) TT_HIP(hipEventRecord(e->ev_dw2, st));
     return ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st, shared);
   }
-  TT_HIP(hipEventRecord(e->ev_fork, st));
-  TT_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+  // auto (0) = 1: measured 179.5 -> 176.3 us per configs[1] step, 150.3 -> 145.5 at configs[2]'s share (with the trainer's
+  // fence events made the same way; profiles/r04_event_scope_ab.txt); 3 = HIP's default system-scope events
+  const int es = e->tuning.event_scope == 3 ? 0 : (e->tuning.event_scope == 2 ? 2 : 1);
+  TT_HIP(hipEventRecord(e->ev_fork[es], st));
+  TT_HIP(hipStreamWaitEvent(e->aux, e->ev_fork[es], 0));
   if (loss_rows > 0) {
     rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, e->aux);
     if (rc != TT_OK) return rc;
@@ -419,12 +438,12 @@ static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_r
   rc = ttp::backward_dw2(t, 2, D, P, e->nslabs, e->slab_stride, e->aux, shared);
   if (rc != TT_OK) return rc;
   if (e->ev_dw2) TT_HIP(hipEventRecord(e->ev_dw2, e->aux));
-  TT_HIP(hipEventRecord(e->ev_join, e->aux));
+  TT_HIP(hipEventRecord(e->ev_join[es], e->aux));
   rc = ttp::backward_dh(t, 2, D, P, st, shared);
   if (rc != TT_OK) return rc;
   rc = ttp::backward_dw1(t, 2, D, P, e->nslabs, e->slab_stride, st, shared);
   if (rc != TT_OK) return rc;
-  TT_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
+  TT_HIP(hipStreamWaitEvent(st, e->ev_join[es], 0));
   return TT_OK;
 }
 
@@ -595,4 +614,40 @@ extern "C" int tt_engine_read_stats(tt_engine* e, double* loss_sum, int64_t* n_b
   if (n_batches) *n_batches = c;
   if (last_loss) *last_loss = l;
   return oob ? TT_ERR_BAD_SHAPE : TT_OK;  // an out-of-range token id was clamped
+}
+
+// Events for ordering streams of ONE device against each other (the trainer's gather fence / slot-ready events).  A
+// default hipEvent performs a system-scope release when it is recorded — a cache write-back the host and other
+// devices would need, and that the kernel behind it on the same stream waits for; streams of the same device need no
+// more than device scope.  scope: 0 default, 1 hipEventDisableSystemFence, 2 hipEventReleaseToDevice.
+extern "C" int tt_event_create(int scope, tt_event_t* out) {
+  TT_REQUIRE(out, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(scope >= 0 && scope <= 2, TT_ERR_BAD_SHAPE);
+  hipEvent_t ev = nullptr;
+  TT_HIP(hipEventCreateWithFlags(&ev, tt_event_flags(scope)));
+  *out = ev;
+  return TT_OK;
+}
+extern "C" int tt_event_destroy(tt_event_t ev) {
+  TT_REQUIRE(ev, TT_ERR_NULL_POINTER);
+  TT_HIP(hipEventDestroy(static_cast<hipEvent_t>(ev)));
+  return TT_OK;
+}
+extern "C" int tt_event_record(tt_event_t ev, tt_stream_t stream) {
+  TT_REQUIRE(ev, TT_ERR_NULL_POINTER);
+  TT_HIP(hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream)));
+  return TT_OK;
+}
+extern "C" int tt_stream_wait_event(tt_stream_t stream, tt_event_t ev) {
+  TT_REQUIRE(ev, TT_ERR_NULL_POINTER);
+  TT_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev), 0));
+  return TT_OK;
+}
+// 1: everything recorded before the event has completed; 0: not yet; < 0 / other: error
+extern "C" int tt_event_done(tt_event_t ev) {
+  TT_REQUIRE(ev, TT_ERR_NULL_POINTER);
+  const hipError_t r = hipEventQuery(static_cast<hipEvent_t>(ev));
+  if (r == hipSuccess) return 1;
+  if (r == hipErrorNotReady) return 0;
+  return TT_ERR_BAD_HANDLE;
 }

@@ -497,10 +497,19 @@ __global__ __launch_bounds__(WPB * TT_WAVE) void pool_colsliced_kernel(
     long long units_per_class) {
   const int lane = threadIdx.x & (TT_WAVE - 1);
   const int wave = threadIdx.x >> 6;
-  const int cls = (int)(blockIdx.x & 7);
-  const long long j = (long long)(blockIdx.x >> 3) * WPB + wave;  // this wave's unit within its class
-  const long long u = cls * units_per_class + j;
-  if (j >= units_per_class || u >= (long long)NS * N) return;  // wave-uniform; no workgroup barrier below
+  long long u;
+  if (units_per_class > 0) {  // XCD class x owns a contiguous range of units: its slice(s) stay in ITS L2
+    const int cls = (int)(blockIdx.x & 7);
+    const long long j = (long long)(blockIdx.x >> 3) * WPB + wave;  // this wave's unit within its class
+    u = cls * units_per_class + j;
+    if (j >= units_per_class) return;
+  } else {
+    // chip-wide slice-major order (a slice too big for an L2, V x 128 bytes > 13 MB): the whole chip works through
+    // ONE slice at a time, so the live working set is a slice or two — a few tens of MB, resident in the 256 MiB
+    // Infinity Cache — and every table line comes from HBM once per launch however many tokens name it
+    u = (long long)blockIdx.x * WPB + wave;
+  }
+  if (u >= (long long)NS * N) return;  // wave-uniform; no workgroup barrier below
   const int slice = (int)(u / N);
   const long long text = u - (long long)slice * N;
   const int rslot = lane >> 3, piece = lane & 7;
@@ -764,12 +773,13 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   const bool columns = form == TT_K1_COLUMN_SLICES || (form == TT_K1_AUTO && colsliced_applies(V, D, S));
   if (columns) {
     const int NS = D / kColSliceFloats;
-    const long long upc = ((long long)NS * N + 7) / 8;  // units per XCD class
+    const bool per_xcd = (double)V * kColSliceFloats * 4.0 <= 13.0e6;  // a slice an XCD's L2 can (mostly) hold
+    const long long upc = per_xcd ? ((long long)NS * N + 7) / 8 : 0;   // units per XCD class; 0: chip-wide slice-major order
     // waves (= units) per workgroup: 8.  Beside the projection chain the gather's residency is a number of WORKGROUPS
     // per CU, so this sets its waves per CU: 3 x 8 there (register-bound) against 4 x 4 (LDS-bound) — 179 vs 200 us
     // per configs[1] step; 6 / 12 / 16 waves: 194 / 190 / 201 us.  (Alone 4-wave workgroups are 3 us faster.)
     constexpr int kColWaves = 8;
-    const long long wgs = 8 * ((upc + kColWaves - 1) / kColWaves);
+    const long long wgs = per_xcd ? 8 * ((upc + kColWaves - 1) / kColWaves) : ((long long)NS * N + kColWaves - 1) / kColWaves;
     if (wgs > 0x7fffffffLL) return TT_ERR_BAD_SHAPE;
     float* ssq = ws;  // [N][NS]
     const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
@@ -848,7 +858,8 @@ int launch_stream(const float* table, const void* ids, const void* mask, const i
     case 1: TT_STREAM_CASE(1, 16); break;
     case 2: TT_STREAM_CASE(2, 12); break;
     case 3:  // D in (512, 768]: U rows x 3 KiB in flight per wave
-      if (rows == 4) TT_STREAM_CASE(3, 4);
+      if (rows == 3) TT_STREAM_CASE(3, 3);
+      else if (rows == 4) TT_STREAM_CASE(3, 4);
       else if (rows == 8) TT_STREAM_CASE(3, 8);
       else TT_STREAM_CASE(3, 6);
       break;
@@ -926,6 +937,12 @@ extern "C" size_t tt_gather_pool_sliced_workspace_bytes(int64_t N, int D) {
   return ((size_t)N * kSlices * (size_t)D + (size_t)N) * sizeof(float);
 }
 
+// internal (engine.hip): workspace of the column-sliced form alone (sums of squares [N][D / 32]); 0 where it cannot apply
+size_t tt_k1_colsliced_workspace_bytes(int64_t N, int D) {
+  if (N <= 0 || D <= 0 || D % kColSliceFloats != 0 || D / kColSliceFloats > 32) return 0;
+  return (size_t)N * (size_t)(D / kColSliceFloats) * sizeof(float);
+}
+
 // internal (engine.hip) + public: the XCD-sliced form.  Same contract as tt_gather_pool_norm_f32.
 int tt_k1_sliced_supported(int S, int D, const float* table, const float* out) {
   return (D % 4 == 0) && D <= 1024 && S <= kSlicedMaxS && tt_aligned16(table) && tt_aligned16(out);
@@ -958,7 +975,10 @@ int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, cons
   TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
   TT_REQUIRE(tt_k1_sliced_supported(S, D, table, out) && tt_aligned16(workspace), TT_ERR_BAD_SHAPE);
-  TT_REQUIRE(workspace_bytes >= tt_gather_pool_sliced_workspace_bytes(N, D), TT_ERR_WORKSPACE);
+  // the column slices keep one float per (text, slice); the row slices a whole partial row per (text, slice)
+  const bool cols_only = form == TT_K1_COLUMN_SLICES || (form == TT_K1_AUTO && colsliced_applies(V, D, S));
+  TT_REQUIRE(workspace_bytes >= (cols_only ? tt_k1_colsliced_workspace_bytes(N, D) : tt_gather_pool_sliced_workspace_bytes(N, D)),
+             TT_ERR_WORKSPACE);
   if (N == 0) return TT_OK;
   float* ws = static_cast<float*>(workspace);
   const int md = mask ? mask_dtype : TT_I32;

@@ -32,6 +32,11 @@ static inline unsigned tt_k1_lds_for_cap(int blocks_per_cu) {
   return (160u * 1024u) / (unsigned)blocks_per_cu - 1024u;  // one granule of slack: n fit, n + 1 do not
 }
 
+// hipEventCreateWithFlags flags for tt_tuning.event_scope / tt_event_create's `scope`
+static inline unsigned tt_event_flags(int scope) {
+  return hipEventDisableTiming | (scope == 1 ? hipEventDisableSystemFence : scope == 2 ? hipEventReleaseToDevice : 0u);
+}
+
 static inline bool tt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #ifdef __HIPCC__

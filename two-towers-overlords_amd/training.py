@@ -251,7 +251,7 @@ class TripletTrainer:
                  process_group=None, engine=None, overlap_streams: Optional[bool] = None,
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
                  freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: bool = False,
-                 gather_under_exchange: bool = True, tuning: Optional[dict] = None):
+                 gather_under_exchange: bool = True, tuning: Optional[dict] = None, event_scope: Optional[int] = None):
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -342,9 +342,19 @@ class TripletTrainer:
         self._next_slot = 0
         self._apply_stream = None             # the stream the last apply() ran phase B on
         if self.side is not None:             # events are reused: one "fence" and one "ready" per slot
-            self._slot_fence = [torch.cuda.Event() for _ in range(self.SLOTS)]
-            self._slot_fence2 = [torch.cuda.Event() for _ in range(self.SLOTS)]
-            self._slot_ready = [torch.cuda.Event() for _ in range(self.SLOTS)]
+            # The events that order the side stream and the caller's stream against each other are same-device events:
+            # created without the system-scope fence a default hipEvent performs when it is recorded (a cache write-back
+            # that the next kernel of the recording stream waits for — the fence sits between Adam and the next batch's
+            # first projection kernel, on the critical chain: 179.5 -> 176.3 us per configs[1] step, 150.3 -> 145.5 at
+            # configs[2]'s share).  event_scope (= tt_tuning.event_scope): 1 no system fence, 2 device-scope release,
+            # 3 torch's default events; None / 0: the engine tuning's, else 1.
+            if not event_scope:
+                event_scope = int((tuning or {}).get("event_scope", 0)) or 1
+            self.event_scope = int(event_scope)
+            mk = (lambda: _TorchEvent()) if self.event_scope == 3 else (lambda: _lib.StreamEvent(self.event_scope))
+            self._slot_fence = [mk() for _ in range(self.SLOTS)]
+            self._slot_fence2 = [mk() for _ in range(self.SLOTS)]
+            self._slot_ready = [mk() for _ in range(self.SLOTS)]
             # tt_engine_create cleared the workspace on the main stream: order the side stream behind it
             self.side.wait_stream(torch.cuda.current_stream(self.device))
         self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
@@ -403,12 +413,12 @@ class TripletTrainer:
         cur = torch.cuda.current_stream(self.device)
         fence = self._slot_fence[slot]
         fence.record(cur)
-        self.side.wait_event(fence)
+        fence.wait(self.side)
         if self._apply_stream is not None and cur != self._apply_stream:
             # the batch was produced on a stream of its own (a copy stream): (b) lives on the stream apply() uses
             fence2 = self._slot_fence2[slot]
             fence2.record(self._apply_stream)
-            self.side.wait_event(fence2)
+            fence2.wait(self.side)
         if batch.ready_event is not None:  # produced on a stream of its own (a copy stream)
             self.side.wait_event(batch.ready_event)
         # K1 reads these tensors on the side stream: tell the caching allocator, so that memory the producer
@@ -534,7 +544,7 @@ class TripletTrainer:
                 issue_next = None
             self._apply_stream = torch.cuda.current_stream(self.device)
             if ev is not None and not ev.query():  # (a gather issued two batches ago has usually finished:
-                self._apply_stream.wait_event(ev)  #  then no wait packet goes into this stream at all)
+                ev.wait(self._apply_stream)        #  then no wait packet goes into this stream at all)
         if self.device.type == "cuda":  # read by phase B on this stream, possibly allocated on a producer's stream
             for t in (neg_index, query_ids):
                 if t is not None:
@@ -887,7 +897,7 @@ class TripletTrainer:
             self._ring_load(slot_k1, nxt)
         g = self._graph(slot_fb, slot_k1)
         if ev is not None:  # pooled by an eager K1 on the side stream
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            ev.wait(torch.cuda.current_stream(self.device))
         g.replay()
         self._steps_done += 1
         self._micro += 1
@@ -938,6 +948,22 @@ class TripletTrainer:
             dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.pg)
             n = int(c.item())
         return loss_sum / max(n, 1)
+
+
+class _TorchEvent:
+    """torch.cuda.Event behind the record(stream) / wait(stream) / query() interface of _lib.StreamEvent."""
+
+    def __init__(self):
+        self.ev = torch.cuda.Event()
+
+    def record(self, stream) -> None:
+        self.ev.record(stream)
+
+    def wait(self, stream) -> None:
+        stream.wait_event(self.ev)
+
+    def query(self) -> bool:
+        return self.ev.query()
 
 
 def shard_sizes(global_B: int, world: int):

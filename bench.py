@@ -395,13 +395,13 @@ def run_module_path(args, device) -> dict:
 def secondary_c4(args, world, rank, device) -> dict:
     """BASELINE.json configs[3] (V=250k, d=768, proj 768, S=256, B=16384: a 768 MB table, three times the Infinity
     Cache — the configuration where K1 really streams from HBM), measured in this same run with the same code path:
-    step rate, K1 in the loop and K1 alone.  `traffic` is null: PMC counters are not collected in a timed run."""
+    step rate, K1 in the loop and K1 alone.  `traffic` comes from the newest committed PMC passes of this kernel
+    (profiles/rNN_k1_traffic_c4.json; `traffic_source` says so): PMC counters are not collected in a timed run."""
     a = copy.copy(args)
     a.config, a.steps, a.warmup, a.no_cpu_baseline = "c4", 20, 6, True
     a.tuning = {}
     # ~130 steps of set-up (0.8 s) before the 20 timed ones: the first ~70 steps after an idle gap run 10-20 % slower
     a.n_distinct, a.calibrate_steps, a.calibrate_rounds, a.iso_launches = 2, 24, 2, 8
-    a.no_traffic_file = True  # `traffic` stays null here: nothing is read back from committed profiles
     torch.cuda.empty_cache()
     r = run_config(a, world, rank, device)
     torch.cuda.empty_cache()
@@ -615,21 +615,27 @@ def run_config(args, world, rank, device) -> dict:
     alg = k1_algorithmic_bytes(roles * B, S, D)
     if args.ragged and args.inputs == "ids3":  # n_valid*D*4 + S*4 + D*4 per text with the actual lengths
         alg = int(valid_tokens * D * 4 + roles * B * (S * 4 + D * 4))
-    traffic = traffic_source = None  # fabric-side bytes per K1 launch: from the committed PMC passes of this same workload, if any
-    import glob
-    tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_k1_traffic_{args.config}.json")))
-    if tpaths and not args.zipf and not getattr(args, "no_traffic_file", False):  # the newest round's PMC passes
-        tj = json.load(open(tpaths[-1]))
-        if int(tj.get("algorithmic_bytes_per_launch", -1)) == alg and args.inputs == "ids3":
-            traffic = tj["traffic_bytes_per_launch"]
-            traffic_source = (os.path.relpath(tpaths[-1], ROOT) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                              "workload (`bench.py --k1-only`), committed; PMC counters are not collected in a timed run")
-    achieved = alg / (k1_ms * 1e-3) / 1e9
     from two_towers_overlords_amd import _lib as _ttlib
     sliced = bool(_ttlib.load().tt_k1_prefers_sliced(V, D, roles * B, S))
     streaming = (trainer.side is not None and trainer.engine_k1_cap < 0
                  and bool(_ttlib.load().tt_k1_prefers_stream(V, D, roles * B, S)))
-    columns = sliced and bool(_ttlib.load().tt_k1_sliced_form(V, D, S))
+    columns = sliced and _ttlib.load().tt_k1_sliced_form(V, D, S) == _ttlib.TT_K1_COLUMN_SLICES
+    forced = (trainer.engine.tuning or {}).get("k1_form") if hasattr(trainer.engine, "tuning") else None
+    if forced:  # --tune k1_form=...: the engine was told which form to use
+        streaming, sliced = forced == _ttlib.TT_K1_STREAM, forced in (_ttlib.TT_K1_ROW_SLICES, _ttlib.TT_K1_COLUMN_SLICES)
+        columns = forced == _ttlib.TT_K1_COLUMN_SLICES
+    k1_kernel = ("pool_colsliced_kernel" if columns else "pool_sliced_kernel" if sliced else
+                 "pool_norm_stream_kernel" if (streaming or args.k1_only and forced == _ttlib.TT_K1_STREAM) else "pool_norm_kernel")
+    traffic = traffic_source = None  # fabric-side bytes per K1 launch: from the committed PMC passes of this same workload AND kernel, if any
+    import glob
+    tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_k1_traffic_{args.config}.json")))
+    if tpaths and not args.zipf and not args.ragged and args.inputs == "ids3":  # the newest round's PMC passes
+        tj = json.load(open(tpaths[-1]))
+        if int(tj.get("algorithmic_bytes_per_launch", -1)) == alg and tj.get("kernel", "").split(",")[0] == k1_kernel:
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_source = (os.path.relpath(tpaths[-1], ROOT) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "workload and kernel (`bench.py --k1-only`), committed; PMC counters are not collected in a timed run")
+    achieved = alg / (k1_ms * 1e-3) / 1e9
     k1_label = ("pool_colsliced_kernel + pool_colnorm_kernel (K1, XCD-sliced form, 32-column slices — one 128-byte line per "
                 "row, a slice fits the XCD's L2: gather + masked mean-pool, then the L2 norm; both launches lie inside the "
                 "timed events)" if columns

@@ -75,7 +75,7 @@ def test_module_forward_backward_matches_reference(name):
     assert torch.equal(q2, q) and torch.equal(d2, p)
     loss = crit(q, p, n)
     assert abs(loss.item() - float(g["fwd/loss"])) <= TOL
-    assert np.abs(crit.cosine_distance(q, p).cpu().numpy() - g["fwd/pos_dist"]).max() <= TOL
+    assert np.abs(crit.cosine_distance(q, p).detach().cpu().numpy() - g["fwd/pos_dist"]).max() <= TOL  # (differentiable, like the reference's)
     loss.backward()
     for k, prm in m.named_parameters():
         if prm.requires_grad:

@@ -21,6 +21,26 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device: torch.device):
+    """Context that makes `device` current for the launch — a no-op object when it already is (entering
+    `torch.cuda.device` costs several microseconds of host time per call, and the module path makes ~20 calls per step)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 def _req(t: torch.Tensor, name: str, dtype=None, ndim: Optional[int] = None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
@@ -117,7 +137,7 @@ def gather_pool_norm(
         if tuple(out.shape) != (N, D):
             raise ValueError(f"out: expected {(N, D)}, got {tuple(out.shape)}")
     flag = torch.zeros(1, dtype=torch.int32, device=table.device) if check_ids else None
-    with torch.cuda.device(table.device):
+    with _on(table.device):
         if stream_form:
             nbytes = int(_lib.load().tt_gather_pool_stream_workspace_bytes())
             ws = _scratch(table.device, nbytes)  # queue head + per-CU registry; stream-ordered reuse
@@ -152,7 +172,7 @@ def pool_norm_dense(
     N, S, D = hidden.shape
     mask, mw, lens = _mask_or_lens(attention_mask, lens, N, S, hidden.device)
     out = torch.empty((N, D), dtype=torch.float32, device=hidden.device)
-    with torch.cuda.device(hidden.device):
+    with _on(hidden.device):
         call("tt_pool_norm_dense_f32", hidden.data_ptr(), _ptr(mask), mw, _ptr(lens), out.data_ptr(), N, S, D, _stream())
     return out
 
@@ -165,7 +185,7 @@ def embed_gather(table: torch.Tensor, input_ids: torch.Tensor, check_ids: bool =
     V, D = table.shape
     out = torch.empty((*input_ids.shape, D), dtype=torch.float32, device=table.device)
     flag = torch.zeros(1, dtype=torch.int32, device=table.device) if check_ids else None
-    with torch.cuda.device(table.device):
+    with _on(table.device):
         call("tt_embed_gather_f32", table.data_ptr(), input_ids.data_ptr(), iw, out.data_ptr(), input_ids.numel(), D, V,
              _ptr(flag), _stream())
     if check_ids and int(flag.item()) != 0:
@@ -185,7 +205,7 @@ def proj_fwd(x, w1, b1, w2, b2, tuning=None) -> Tuple[torch.Tensor, torch.Tensor
             raise ValueError(f"{name}: expected {shape}, got {tuple(t.shape)}")
     h = torch.empty((M, P), dtype=torch.float32, device=x.device)
     out = torch.empty((M, P), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         call("tt_proj_fwd_f32", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
              h.data_ptr(), out.data_ptr(), M, D, P, _lib.tuning_ref(tuning), _stream())
     return out, h
@@ -215,7 +235,7 @@ def proj_bwd(d_out, x, h, w2, tuning=None) -> Tuple[torch.Tensor, torch.Tensor, 
         return dW1, db1, dW2, db2
     nbytes = _lib.load().tt_proj_bwd_workspace_bytes(M, D, P)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         call("tt_proj_bwd_f32", d_out.data_ptr(), x.data_ptr(), h.data_ptr(), w2.data_ptr(), dW1.data_ptr(),
              db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), ws.data_ptr(), nbytes, 0, M, D, P, _lib.tuning_ref(tuning),
              _stream())
@@ -242,7 +262,7 @@ def triplet_fwd_bwd(q, p, n, margin: float, grad_scale: Optional[float] = None, 
     if need_grad:
         dq, dp, dn = torch.empty((3, B, P), dtype=torch.float32, device=dev).unbind(0)  # one buffer: see _TripletLossFn
     gs = (1.0 / B) if grad_scale is None else grad_scale
-    with torch.cuda.device(dev):
+    with _on(dev):
         call("tt_triplet_fwd_bwd_f32", q.data_ptr(), p.data_ptr(), n.data_ptr(), margin, gs, B, P, loss.data_ptr(),
              pd.data_ptr(), nd.data_ptr(), hinge.data_ptr(), _ptr(dq), _ptr(dp), _ptr(dn), _stream())
     return loss, pd, nd, dq, dp, dn
@@ -256,7 +276,7 @@ def adam_step_flat(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, bet
         _req(t, name, torch.float32)
         if t.numel() != n:
             raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
-    with torch.cuda.device(params.device):
+    with _on(params.device):
         call("tt_adam_f32", params.data_ptr(), grads.data_ptr(), 1, 0, exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
              lr, beta1, beta2, eps, step, grad_scale, _stream())
 
@@ -276,7 +296,7 @@ def adam_step_multi(tensors, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1
                 raise ValueError(f"{name} of tensor {i}: expected {n} elements on {dev}")
         arr[i].param, arr[i].grad, arr[i].exp_avg, arr[i].exp_avg_sq = (t.data_ptr() for t in quad)
         arr[i].n = n
-    with torch.cuda.device(dev):
+    with _on(dev):
         call("tt_adam_multi_f32", arr, len(tensors), lr, beta1, beta2, eps, int(step), _stream())
 
 
@@ -288,7 +308,7 @@ def cosine_distance(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         raise ValueError("cosine_distance: x and y must have the same [B, P] shape and device")
     B, P = x.shape
     out = torch.empty(B, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         call("tt_cosine_distance_f32", x.data_ptr(), y.data_ptr(), B, P, out.data_ptr(), _stream())
     return out
 
@@ -302,7 +322,7 @@ def cosine_distance_bwd(x: torch.Tensor, y: torch.Tensor, grad_dist: torch.Tenso
     if tuple(y.shape) != (B, P) or grad_dist.shape[0] != B:
         raise ValueError("cosine_distance_bwd: inconsistent shapes")
     dx, dy = torch.empty_like(x), torch.empty_like(y)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         call("tt_cosine_distance_bwd_f32", x.data_ptr(), y.data_ptr(), grad_dist.data_ptr(), B, P, dx.data_ptr(), dy.data_ptr(),
              _stream())
     return dx, dy
@@ -321,7 +341,7 @@ def cosine_scores(q: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
     out = torch.empty((Q, N), dtype=torch.float32, device=q.device)
     nbytes = _lib.load().tt_cosine_scores_workspace_bytes(Q, N, P)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         call("tt_cosine_scores_f32", q.data_ptr(), d.data_ptr(), out.data_ptr(), Q, N, P, ws.data_ptr(), nbytes, _stream())
     return out
 
@@ -348,7 +368,7 @@ def ndcg_at_k(scores: torch.Tensor, relevance: torch.Tensor, ks=(10,), valid: Op
     out = torch.empty((Q, len(ks)), dtype=torch.float32, device=scores.device)
     ks_dev = torch.empty(len(ks), dtype=torch.int32, device=scores.device)
     ks_host = (C.c_int32 * len(ks))(*ks)
-    with torch.cuda.device(scores.device):
+    with _on(scores.device):
         call("tt_ndcg_at_k_f32", scores.data_ptr(), gains.data_ptr(), _ptr(vm), Q, N, ks_host, len(ks), ks_dev.data_ptr(),
              out.data_ptr(), _stream())
         torch.cuda.current_stream().synchronize()  # ks_host must outlive the async H2D copy
@@ -388,7 +408,7 @@ def inbatch_triplet_fwd_bwd(q: torch.Tensor, d: torch.Tensor, margin: float, pos
         raise ValueError("inbatch: dq_out / dd_out must match q / d")
     nbytes = _lib.load().tt_inbatch_workspace_bytes(Bq, Bd, P)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         call("tt_inbatch_triplet_fwd_bwd_f32", q.data_ptr(), d.data_ptr(), _ptr(pos_index), _ptr(qid_q), _ptr(qid_d), margin,
              gs, den, Bq, Bd, P, loss.data_ptr(), dq.data_ptr(), dd.data_ptr(), 0, ws.data_ptr(), nbytes, _stream())
     return loss, dq, dd

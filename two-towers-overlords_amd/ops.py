@@ -378,9 +378,12 @@ def ndcg_at_k(scores: torch.Tensor, relevance: torch.Tensor, ks=(10,), valid: Op
 def inbatch_triplet_fwd_bwd(q: torch.Tensor, d: torch.Tensor, margin: float, pos_index: Optional[torch.Tensor] = None,
                             qid_q: Optional[torch.Tensor] = None, qid_d: Optional[torch.Tensor] = None,
                             grad_scale: Optional[float] = None, loss_denominator: Optional[float] = None,
-                            dq_out: Optional[torch.Tensor] = None, dd_out: Optional[torch.Tensor] = None):
+                            dq_out: Optional[torch.Tensor] = None, dd_out: Optional[torch.Tensor] = None,
+                            workspace: Optional[torch.Tensor] = None):
     """In-batch-negatives triplet loss: returns (loss[1], dq [Bq,P], dd [Bd,P]).
-    Defaults: mean over the Bq*(Bd-1) (query, other document) pairs."""
+    Defaults: mean over the Bq*(Bd-1) (query, other document) pairs.  `workspace`: a float32 buffer of at least
+    tt_inbatch_workspace_bytes(Bq, Bd, P) bytes the caller keeps between steps (the similarity matrix alone is
+    Bq x Bd floats: taking ~100 MB from the caching allocator every step makes the host time of a step bimodal)."""
     _req(q, "q", torch.float32, 2)
     _req(d, "d", torch.float32, 2)
     Bq, P = q.shape
@@ -407,7 +410,12 @@ def inbatch_triplet_fwd_bwd(q: torch.Tensor, d: torch.Tensor, margin: float, pos
     if tuple(dq.shape) != (Bq, P) or tuple(dd.shape) != (Bd, P):
         raise ValueError("inbatch: dq_out / dd_out must match q / d")
     nbytes = _lib.load().tt_inbatch_workspace_bytes(Bq, Bd, P)
-    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=q.device)
+    if workspace is not None:
+        ws = _req(workspace, "workspace", torch.float32)
+        if ws.numel() * 4 < nbytes or ws.device != q.device:
+            raise ValueError(f"inbatch: workspace holds {ws.numel() * 4} bytes, {nbytes} are needed")
+    else:
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=q.device)
     with _on(q.device):
         call("tt_inbatch_triplet_fwd_bwd_f32", q.data_ptr(), d.data_ptr(), _ptr(pos_index), _ptr(qid_q), _ptr(qid_d), margin,
              gs, den, Bq, Bd, P, loss.data_ptr(), dq.data_ptr(), dd.data_ptr(), 0, ws.data_ptr(), nbytes, _stream())

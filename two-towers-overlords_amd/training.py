@@ -772,7 +772,7 @@ class TripletTrainer:
             qid = None if query_ids is None else query_ids.to(torch.int64).contiguous()
             z = float(B * (B - 1))
             loss, _, _ = ops.inbatch_triplet_fwd_bwd(emb[0], emb[1], self.margin, None, qid, qid, 1.0 / (z * k), z,
-                                                     dq_out=dout[0], dd_out=dout[1])
+                                                     dq_out=dout[0], dd_out=dout[1], workspace=self._inbatch_ws(B, B))
             eng.add_loss(loss)
             eng.backward(slot, B, 2)
             return
@@ -807,7 +807,7 @@ class TripletTrainer:
             loss, _, dd_all = ops.inbatch_triplet_fwd_bwd(emb[0], d_all.contiguous(), self.margin, pos,
                                                           pad_q[:B].contiguous() if have_qid else None,
                                                           None if qid_all is None else qid_all.contiguous(),
-                                                          1.0 / (z * k), z, dq_out=dout[0])
+                                                          1.0 / (z * k), z, dq_out=dout[0], workspace=self._inbatch_ws(B, global_B))
         else:
             dd_all = torch.zeros((global_B, self.P), dtype=torch.float32, device=self.device)
         dist.all_reduce(dd_all, op=dist.ReduceOp.SUM, group=self.pg)
@@ -815,6 +815,18 @@ class TripletTrainer:
             dout[1].copy_(dd_all[offs[r]: offs[r] + B])
             eng.add_loss(loss)
             eng.backward(slot, B, 2)
+
+    def _inbatch_ws(self, Bq: int, Bd: int) -> Optional[torch.Tensor]:
+        """Grow-only workspace of the in-batch loss (the [Bq, Bd] similarity matrix and the gradient slabs), kept between
+        steps: stream-ordered reuse on the stream phase B runs on."""
+        if self.device.type != "cuda":
+            return None
+        need = (int(_lib.load().tt_inbatch_workspace_bytes(Bq, Bd, self.P)) + 3) // 4
+        ws = getattr(self, "_inbatch_workspace", None)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._inbatch_workspace = ws
+        return ws
 
     def _valid_rows(self, sizes, mb: int) -> torch.Tensor:
         """Row indices of the real (non-padding) rows inside the [world * mb] all-gathered blocks."""

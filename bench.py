@@ -250,6 +250,9 @@ def main():
     ap.add_argument("--event-scope", type=int, default=None, choices=[1, 2, 3],
                     help="release scope of the events that order the gather stream and the caller's stream, and the engine's "
                          "two streams (1 no system-scope fence [default], 2 device-scope release, 3 HIP's default events)")
+    ap.add_argument("--no-fence-at-loss", action="store_true",
+                    help="A/B: the gather stream's slot fence as an event of its own at the start of the step (round 3) instead "
+                         "of the engine's loss / fork event (TripletTrainer(fence_at_loss=False))")
     ap.add_argument("--dp-split", action="store_true",
                     help="data-parallel step with the exchange in two parts (TripletTrainer(split_exchange=True))")
     ap.add_argument("--no-cpu-baseline-bert", action="store_true",
@@ -290,7 +293,8 @@ def main():
         return
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
-                    and not args.zipf and not args.ragged and not args.tuning and not args.dp_split)
+                    and not args.zipf and not args.ragged and not args.tuning and not args.dp_split
+                    and not args.no_fence_at_loss)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
     # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")
     args.cpu_baseline_later = bool(rank == 0 and world == 1 and default_line and not args.no_secondary)
@@ -454,7 +458,8 @@ def run_config(args, world, rank, device) -> dict:
     trainer = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
                              overlap_streams=(False if (args.no_overlap or args.k1_only) else None),
                              k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss,
-                             tuning=(args.tuning or None), split_exchange=bool(args.dp_split))
+                             tuning=(args.tuning or None), split_exchange=bool(args.dp_split),
+                             fence_at_loss=not args.no_fence_at_loss)
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1

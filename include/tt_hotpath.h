@@ -524,6 +524,15 @@ typedef void* tt_event_t; /* hipEvent_t */
 int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event);
 
 /*
+ * Optional hand-off point inside tt_engine_fwd_bwd / tt_engine_backward: `event` (NULL = none) is recorded on the caller's
+ * stream right after the loss kernel — everything phase B of EARLIER batches did lies before it in stream order, and
+ * so does this batch's forward.  In the fork backward it IS the fork point (the engine's second stream waits for this
+ * record instead of one of its own), so a caller whose gather stream needs "phase B of the previous batch has
+ * finished with its pooled slot" gets that edge without an event packet of its own on the critical stream.
+ */
+int tt_engine_set_loss_event(tt_engine* e, tt_event_t event);
+
+/*
  * Events that order streams of ONE device against each other — what the host side needs around tt_engine_pool* on a
  * side stream: "the gather may overwrite this slot once phase B of three batches ago has finished", "phase B may read
  * the slot once the gather has finished".  A default hipEvent performs a system-scope release (cache write-back)

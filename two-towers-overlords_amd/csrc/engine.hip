@@ -85,6 +85,7 @@ struct tt_engine {
   bool gathers_share_chip;  // tt_engine_set_sharing: token-id gathers are running beside phase B
   int bwd_mode;             // tt_engine_set_backward: TT_BWD_AUTO / TT_BWD_FORK / TT_BWD_FUSED
   hipEvent_t ev_dw2;        // tt_engine_set_dw2_event: recorded once the dW2 / db2 slabs are complete (may be null)
+  hipEvent_t ev_loss;       // tt_engine_set_loss_event: recorded on the caller's stream right after the loss kernel (may be null)
 };
 
 namespace {
@@ -417,6 +418,7 @@ static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_r
   const ttp::Plan shared = chain_plan(e);
   int rc;
   if (!use_fork(e)) {
+    if (e->ev_loss) TT_HIP(hipEventRecord(e->ev_loss, st));
     if (loss_rows > 0) {
       rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
       if (rc != TT_OK) return rc;
@@ -429,8 +431,11 @@ static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_r
   // auto (0) = 1: measured 179.5 -> 176.3 us per configs[1] step, 150.3 -> 145.5 at configs[2]'s share (with the trainer's
   // fence events made the same way; profiles/r04_event_scope_ab.txt); 3 = HIP's default system-scope events
   const int es = e->tuning.event_scope == 3 ? 0 : (e->tuning.event_scope == 2 ? 2 : 1);
-  TT_HIP(hipEventRecord(e->ev_fork[es], st));
-  TT_HIP(hipStreamWaitEvent(e->aux, e->ev_fork[es], 0));
+  // the fork point: ONE event on the caller's stream, the caller's if it gave one (tt_engine_set_loss_event) — a second
+  // stream of the caller's may wait for the same record instead of paying for a packet of its own
+  hipEvent_t fork = e->ev_loss ? e->ev_loss : e->ev_fork[es];
+  TT_HIP(hipEventRecord(fork, st));
+  TT_HIP(hipStreamWaitEvent(e->aux, fork, 0));
   if (loss_rows > 0) {
     rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, e->aux);
     if (rc != TT_OK) return rc;
@@ -533,6 +538,12 @@ extern "C" int tt_engine_reduce_grads_range(tt_engine* e, float* grad_out, int64
 extern "C" int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   e->ev_dw2 = static_cast<hipEvent_t>(event);
+  return TT_OK;
+}
+
+extern "C" int tt_engine_set_loss_event(tt_engine* e, tt_event_t event) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  e->ev_loss = static_cast<hipEvent_t>(event);
   return TT_OK;
 }
 

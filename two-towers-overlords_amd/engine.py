@@ -211,6 +211,12 @@ class HotPathEngine:
         self._dw2_event = event  # keep it alive while the engine holds its handle
         call("tt_engine_set_dw2_event", self._h, None if event is None else event.cuda_event)
 
+    def set_loss_event(self, event) -> None:
+        """`event` (_lib.StreamEvent or None) is recorded inside fwd_bwd() / backward() right after the loss kernel, on the
+        caller's stream (tt_engine_set_loss_event) — in the fork backward it doubles as the fork point."""
+        self._loss_event = event  # keep it alive while the engine holds its handle
+        call("tt_engine_set_loss_event", self._h, None if event is None else event._h)
+
     def adam(self, step: int, lr: float, grads: Optional[torch.Tensor] = None, beta1=0.9, beta2=0.999, eps=1e-8) -> None:
         g = None
         if grads is not None:

@@ -251,7 +251,8 @@ class TripletTrainer:
                  process_group=None, engine=None, overlap_streams: Optional[bool] = None,
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
                  freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: bool = False,
-                 gather_under_exchange: bool = True, tuning: Optional[dict] = None, event_scope: Optional[int] = None):
+                 gather_under_exchange: bool = True, tuning: Optional[dict] = None, event_scope: Optional[int] = None,
+                 fence_at_loss: bool = True):
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -355,6 +356,16 @@ class TripletTrainer:
             self._slot_fence = [mk() for _ in range(self.SLOTS)]
             self._slot_fence2 = [mk() for _ in range(self.SLOTS)]
             self._slot_ready = [mk() for _ in range(self.SLOTS)]
+            # fence_at_loss: the gather of batch i + 2 may overwrite its pooled slot once phase B of batch i - 1 has
+            # finished with it.  Instead of recording a fence event of its own on the caller's stream at the start of
+            # step i (an event packet between Adam and the first projection kernel of the next batch: the critical
+            # chain), the side stream waits for the event the engine records right after batch i's loss kernel anyway —
+            # in the fork backward that record IS the fork point — which lies behind all of batch i - 1 in stream order.
+            self._loss_event = None
+            if fence_at_loss and self.event_scope != 3 and hasattr(self.engine, "set_loss_event"):
+                self._loss_event = _lib.StreamEvent(self.event_scope)
+                self.engine.set_loss_event(self._loss_event)
+        self._prewaited = None                # slot whose "ready" event the caller's stream already waits for
             # tt_engine_create cleared the workspace on the main stream: order the side stream behind it
             self.side.wait_stream(torch.cuda.current_stream(self.device))
         self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
@@ -388,10 +399,13 @@ class TripletTrainer:
                 for name, off, shape in flat_param_slices(self.D, self.P)}
 
     # -- pipeline: gathers run ahead of the weight-dependent part ---------------------
-    def gather(self, batch: Batch) -> None:
+    def gather(self, batch: Batch, fence=None) -> None:
         """Enqueue K1 (gather + pool + normalise) for a batch that a later `apply()` will
         consume.  Weight-independent, so it may run up to SLOTS-1 batches ahead; with a side
-        stream it runs concurrently with the projection kernels of earlier batches."""
+        stream it runs concurrently with the projection kernels of earlier batches.
+        `fence` (apply() passes it to `issue_next`): an event already recorded on the caller's stream behind
+        everything this gather must wait for — the batch's tensors were produced before that record and the phase B
+        that last read the slot lies before it; the side stream then waits for IT and no event is recorded here."""
         if len(self._pending) >= self.SLOTS:
             raise RuntimeError("gather(): all pooled-input slots are in use; call apply() first")
         slot = self._next_slot
@@ -411,14 +425,17 @@ class TripletTrainer:
         # H2D copy), (b) the fwd_bwd that last read this pooled-input slot (enqueued earlier on the same
         # stream), (c) graph replays.  K1 runs two batches ahead, so this wait is off the critical path.
         cur = torch.cuda.current_stream(self.device)
-        fence = self._slot_fence[slot]
-        fence.record(cur)
-        fence.wait(self.side)
-        if self._apply_stream is not None and cur != self._apply_stream:
-            # the batch was produced on a stream of its own (a copy stream): (b) lives on the stream apply() uses
-            fence2 = self._slot_fence2[slot]
-            fence2.record(self._apply_stream)
-            fence2.wait(self.side)
+        if fence is not None and (self._apply_stream is None or cur == self._apply_stream):
+            fence.wait(self.side)  # recorded by the engine behind (a), (b) and (c): nothing to record here
+        else:
+            fence = self._slot_fence[slot]
+            fence.record(cur)
+            fence.wait(self.side)
+            if self._apply_stream is not None and cur != self._apply_stream:
+                # the batch was produced on a stream of its own (a copy stream): (b) lives on the stream apply() uses
+                fence2 = self._slot_fence2[slot]
+                fence2.record(self._apply_stream)
+                fence2.wait(self.side)
         if batch.ready_event is not None:  # produced on a stream of its own (a copy stream)
             self.side.wait_event(batch.ready_event)
         # K1 reads these tensors on the side stream: tell the caching allocator, so that memory the producer
@@ -523,71 +540,101 @@ class TripletTrainer:
 
     def apply(self, global_B: Optional[int] = None, issue_next=None) -> None:
         """fwd + bwd of the oldest gathered batch, gradient exchange, optimizer.
-        `issue_next()` (optional) is called where enqueueing further gathers overlaps best:
-        before the projection kernels when gathers have their own stream, else right after
-        the gradient all-reduce has been launched."""
+        `issue_next(fence)` (optional) is called where enqueueing further gathers overlaps best — it should call
+        `gather(next_batch, fence=fence)` for a batch whose tensors were produced BEFORE this call: single replica:
+        right behind this batch's forward + backward launches (the side stream waits for the engine's loss event,
+        see __init__), or ahead of them when that event is not in use; with a gradient exchange: right before the
+        all-reduce."""
         slot, ev, local_B, neg_index, query_ids = self._pending.popleft()
         global_B = global_B or local_B * self.world
         if global_B <= 0:
             raise ValueError("apply(): empty global batch")
         k = self.accumulation_steps
         self._steps_done += 1
+        loss_fence = self._loss_event if self.side is not None else None
         if self.side is not None:
-            # Where the next gather goes.  Single replica: ahead of this batch's projection kernels (both streams
-            # stay busy back to back).  With a gradient exchange: right before the all-reduce (below), so that the
+            # Where the next gather goes.  Single replica: behind this batch's phase-B launches in HOST order, waiting
+            # for the loss event (both streams stay busy back to back, and the caller's stream carries no fence packet).
+            # With a gradient exchange: right before the all-reduce (below), so that the
             # gather starts when the chain goes idle for the exchange and the chain's own kernels run beside less
             # of it — measured with a stand-in exchange on one GPU (bench.py --simulate-allreduce-us): placed ahead
             # of the projection kernels instead, the gather is over before the exchange starts and the exchange's
             # latency is fully exposed (a 60 us exchange: 286 vs 249 us per step).
-            if issue_next is not None and not (self._exchange and self._gather_under_exchange):
-                issue_next()
+            if issue_next is not None and loss_fence is None and not (self._exchange and self._gather_under_exchange):
+                issue_next(None)
                 issue_next = None
             self._apply_stream = torch.cuda.current_stream(self.device)
-            if ev is not None and not ev.query():  # (a gather issued two batches ago has usually finished:
-                ev.wait(self._apply_stream)        #  then no wait packet goes into this stream at all)
+            if ev is not None and self._prewaited != slot and not ev.query():  # (a gather issued two batches ago has
+                ev.wait(self._apply_stream)  # usually finished: then no wait packet goes into this stream at all)
+            self._prewaited = None
         if self.device.type == "cuda":  # read by phase B on this stream, possibly allocated on a producer's stream
             for t in (neg_index, query_ids):
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream(self.device))
+        ran = False
         if self.loss_kind == "inbatch":
             self._inbatch_fwd_bwd(slot, local_B, query_ids, k, global_B)
+            ran = local_B > 0
         elif local_B > 0:
             self.engine.fwd_bwd(slot, local_B, self.margin, 1.0 / (global_B * k), float(global_B), neg_index=neg_index)
+            ran = True
+        fence = None
+        if loss_fence is not None and ran:  # the engine has recorded it (in C) behind this batch's loss kernel
+            loss_fence.recorded = True
+            fence = loss_fence
+        issue = (lambda: issue_next(fence)) if issue_next is not None else None
+        if issue is not None and self.side is not None and not (self._exchange and self._gather_under_exchange):
+            issue()
+            issue = None
         if self._dry:
-            if issue_next is not None:
-                issue_next()
+            if issue is not None:
+                issue()
             return
         self._micro += 1
         do_step = self._micro % k == 0
         if self.bucket is None:  # single replica, no accumulation: Adam folds the slab sum
             if local_B == 0:  # nothing was computed: the slabs still hold the previous batch's gradients
-                if issue_next is not None:
-                    issue_next()
+                if issue is not None:
+                    issue()
                 return
             self.step_count += 1
+            self._prewait_next()
             if self._auto_step:  # step counter on the device: the same call sequence is graph-replayable
                 self.engine.adam_auto(self.lr, None, self.betas[0], self.betas[1], self.eps)
             else:
                 self.engine.adam(self.step_count, self.lr, None, self.betas[0], self.betas[1], self.eps)
-            if issue_next is not None:
-                issue_next()
+            if issue is not None:
+                issue()
             return
         first_micro = not self._carry  # nothing un-applied in the bucket: this batch's gradients overwrite it
         self._carry = not do_step
         if self._split:
-            self._split_step(local_B, first_micro, do_step, issue_next)
+            self._split_step(local_B, first_micro, do_step, issue)
             return
         if local_B > 0:
             self.engine.reduce_grads(self.bucket, accumulate=not first_micro)
         elif first_micro:  # an empty shard contributes zero gradients but still takes part in the all-reduce
             self.bucket.zero_()
-        if issue_next is not None:
-            issue_next()  # weight-independent; enqueued BEFORE the exchange so that its fence does not wait for it
+        if issue is not None:
+            issue()  # weight-independent; enqueued BEFORE the exchange so that its fence does not wait for it
         if do_step and self._exchange:
             self._all_reduce(self.bucket)
         if do_step:
             self.step_count += 1
+            self._prewait_next()
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
+
+    def _prewait_next(self) -> None:
+        """The NEXT batch's gather must have finished before its forward starts.  If it has not yet (the host runs ahead
+        of the GPU, so at enqueue time it usually has not), the wait goes into the caller's stream HERE, ahead of this
+        step's Adam — in the fork backward right behind the join, where the stream stops for an event anyway — rather
+        than between Adam and the next batch's first projection kernel."""
+        if self.side is None or not self._pending:
+            return
+        slot, ev, *_ = self._pending[0]
+        if ev is not None and not ev.query():
+            ev.wait(torch.cuda.current_stream(self.device))
+            self._prewaited = slot
 
     # -- checkpoint / resume of the optimizer side ---------------------------------------------
     def state_dict(self) -> dict:
@@ -649,7 +696,7 @@ class TripletTrainer:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(steps):
-                        self.apply(None, issue_next=lambda: self.gather(b))
+                        self.apply(None, issue_next=lambda fence=None: self.gather(b, fence=fence))
                     e1.record()
                     while self._pending:
                         self.apply(None)
@@ -899,7 +946,7 @@ class TripletTrainer:
         nxt = None if nxt is None else as_batch(nxt)
         entry = self._pending[0]
         if not self._graphable(entry, nxt):
-            self.apply(global_B, issue_next=(lambda: self.gather(nxt)) if nxt is not None else None)
+            self.apply(global_B, issue_next=(lambda fence=None: self.gather(nxt, fence=fence)) if nxt is not None else None)
             return
         slot_fb, ev, B, _, _ = self._pending.popleft()
         slot_k1 = None

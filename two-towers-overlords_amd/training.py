@@ -365,9 +365,11 @@ class TripletTrainer:
             if fence_at_loss and self.event_scope != 3 and hasattr(self.engine, "set_loss_event"):
                 self._loss_event = _lib.StreamEvent(self.event_scope)
                 self.engine.set_loss_event(self._loss_event)
-        self._prewaited = None                # slot whose "ready" event the caller's stream already waits for
             # tt_engine_create cleared the workspace on the main stream: order the side stream behind it
             self.side.wait_stream(torch.cuda.current_stream(self.device))
+        else:
+            self._loss_event = None
+        self._prewaited = None                # slot whose "ready" event the caller's stream already waits for
         self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
         self.k1_event_every = 4               # ... of every 4th launch
         self.k1_event_pool = []               # optional pre-created (start, end) pairs for those

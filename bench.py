@@ -250,9 +250,9 @@ def main():
     ap.add_argument("--event-scope", type=int, default=None, choices=[1, 2, 3],
                     help="release scope of the events that order the gather stream and the caller's stream, and the engine's "
                          "two streams (1 no system-scope fence [default], 2 device-scope release, 3 HIP's default events)")
-    ap.add_argument("--no-fence-at-loss", action="store_true",
-                    help="A/B: the gather stream's slot fence as an event of its own at the start of the step (round 3) instead "
-                         "of the engine's loss / fork event (TripletTrainer(fence_at_loss=False))")
+    ap.add_argument("--fence-at-loss", type=int, default=None, choices=[0, 1],
+                    help="A/B: 1 = the gather stream's slot fence is the engine's loss / fork event, 0 = an event of its own at "
+                         "the start of the step (TripletTrainer(fence_at_loss=...)); default: calibrate() decides")
     ap.add_argument("--dp-split", action="store_true",
                     help="data-parallel step with the exchange in two parts (TripletTrainer(split_exchange=True))")
     ap.add_argument("--no-cpu-baseline-bert", action="store_true",
@@ -294,7 +294,7 @@ def main():
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
                     and not args.zipf and not args.ragged and not args.tuning and not args.dp_split
-                    and not args.no_fence_at_loss)
+                    and args.fence_at_loss is None)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
     # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")
     args.cpu_baseline_later = bool(rank == 0 and world == 1 and default_line and not args.no_secondary)
@@ -459,7 +459,7 @@ def run_config(args, world, rank, device) -> dict:
                              overlap_streams=(False if (args.no_overlap or args.k1_only) else None),
                              k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss,
                              tuning=(args.tuning or None), split_exchange=bool(args.dp_split),
-                             fence_at_loss=not args.no_fence_at_loss)
+                             fence_at_loss=(None if args.fence_at_loss is None else bool(args.fence_at_loss)))
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1
@@ -576,7 +576,8 @@ def run_config(args, world, rank, device) -> dict:
         e1.record()
     set_up_steps = 0  # steps of this workload executed before the timed region besides --warmup
     if trainer.calibration:
-        set_up_steps += 2 * trainer.calibration["rounds"] * (trainer.calibration["steps"] + depth)  # dry fwd+bwd (no optimizer)
+        combos = len(trainer.calibration.get("ms_per_step_by_fence") or (0, 0))  # backward schedules x fence placements timed
+        set_up_steps += combos * trainer.calibration["rounds"] * (trainer.calibration["steps"] + depth)  # dry fwd+bwd (no optimizer)
     if args.e2e:
         elapsed, e2e_info = run_e2e(args, trainer, cfg, device, rank, world, barrier)
         host_issue = elapsed

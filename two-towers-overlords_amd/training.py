@@ -252,7 +252,7 @@ class TripletTrainer:
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
                  freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: bool = False,
                  gather_under_exchange: bool = True, tuning: Optional[dict] = None, event_scope: Optional[int] = None,
-                 fence_at_loss: bool = True):
+                 fence_at_loss: Optional[bool] = None):
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -359,12 +359,21 @@ class TripletTrainer:
             # fence_at_loss: the gather of batch i + 2 may overwrite its pooled slot once phase B of batch i - 1 has
             # finished with it.  Instead of recording a fence event of its own on the caller's stream at the start of
             # step i (an event packet between Adam and the first projection kernel of the next batch: the critical
-            # chain), the side stream waits for the event the engine records right after batch i's loss kernel anyway —
+            # chain), the side stream may wait for the event the engine records right after batch i's loss kernel anyway —
             # in the fork backward that record IS the fork point — which lies behind all of batch i - 1 in stream order.
+            # The gather then starts ~half a step later, beside the backward instead of the forward: measured
+            # (profiles/r04_fence_at_loss_ab.txt) configs[1] 175.3 -> 173.4 us, in-batch loss B = 4096 619.5 -> 591.1 us,
+            # but configs[2]'s share 142.5 -> 148.3 us (its 65 us gather is better spent beside the forward), and with a
+            # gradient exchange the gather belongs UNDER the exchange (207.8 vs 186.7 us at a 60 us stand-in).  So: never
+            # with an exchange; None = on for the in-batch loss, and for the triplet loss whatever calibrate() measures
+            # on the device at hand (off until then).
             self._loss_event = None
-            if fence_at_loss and self.event_scope != 3 and hasattr(self.engine, "set_loss_event"):
+            self._use_loss_fence = False
+            if fence_at_loss is not False and self.event_scope != 3 and hasattr(self.engine, "set_loss_event") and not self._exchange:
                 self._loss_event = _lib.StreamEvent(self.event_scope)
                 self.engine.set_loss_event(self._loss_event)
+                self._use_loss_fence = bool(fence_at_loss) or (fence_at_loss is None and self.loss_kind == "inbatch")
+            self._fence_arg = fence_at_loss
             # tt_engine_create cleared the workspace on the main stream: order the side stream behind it
             self.side.wait_stream(torch.cuda.current_stream(self.device))
         else:
@@ -553,7 +562,7 @@ class TripletTrainer:
             raise ValueError("apply(): empty global batch")
         k = self.accumulation_steps
         self._steps_done += 1
-        loss_fence = self._loss_event if self.side is not None else None
+        loss_fence = self._loss_event if (self.side is not None and self._use_loss_fence) else None
         if self.side is not None:
             # Where the next gather goes.  Single replica: behind this batch's phase-B launches in HOST order, waiting
             # for the loss event (both streams stay busy back to back, and the caller's stream carries no fence packet).
@@ -687,11 +696,15 @@ class TripletTrainer:
             return {}
         b = as_batch(batch)
         depth = self.SLOTS - 1 if self.side is not None else 1
-        times = {"fused": [], "fork": []}
+        # second dimension: where the gather's slot fence comes from (see __init__, fence_at_loss) — only where the
+        # caller left it open and the engine's loss event exists
+        fences = (False, True) if (self.side is not None and self._loss_event is not None and self._fence_arg is None) else (self._use_loss_fence,)
+        times = {(m, f): [] for m in ("fused", "fork") for f in fences}
         self._dry = True
         try:
             for _ in range(rounds):
-                for mode in ("fused", "fork"):
+                for mode, fence in times:
+                    self._use_loss_fence = fence
                     self.engine.set_backward(mode)
                     while len(self._pending) < depth:
                         self.gather(b)
@@ -703,18 +716,23 @@ class TripletTrainer:
                     while self._pending:
                         self.apply(None)
                     e1.synchronize()
-                    times[mode].append(e0.elapsed_time(e1) / steps)
+                    times[(mode, fence)].append(e0.elapsed_time(e1) / steps)
         finally:
             self._dry = False
-        best = {m: min(v) for m, v in times.items()}
+        keys = list(times)
+        best = {kf: min(v) for kf, v in times.items()}
         if self.world > 1:  # every replica must take the same decision: decide on the slowest rank's times
-            t = torch.tensor([best["fused"], best["fork"]], dtype=torch.float64, device=self.device)
+            t = torch.tensor([best[kf] for kf in keys], dtype=torch.float64, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
-            best = {"fused": float(t[0]), "fork": float(t[1])}
+            best = {kf: float(t[i]) for i, kf in enumerate(keys)}
         pick = min(best, key=best.get)
-        self.engine.set_backward(pick)
+        self.engine.set_backward(pick[0])
+        self._use_loss_fence = pick[1]
         self.engine.read_stats(reset=True)  # the dry steps' losses do not belong to any epoch
-        self.calibration = {"backward": pick, "ms_per_step": best, "steps": steps, "rounds": rounds}
+        self.calibration = {"backward": pick[0], "fence_at_loss": pick[1],
+                            "ms_per_step": {m: min(best[kf] for kf in keys if kf[0] == m) for m in ("fused", "fork")},
+                            "ms_per_step_by_fence": {f"{m},{'loss' if f else 'own'}": best[(m, f)] for m, f in keys},
+                            "steps": steps, "rounds": rounds}
         return self.calibration
 
     def _split_step(self, local_B: int, first_micro: bool, do_step: bool, issue_next) -> None:

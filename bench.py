@@ -253,6 +253,8 @@ def main():
     ap.add_argument("--fence-at-loss", type=int, default=None, choices=[0, 1],
                     help="A/B: 1 = the gather stream's slot fence is the engine's loss / fork event, 0 = an event of its own at "
                          "the start of the step (TripletTrainer(fence_at_loss=...)); default: calibrate() decides")
+    ap.add_argument("--grad-slabs", type=int, default=0,
+                    help="split-K slabs of the weight-gradient GEMMs (tt_engine_config.grad_slabs; 0 = the engine's choice)")
     ap.add_argument("--dp-split", action="store_true",
                     help="data-parallel step with the exchange in two parts (TripletTrainer(split_exchange=True))")
     ap.add_argument("--no-cpu-baseline-bert", action="store_true",
@@ -294,7 +296,7 @@ def main():
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
                     and not args.zipf and not args.ragged and not args.tuning and not args.dp_split
-                    and args.fence_at_loss is None)
+                    and args.fence_at_loss is None and not args.grad_slabs)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
     # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")
     args.cpu_baseline_later = bool(rank == 0 and world == 1 and default_line and not args.no_secondary)
@@ -459,7 +461,8 @@ def run_config(args, world, rank, device) -> dict:
                              overlap_streams=(False if (args.no_overlap or args.k1_only) else None),
                              k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss,
                              tuning=(args.tuning or None), split_exchange=bool(args.dp_split),
-                             fence_at_loss=(None if args.fence_at_loss is None else bool(args.fence_at_loss)))
+                             fence_at_loss=(None if args.fence_at_loss is None else bool(args.fence_at_loss)),
+                             grad_slabs=args.grad_slabs)
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1
@@ -677,7 +680,7 @@ def run_config(args, world, rank, device) -> dict:
                    "backend": (args.backend if world > 1 else None), "ids": "int32 [3,B,S], "
                    + ("zipf" if args.zipf else "uniform") + (", ragged lengths" if args.ragged else ", full length"), "parallelism": f"dp{world}", "inputs": args.inputs,
                    "k1_only": bool(args.k1_only), "tuning": (trainer.engine.tuning or None),
-                   "event_scope": getattr(trainer, "event_scope", None),
+                   "event_scope": getattr(trainer, "event_scope", None), "grad_slabs": trainer.engine.n_slabs,
                    "gather_overlap": ("side stream, " + ("K1's LDS reservation paired with the projection tile (auto)"
                                                        if trainer.engine_k1_cap < 0 else
                                                        "K1 capped at %d workgroups/CU" % trainer.engine_k1_cap))

@@ -45,6 +45,7 @@ class TTEngineConfig(C.Structure):
         ("max_S", C.c_int32),
         ("device", C.c_int32),
         ("k1_blocks_per_cu", C.c_int32),
+        ("grad_slabs", C.c_int32),
     ]
 
 

@@ -140,13 +140,13 @@ void carve(tt_engine* e, char* base, size_t* total) {
 static int fill_dims(tt_engine* e, const tt_engine_config* cfg) {
   TT_REQUIRE(cfg->V >= 1 && cfg->V <= 0x7fffffffLL && cfg->D >= 1 && cfg->P >= 1 && cfg->P <= 1024 &&
                  cfg->max_B >= 1 && cfg->max_S >= 1 && (int64_t)cfg->max_B * 3 <= 0x7fffffffLL &&
-                 cfg->k1_blocks_per_cu >= TT_K1_SHARE_AUTO,
+                 cfg->k1_blocks_per_cu >= TT_K1_SHARE_AUTO && cfg->grad_slabs >= 0 && cfg->grad_slabs <= 16,
              TT_ERR_BAD_SHAPE);
   e->cfg = *cfg;
   e->tower_n = (int64_t)cfg->P * cfg->D + cfg->P + (int64_t)cfg->P * cfg->P + cfg->P;
   e->nparam = 2 * e->tower_n;
   e->slab_stride = (e->nparam + 3) / 4 * 4;
-  e->nslabs = ttp::choose_nsplit(cfg->max_B);
+  e->nslabs = cfg->grad_slabs > 0 ? cfg->grad_slabs : ttp::choose_nsplit_towers(cfg->max_B, cfg->P, cfg->D);
   return TT_OK;
 }
 

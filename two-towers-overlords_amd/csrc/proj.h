@@ -43,6 +43,8 @@ inline Plan plan_of(const tt_tuning* t, int policy = kTileAuto) {
 int k_per_split(int M, int nsplit);
 // split count used for a standalone backward over M rows
 int choose_nsplit(long long M);
+// split count for the engine's two towers (B query rows, 2B document rows) at projection width P over inputs of width D
+int choose_nsplit_towers(long long B, int P, int D);
 // Largest static LDS (bytes) of a workgroup of the projection kernels forward()/backward_*() launch for
 // `rows` rows in total with the given plan — what a gather workgroup's LDS reservation is sized against.
 size_t chain_lds_bytes(long long rows, int P, const Plan& plan);

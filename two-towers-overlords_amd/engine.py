@@ -34,14 +34,15 @@ def flat_param_slices(D: int, P: int):
 
 class HotPathEngine:
     def __init__(self, table: torch.Tensor, projection_dim: int, max_batch: int, max_seq_len: int,
-                 k1_blocks_per_cu: int = 0, tuning=None):
+                 k1_blocks_per_cu: int = 0, tuning=None, grad_slabs: int = 0):
         _req(table, "table", torch.float32, 2)
         self.device = table.device
         self.table = table
         self.V, self.D = table.shape
         self.P = int(projection_dim)
         self.max_B, self.max_S = int(max_batch), int(max_seq_len)
-        cfg = TTEngineConfig(self.V, self.D, self.P, self.max_B, self.max_S, self.device.index or 0, int(k1_blocks_per_cu))
+        cfg = TTEngineConfig(self.V, self.D, self.P, self.max_B, self.max_S, self.device.index or 0, int(k1_blocks_per_cu),
+                             int(grad_slabs))
         lib = _lib.load()
         nbytes = lib.tt_engine_workspace_bytes(C.byref(cfg))
         if nbytes == 0:

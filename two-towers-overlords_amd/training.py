@@ -252,7 +252,7 @@ class TripletTrainer:
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
                  freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: bool = False,
                  gather_under_exchange: bool = True, tuning: Optional[dict] = None, event_scope: Optional[int] = None,
-                 fence_at_loss: Optional[bool] = None):
+                 fence_at_loss: Optional[bool] = None, grad_slabs: int = 0):
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -287,7 +287,8 @@ class TripletTrainer:
         # `tuning`: tt_tuning fields for THIS trainer's engine (include/tt_hotpath.h; K1 form, tiles, ...): per handle,
         # nothing process-wide — two trainers in one process may differ
         self.engine = engine if engine is not None else HotPathEngine(table.contiguous(), self.P, max_batch, max_seq_len,
-                                                                      k1_blocks_per_cu=k1_blocks_per_cu, tuning=tuning)
+                                                                      k1_blocks_per_cu=k1_blocks_per_cu, tuning=tuning,
+                                                                      grad_slabs=grad_slabs)
         self.engine_k1_cap = int(k1_blocks_per_cu or 0)
         n = self.engine.n_params
         self.flat = torch.cat([t.reshape(-1).float() for t in tensors]).to(self.device).contiguous()

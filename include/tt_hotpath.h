@@ -382,8 +382,8 @@ typedef struct {
                                                    per-text K1 at 2 workgroups per CU beside 128x64 tiles
                                  n >= 2            at most n gather workgroups per CU, 128x64 tiles (A/B) */
   int32_t grad_slabs; /* split-K slabs of the weight-gradient GEMMs (1..16; fixed for the handle's lifetime: the slab
-                         workspace is sized by it); 0 = chosen for (max_B, P, D) so that the two towers' tiles — the
-                         document tower's are twice as long — pack the chip's compute units evenly */
+                         workspace is sized by it); 0 = about 256 query rows per split, at least four where the batch
+                         allows them (measured) */
 } tt_engine_config;
 #define TT_K1_SHARE_AUTO (-1)
 

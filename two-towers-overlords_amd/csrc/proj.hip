@@ -19,53 +19,22 @@ int choose_nsplit(long long M) {
   return (int)s;
 }
 
-// Split count for the engine's weight-gradient launches.  One launch holds both towers' tiles: (P/64)(N/64) tiles per
-// tower and split, the document tower's (2B rows) twice as long as the query tower's.  The rule of round 1-3 was
-// ceil(B / 256) (about 256 rows per split); at BASELINE.json configs[1] that is 8 splits = 576 tiles on 256 compute
-// units, three rounds where 2.25 are needed.  Here: the split count whose tiles, dealt longest first onto the compute
-// units (the order the launch uses), finish earliest — a tile costs its k range plus ~3 K-steps of prologue and
-// epilogue.  configs[1]: 7 splits (504 tiles, two per CU: one long + one short).  Measured: DESIGN.md section 8, round 4.
+// Split count for the engine's weight-gradient launches (one launch holds both towers' tiles; the document tower's
+// are twice as long).  About 256 query rows per split as in rounds 1-3, but never fewer than four splits where the
+// batch allows them: measured in round 4 (profiles/r04_grad_slabs_ab.txt) B = 512 runs 94.1 / 85.4 / 82.1 us per step
+// with 2 / 3 / 4 splits (the old rule gave 2).  A longest-first packing model of the tiles onto the 256 compute units
+// — which prefers 7 splits to 8 at BASELINE.json configs[1]: 504 tiles, two per CU, instead of 576 = 2.25 per CU paid
+// as three rounds — was built and is falsified by the same measurement: 8 splits 173.5 us, 7 176.9, 6 177.2, 4 186.6,
+// 10 172.9; beside the gather the weight-gradient tiles are latency-bound, not round-bound, and shorter tiles win.
 int choose_nsplit_towers(long long B, int P, int D) {
+  (void)P;
+  (void)D;
   if (B < 1) return 1;
-  if (B > 4096) return choose_nsplit(B);  // big batches run 128x128 weight-gradient tiles beside a streaming gather: the old rule
-  const int cus = 256;
-  const long long overhead = 96;
-  int best = 1;
-  long long best_cost = -1;
-  for (int ns = 1; ns <= 16; ++ns) {
-    long long cost = 0;
-    for (int which = 0; which < 2; ++which) {  // dW2 [P x P], dW1 [P x D]
-      const long long T = (long long)((P + 63) / 64) * (((which == 0 ? P : D) + 63) / 64);
-      // longest-first onto `cus` bins: tiles come in 2 * ns groups of T equal tiles; bins stay within one tile of each
-      // other, so deal whole groups round-robin and track the fullest / emptiest bin exactly for equal-length runs
-      long long load[256] = {0};
-      // gather tile lengths (descending: document tower's splits first, each tower's last split may be shorter)
-      long long len[32];
-      int n = 0;
-      for (int tower = 0; tower < 2; ++tower) {
-        const long long M = tower == 0 ? 2 * B : B;
-        const long long k = k_per_split((int)(M > 0x7fffffffLL ? 0x7fffffffLL : M), ns);
-        for (int z = 0; z < ns; ++z) {
-          const long long kb = z * k < M ? z * k : M, ke = kb + k < M ? kb + k : M;
-          len[n++] = ke - kb;
-        }
-      }
-      for (int i = 1; i < n; ++i)  // insertion sort, descending
-        for (int j = i; j > 0 && len[j] > len[j - 1]; --j) { const long long t = len[j]; len[j] = len[j - 1]; len[j - 1] = t; }
-      for (int g = 0; g < n; ++g)
-        for (long long t = 0; t < T; ++t) {
-          int arg = 0;
-          for (int c = 1; c < cus; ++c)
-            if (load[c] < load[arg]) arg = c;
-          load[arg] += len[g] + overhead;
-        }
-      long long mx = 0;
-      for (int c = 0; c < cus; ++c) mx = load[c] > mx ? load[c] : mx;
-      cost += mx;
-    }
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
-  }
-  return best;
+  long long s = (B + 255) / 256;
+  const long long floor4 = (B + 31) / 32 < 4 ? (B + 31) / 32 : 4;  // splits shorter than one K-step stay empty
+  if (s < floor4) s = floor4;
+  if (s > 16) s = 16;
+  return (int)s;
 }
 
 // XCD-aware workgroup order for the projection GEMMs (gemm_f32.h): on beside the streaming gather, where every

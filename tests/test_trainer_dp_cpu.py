@@ -231,7 +231,7 @@ def test_trainer_state_dict_resumes_exactly(accum):
 
 
 def _worker_split(rank, world, port, accum, q):
-    """One epoch with the exchange in one bucket, then the same epoch from the same start with TT_DP_SPLIT's two-part
+    """One epoch with the exchange in one bucket, then the same epoch from the same start with the two-part (split_exchange=True)
     exchange (second-layer gradients first, first-layer gradients after): same per-element sums, so with two replicas
     the parameters must be bitwise equal.  The last global batch holds one triplet: rank 1's shard is empty."""
     try:

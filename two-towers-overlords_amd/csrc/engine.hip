@@ -396,7 +396,7 @@ static void fill_towers(tt_engine* e, int slot, int32_t B, int32_t doc_rows, ttp
 }
 
 // Backward of phase B.  dW2/db2 and dH are independent; dW1/db1 needs dH.  Two forms, A/B-measured on
-// one box with interleaved runs (TT_BWD=fork|fused overrides the choice):
+// one box with interleaved runs (tt_tuning.backward / tt_engine_set_backward override the choice):
 //   fused: loss mean inside the triplet launch, ONE launch for dW2/db2 + dH, then dW1: 8 launches and no
 //          event traffic per step.  The default: alone on the chip (frozen-feature cache: 125 vs 129 us),
 //          and beside gathers reserved just above the projection tile's LDS, where it ties with the fork

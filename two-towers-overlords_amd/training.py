@@ -378,7 +378,7 @@ class TripletTrainer:
             # tt_engine_create cleared the workspace on the main stream: order the side stream behind it
             self.side.wait_stream(torch.cuda.current_stream(self.device))
         else:
-            self._loss_event = None
+            self._loss_event, self._use_loss_fence, self._fence_arg = None, False, fence_at_loss
         self._prewaited = None                # slot whose "ready" event the caller's stream already waits for
         self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
         self.k1_event_every = 4               # ... of every 4th launch

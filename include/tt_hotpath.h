@@ -77,9 +77,9 @@ typedef struct {
   int32_t k1_stream_offer; /* streaming K1: candidate workgroups launched per workgroup the chip may keep (auto: 16) */
   int32_t k1_share_lds_kb; /* engine: KiB of LDS a gather workgroup occupies while it shares the chip with the
                               projection kernels (auto: paired with the projection tile; -1: no reservation) */
-  int32_t proj_tile;       /* projection block tile, rows x columns in units of 64: 11, 21, 22; 10 = 64 x 32 (auto: by shape) */
+  int32_t proj_tile;       /* projection block tile, rows x columns in units of 64: 11, 21, 22 (auto: by shape) */
   int32_t proj_bk;         /* K-step of the 128x128 projection tile: 16 or 32 */
-  int32_t tn_tile;         /* weight-gradient (split-K) tile: 11, 22 or 10 (64 x 32) */
+  int32_t tn_tile;         /* weight-gradient (split-K) tile: 11 or 22 */
   int32_t xcd_order;       /* XCD-aware workgroup order of the projection GEMMs: 1 on, -1 off */
   int32_t backward;        /* engine: TT_BWD_* schedule of phase B's backward */
   int32_t k1_stream_linger;/* streaming K1: ~microseconds a turned-away candidate lingers before it leaves (auto: 0) */

@@ -218,9 +218,6 @@ PROJ_TUNINGS = [
     {"proj_tile": 22},                                                 # 128x128, K-step 32
     {"tn_transpose": 1},                                               # weight gradients staged through a register transpose
     {"tn_transpose": 1, "tn_tile": 22, "xcd_order": 1},
-    {"proj_tile": 10},                                                 # 64 x 32 tiles (two waves, 128 threads)
-    {"proj_tile": 10, "tn_tile": 10, "xcd_order": 1},
-    {"tn_tile": 10, "tn_transpose": 1},
 ]
 _tid = lambda t: "auto" if t is None else ",".join(f"{k}={v}" for k, v in t.items())
 
@@ -396,7 +393,6 @@ ENGINE_SETUPS = [
     (-1, {"k1_form": "columns", "tn_transpose": 1, "proj_tile": 21, "xcd_order": 1}),
     (2, {"backward": "fork", "k1_form": "per_text"}),
     (-1, {"backward": "fused", "tn_tile": 22, "proj_tile": 22, "proj_bk": 16, "k1_share_lds_kb": 40}),
-    (-1, {"proj_tile": 10, "tn_tile": 10}),
 ]
 _eid = lambda s: f"share={s[0]}," + _tid(s[1])
 

@@ -68,7 +68,7 @@ struct Batch {
 // Static LDS of one workgroup of the (layout, wm, wn) kernel the launcher would pick, in bytes.
 size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk = 32, bool tn_transpose = false);
 
-// Launches one grouped GEMM.  wm/wn pick the block tile: (64*wm) x (64*wn); wm = 1, wn = 0: the 64 x 32 tile (128 threads).
+// Launches one grouped GEMM.  wm/wn pick the block tile: (64*wm) x (64*wn).
 // bk: K-step, 32 or 16 (16 only changes the 128x128 tiles: 40 KB of LDS instead of 72).
 int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st, int bk = 32);
 

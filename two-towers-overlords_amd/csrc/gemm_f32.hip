@@ -43,12 +43,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // under the MFMAs of tile t.  The scalar path (any shape) is correct, not fast.
 //
 // K-contiguous operand: tile [R rows][BK], element (row, k) at P[(r0+row)*ld + k0+k].
-template <int R, int BK, bool VEC, bool FULL, int NTH = kThreads>
-__device__ __forceinline__ void gload_kc(float4 (&v)[R * BK / 4 / NTH], const float* __restrict__ P,
+template <int R, int BK, bool VEC, bool FULL>
+__device__ __forceinline__ void gload_kc(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
                                          int ld, int r0, int rmax, int k0, int kend, int tid) {
 #pragma unroll
-  for (int i = 0; i < R * BK / 4 / NTH; ++i) {
-    const int f = tid + i * NTH;
+  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
     const int row = f / (BK / 4), kq = f % (BK / 4);
     const int gr = r0 + row, gk = k0 + kq * 4;
     if (FULL) {  // interior tile: nothing to guard, so the load stays unconditional and countable
@@ -71,24 +71,24 @@ __device__ __forceinline__ void gload_kc(float4 (&v)[R * BK / 4 / NTH], const fl
     }
   }
 }
-template <int R, int BK, int NTH = kThreads>
-__device__ __forceinline__ void sstore_kc(const float4 (&v)[R * BK / 4 / NTH], float* __restrict__ T, int tid) {
+template <int R, int BK>
+__device__ __forceinline__ void sstore_kc(const float4 (&v)[R * BK / 4 / kThreads], float* __restrict__ T, int tid) {
 #pragma unroll
-  for (int i = 0; i < R * BK / 4 / NTH; ++i) {
-    const int f = tid + i * NTH;
+  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
     const int row = f / (BK / 4), kq = f % (BK / 4);
     *reinterpret_cast<float4*>(T + row * (BK + 4) + kq * 4) = v[i];
   }
 }
 // K-strided operand: tile [BK][R cols], element (k, col) at P[(k0+k)*ld + r0+col].
 // VEC additionally needs rmax % 4 == 0 (a 4-column chunk is all in or all out).
-template <int R, int BK, bool VEC, bool FULL, int NTH = kThreads>
-__device__ __forceinline__ void gload_ks(float4 (&v)[R * BK / 4 / NTH], const float* __restrict__ P,
+template <int R, int BK, bool VEC, bool FULL>
+__device__ __forceinline__ void gload_ks(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
                                          int ld, int r0, int rmax, int k0, int kend, int tid) {
   constexpr int RQ = R / 4;
 #pragma unroll
-  for (int i = 0; i < R * BK / 4 / NTH; ++i) {
-    const int f = tid + i * NTH;
+  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
     const int krow = f / RQ, rq = f % RQ;
     const int gk = k0 + krow, gr = r0 + rq * 4;
     if (FULL) {
@@ -111,12 +111,12 @@ __device__ __forceinline__ void gload_ks(float4 (&v)[R * BK / 4 / NTH], const fl
     }
   }
 }
-template <int R, int BK, int NTH = kThreads>
-__device__ __forceinline__ void sstore_ks(const float4 (&v)[R * BK / 4 / NTH], float* __restrict__ T, int tid) {
+template <int R, int BK>
+__device__ __forceinline__ void sstore_ks(const float4 (&v)[R * BK / 4 / kThreads], float* __restrict__ T, int tid) {
   constexpr int RQ = R / 4;
 #pragma unroll
-  for (int i = 0; i < R * BK / 4 / NTH; ++i) {
-    const int f = tid + i * NTH;
+  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
     const int krow = f / RQ, rq = f % RQ;
     *reinterpret_cast<float4*>(T + krow * R + rq * 4) = v[i];
   }
@@ -137,13 +137,13 @@ __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, 
 // P[(k0+k)*ld + r0+col].  A thread takes FOUR CONSECUTIVE k of ONE column (dword loads, coalesced across lanes =
 // consecutive columns); the chunk is then stored like a K-contiguous operand's (sstore_kt -> [R][BK+4] image).
 // A thread's column is tid % R in every chunk (kThreads % R == 0), which the kTN column sums rely on.
-template <int R, int BK, bool FULL, int NTH = kThreads>
-__device__ __forceinline__ void gload_kt(float4 (&v)[R * BK / 4 / NTH], const float* __restrict__ P,
+template <int R, int BK, bool FULL>
+__device__ __forceinline__ void gload_kt(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
                                          int ld, int r0, int rmax, int k0, int kend, int tid) {
-  static_assert(NTH % R == 0, "one column per thread");
+  static_assert(kThreads % R == 0, "one column per thread");
 #pragma unroll
-  for (int i = 0; i < R * BK / 4 / NTH; ++i) {
-    const int f = tid + i * NTH;
+  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
     const int col = f % R, kq = f / R;
     const int gr = r0 + col, gk = k0 + 4 * kq;
     if (FULL) {
@@ -162,11 +162,11 @@ __device__ __forceinline__ void gload_kt(float4 (&v)[R * BK / 4 / NTH], const fl
     }
   }
 }
-template <int R, int BK, int NTH = kThreads>
-__device__ __forceinline__ void sstore_kt(const float4 (&v)[R * BK / 4 / NTH], float* __restrict__ T, int tid) {
+template <int R, int BK>
+__device__ __forceinline__ void sstore_kt(const float4 (&v)[R * BK / 4 / kThreads], float* __restrict__ T, int tid) {
 #pragma unroll
-  for (int i = 0; i < R * BK / 4 / NTH; ++i) {
-    const int f = tid + i * NTH;
+  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
+    const int f = tid + i * kThreads;
     const int col = f % R, kq = f / R;
     // lanes = consecutive columns, 36- (or 20-) word rows: the 8 lanes of a 128-byte ds_write_b128 phase start
     // 4 banks apart, so the write is conflict-free like the reads
@@ -175,14 +175,10 @@ __device__ __forceinline__ void sstore_kt(const float4 (&v)[R * BK / 4 / NTH], f
 }
 
 // TNT (kTN only): both operands staged through gload_kt / sstore_kt into K-contiguous images.
-// WC: wave columns of the workgroup (2: the 2x2 waves of every tile so far, 256 threads; 1: two waves stacked over the
-// rows, 128 threads, a 64 x 32 tile — half a 64x64 tile, for shapes that leave the chip short of workgroups).
-template <int LAYOUT, int WM, int WN, int BK = 32, bool TNT = false, int WC = 2>
+template <int LAYOUT, int WM, int WN, int BK = 32, bool TNT = false>
 struct TileCfg {
   static_assert(!TNT || LAYOUT == kTN, "register-transposed staging is for kTN");
-  static_assert(WC == 2 || (WC == 1 && WM == 1 && WN == 1 && BK == 32), "the two-wave tile is 64 x 32, K-step 32");
-  static constexpr int NTH = 128 * WC;
-  static constexpr int BM = 64 * WM, BN = 32 * WN * WC, BKP = BK + 4;
+  static constexpr int BM = 64 * WM, BN = 64 * WN, BKP = BK + 4;
   static constexpr bool A_KC = (LAYOUT != kTN) || TNT;   // K-contiguous LDS image
   static constexpr bool B_KC = (LAYOUT == kNT) || TNT;
   static constexpr int A_TILE = A_KC ? BM * BKP : BK * BM;
@@ -196,16 +192,16 @@ struct TileCfg {
 };
 
 // One workgroup's tile: (bx, by) tile coordinates, bz = group * nsplit + split.
-template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32, bool TNT = false, int WC = 2>
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32, bool TNT = false>
 __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ lds, int bx, int by, int bz) {
-  using Cfg = TileCfg<LAYOUT, WM, WN, BK, TNT, WC>;
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, NTH = Cfg::NTH;
+  using Cfg = TileCfg<LAYOUT, WM, WN, BK, TNT>;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
   [[maybe_unused]] constexpr int BKP = Cfg::BKP;
   constexpr bool A_KC = Cfg::A_KC;
   constexpr bool B_KC = Cfg::B_KC;
   constexpr int A_TILE = Cfg::A_TILE;
   constexpr int B_TILE = Cfg::B_TILE;
-  constexpr int NVA = BM * BK / 4 / NTH, NVB = BN * BK / 4 / NTH;
+  constexpr int NVA = BM * BK / 4 / kThreads, NVB = BN * BK / 4 / kThreads;
   static_assert(NVA >= 1 && NVB >= 1, "a K-step of the tile is at least one 16-byte chunk per thread");
 
   constexpr int CP = Cfg::CP;  // padded row of the epilogue's C tile
@@ -236,7 +232,7 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int wrow = WC == 2 ? wave >> 1 : wave, wcol = WC == 2 ? wave & 1 : 0;
+  const int wrow = wave >> 1, wcol = wave & 1;
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -259,28 +255,28 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   auto gload = [&](float4 (&ra)[NVA], float4 (&rb)[NVB], int k0, auto full_tag) {
     constexpr bool F = decltype(full_tag)::value;
     if constexpr (TNT) {
-      gload_kt<BM, BK, F, NTH>(ra, gA, lda, m0, M, k0, kend, tid);
-      gload_kt<BN, BK, F, NTH>(rb, gB, ldb, n0, N, k0, kend, tid);
+      gload_kt<BM, BK, F>(ra, gA, lda, m0, M, k0, kend, tid);
+      gload_kt<BN, BK, F>(rb, gB, ldb, n0, N, k0, kend, tid);
     } else {
-      if constexpr (A_KC) gload_kc<BM, BK, VEC, F, NTH>(ra, gA, lda, m0, M, k0, kend, tid);
-      else gload_ks<BM, BK, VEC, F, NTH>(ra, gA, lda, m0, M, k0, kend, tid);
-      if constexpr (B_KC) gload_kc<BN, BK, VEC, F, NTH>(rb, gB, ldb, n0, N, k0, kend, tid);
-      else gload_ks<BN, BK, VEC, F, NTH>(rb, gB, ldb, n0, N, k0, kend, tid);
+      if constexpr (A_KC) gload_kc<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+      else gload_ks<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+      if constexpr (B_KC) gload_kc<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+      else gload_ks<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
     }
   };
   auto sstore = [&](const float4 (&ra)[NVA], const float4 (&rb)[NVB], int buf) {
     float* As = lds + buf * (A_TILE + B_TILE);
     float* Bs = As + A_TILE;
     if constexpr (TNT) {
-      sstore_kt<BM, BK, NTH>(ra, As, tid);
-      sstore_kt<BN, BK, NTH>(rb, Bs, tid);
+      sstore_kt<BM, BK>(ra, As, tid);
+      sstore_kt<BN, BK>(rb, Bs, tid);
       if (do_colsum) {  // this thread's A chunks are all of column tid % BM (gload_kt); k ascending within the thread
 #pragma unroll
         for (int i = 0; i < NVA; ++i) csum += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
       }
     } else {
-      if (A_KC) sstore_kc<BM, BK, NTH>(ra, As, tid); else sstore_ks<BM, BK, NTH>(ra, As, tid);
-      if (B_KC) sstore_kc<BN, BK, NTH>(rb, Bs, tid); else sstore_ks<BN, BK, NTH>(rb, Bs, tid);
+      if (A_KC) sstore_kc<BM, BK>(ra, As, tid); else sstore_ks<BM, BK>(ra, As, tid);
+      if (B_KC) sstore_kc<BN, BK>(rb, Bs, tid); else sstore_ks<BN, BK>(rb, Bs, tid);
     }
   };
   auto compute = [&](int buf) {
@@ -360,13 +356,13 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   if (VEC && full) kloop(std::true_type{});
   else kloop(std::false_type{});
   if constexpr (TNT) {
-    if (do_colsum) {  // NTH / BM threads hold partial sums of each column: add them in thread order (LDS is free here)
+    if (do_colsum) {  // kThreads / BM threads hold partial sums of each column: add them in thread order (LDS is free here)
       lds[tid] = csum;
       __syncthreads();
       if (tid < BM) {
         csum = lds[tid];
 #pragma unroll
-        for (int t = 1; t < NTH / BM; ++t) csum += lds[tid + t * BM];
+        for (int t = 1; t < kThreads / BM; ++t) csum += lds[tid + t * BM];
       }
       __syncthreads();
     }
@@ -384,11 +380,11 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   const bool vecC = VEC && ((ldc & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(gC) & 15) == 0) &&
                     ((b.slab_stride & 3) == 0) &&
                     (EPI != kReluMask || (((ldaux & 3) == 0) && ((reinterpret_cast<uintptr_t>(gaux) & 15) == 0)));
-  constexpr int NI = EP_ROWS * BN / 4 / NTH;  // 16-byte chunks of one pass per thread
-  static_assert(NTH % (BN / 4) == 0, "every chunk of a thread lies in the same 4 columns");
+  constexpr int NI = EP_ROWS * BN / 4 / kThreads;  // 16-byte chunks of one pass per thread
+  static_assert(kThreads % (BN / 4) == 0, "every chunk of a thread lies in the same 4 columns");
   const int c4 = (tid % (BN / 4)) * 4, n = n0 + c4;
   const int row_first = tid / (BN / 4);
-  constexpr int ROW_STEP = NTH / (BN / 4);
+  constexpr int ROW_STEP = kThreads / (BN / 4);
 #pragma unroll
   for (int ep = 0; ep < EP; ++ep) {
     if (ep > 0) __syncthreads();  // the previous pass has been read out
@@ -550,16 +546,6 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
   gemm_body<LAYOUT, EPI, WM, WN, VEC, BK, TNT>(b, lds, bx, by, bz);
 }
 
-// The 64 x 32 tile: two waves stacked over the rows, 128 threads, 27 KB of LDS.  Twice the workgroups of the 64x64 tile
-// for the same product — for shapes where 64x64 tiles leave the 256 compute units with one or two workgroups each.
-template <int LAYOUT, int EPI, bool TNT = false>
-__global__ __launch_bounds__(128) void gemm_f32_n32_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, 1, 1, 32, TNT, 1>::LDS_FLOATS];
-  int bx, by, bz;
-  if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
-  gemm_body<LAYOUT, EPI, 1, 1, true, 32, TNT, 1>(b, lds, bx, by, bz);
-}
-
 // The BK = 16 tile shares a CU with the streaming gather's workgroup (gather_pool.hip): three waves per SIMD's worth
 // of registers (<= 168) leave room for two of these workgroups plus the gather's 4 waves of up to 176.
 // (A 128-register build — a few dwords of scratch outside the K loop — changed nothing at configs[3]: 6.14-6.31 vs
@@ -613,18 +599,6 @@ bool problem_vec_ok(const Problem& p) {
 }
 
 // kTN tiles exist in two staging forms (template TNT); every other layout has one.
-template <int LAYOUT, int EPI>
-void launch_tile_n32(const Batch& b, dim3 grid, hipStream_t st) {
-  const dim3 block(128);
-  if constexpr (LAYOUT == kTN) {
-    if (b.tn_transpose) {
-      hipLaunchKernelGGL((gemm_f32_n32_kernel<LAYOUT, EPI, true>), grid, block, 0, st, b);
-      return;
-    }
-  }
-  hipLaunchKernelGGL((gemm_f32_n32_kernel<LAYOUT, EPI>), grid, block, 0, st, b);
-}
-
 template <int LAYOUT, int EPI, int WM, int WN, int BK>
 void launch_tile(const Batch& b, dim3 grid, hipStream_t st) {
   const dim3 block(kThreads);
@@ -648,12 +622,11 @@ int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
     maxN = b.p[i].N > maxN ? b.p[i].N : maxN;
   }
   if (maxM == 0 || maxN == 0) return TT_OK;
-  bool vec = true;
-  for (int i = 0; i < b.count; ++i) vec = vec && (b.p[i].M == 0 || problem_vec_ok<LAYOUT>(b.p[i]));
-  if (wn == 0 && !vec) wn = 1;  // the 64 x 32 tile exists on the vector path only
-  const int BM = 64 * wm, BN = wn == 0 ? 32 : 64 * wn;
+  const int BM = 64 * wm, BN = 64 * wn;
   dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count * b.nsplit);
   const dim3 block(kThreads);
+  bool vec = true;
+  for (int i = 0; i < b.count; ++i) vec = vec && (b.p[i].M == 0 || problem_vec_ok<LAYOUT>(b.p[i]));
   if (!vec) b.xcd_order = 0;
   if (b.xcd_order) {  // 1-D grid, 8 classes x (their share of the sharing groups, rounded up) x tiles per group
     b.gx = (int)grid.x; b.gy = (int)grid.y; b.gz = (int)grid.z;
@@ -664,7 +637,6 @@ int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
     else grid = dim3((unsigned)total, 1, 1);
   }
   if (!vec) hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, 1, 1, false>), dim3((maxN + 63) / 64, (maxM + 63) / 64, b.count * b.nsplit), block, 0, st, b);
-  else if (wm == 1 && wn == 0) launch_tile_n32<LAYOUT, EPI>(b, grid, st);
   else if (wm == 1 && wn == 1) launch_tile<LAYOUT, EPI, 1, 1, 32>(b, grid, st);
   else if (wm == 2 && wn == 1) launch_tile<LAYOUT, EPI, 2, 1, 32>(b, grid, st);
   else if (wm == 2 && wn == 2 && bk == 16) launch_tile<LAYOUT, EPI, 2, 2, 16>(b, grid, st);  // shares a CU with the streaming gather
@@ -680,7 +652,7 @@ int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStrea
   bool vec = true;
   for (int i = 0; i < bt.count; ++i) vec = vec && (bt.p[i].M == 0 || problem_vec_ok<kTN>(bt.p[i]));
   for (int i = 0; i < bn.count; ++i) vec = vec && (bn.p[i].M == 0 || problem_vec_ok<kNN>(bn.p[i]));
-  if (!vec || !((wm == 1 && wn == 1) || (wm == 2 && wn == 1))) {  // odd shapes / the 64 x 32 tile: two ordinary launches
+  if (!vec || !((wm == 1 && wn == 1) || (wm == 2 && wn == 1))) {  // odd shapes: two ordinary launches
     int rc = launch(kTN, kStore, bt, 1, 1, st);
     if (rc != TT_OK) return rc;
     return launch(kNN, kReluMask, bn, wm, wn, st);
@@ -723,12 +695,6 @@ static size_t lds_of(Layout layout, bool tnt) {
 }
 
 size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk, bool tn_transpose) {
-  if (wn == 0) {  // 64 x 32
-    const int f = layout == kNT ? TileCfg<kNT, 1, 1, 32, false, 1>::LDS_FLOATS
-                                : layout == kNN ? TileCfg<kNN, 1, 1, 32, false, 1>::LDS_FLOATS
-                                                : tn_transpose ? TileCfg<kTN, 1, 1, 32, true, 1>::LDS_FLOATS : TileCfg<kTN, 1, 1, 32, false, 1>::LDS_FLOATS;
-    return (size_t)f * sizeof(float);
-  }
   if (wm == 2 && wn == 2 && bk == 16) return lds_of<2, 2, 16>(layout, tn_transpose);
   if (wm == 2 && wn == 2) return lds_of<2, 2, 32>(layout, tn_transpose);
   if (wm == 2 && wn == 1) return lds_of<2, 1, 32>(layout, tn_transpose);

@@ -54,7 +54,6 @@ static int tn_transpose_for(const Plan& pl) {
 // BERT sizes), or — beside the streaming gather — 128x128 with K-step 16: a quarter of the operand re-reads.
 static void pick_tn_tile(int M, int N, const Plan& pl, int& wm, int& wn, int& bk) {
   wm = wn = 1; bk = 32;
-  if (pl.t.tn_tile == 10) { wn = 0; return; }  // 64 x 32
   const bool big = pl.t.tn_tile ? pl.t.tn_tile == 22 : pl.policy == kTileStream;
   if (big && M >= 256 && N >= 256) { wm = wn = 2; bk = 16; }
 }
@@ -66,8 +65,8 @@ static void pick_tn_tile(int M, int N, const Plan& pl, int& wm, int& wn, int& bk
 static void pick_tile(long long total_rows, int N, int& wm, int& wn, int& bk, const Plan& pl) {
   const bool low_traffic = pl.policy == kTileLowTraffic;
   bk = 32;
-  if (pl.t.proj_tile == 10 || pl.t.proj_tile == 11 || pl.t.proj_tile == 21 || pl.t.proj_tile == 22) {
-    wm = pl.t.proj_tile / 10; wn = pl.t.proj_tile % 10;  // 10: 64 x 32
+  if (pl.t.proj_tile == 11 || pl.t.proj_tile == 21 || pl.t.proj_tile == 22) {
+    wm = pl.t.proj_tile / 10; wn = pl.t.proj_tile % 10;
     if (wm == 2 && wn == 2 && pl.t.proj_bk == 16) bk = 16;
     return;
   }
@@ -88,7 +87,7 @@ size_t chain_lds_bytes(long long rows, int P, const Plan& pl) {
   pick_tile(rows, P, wm, wn, bk, pl);
   size_t m = ttg::tile_lds_bytes(ttg::kNT, wm, wn, bk);
   const size_t nn = ttg::tile_lds_bytes(ttg::kNN, wm, wn, bk);
-  const size_t tn = ttg::tile_lds_bytes(ttg::kTN, 1, pl.t.tn_tile == 10 ? 0 : 1, 32, tn_transpose_for(pl) != 0);
+  const size_t tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1, 32, tn_transpose_for(pl) != 0);
   m = nn > m ? nn : m;
   return tn > m ? tn : m;
 }
@@ -181,7 +180,7 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
   pick_tile(rows, P, wm, wn, bk, pl);
   int tm, tn, tbk;
   pick_tn_tile(P, P, pl, tm, tn, tbk);
-  if ((wm == 2 && wn == 2) || wn == 0 || tm != 1 || tn != 1) {  // the fused kernel carries 64x64 TN tiles beside 64x64 / 128x64 NN tiles only
+  if ((wm == 2 && wn == 2) || tm != 1) {  // the fused kernel carries 64x64 TN tiles beside 64x64 / 128x64 NN tiles only
     int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, tm, tn, st, tbk);
     if (rc != TT_OK) return rc;
     return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st, bk);

@@ -83,8 +83,7 @@ typedef struct {
   int32_t xcd_order;       /* XCD-aware workgroup order of the projection GEMMs: 1 on, -1 off */
   int32_t backward;        /* engine: TT_BWD_* schedule of phase B's backward */
   int32_t k1_stream_linger;/* streaming K1: ~microseconds a turned-away candidate lingers before it leaves (auto: 0) */
-  int32_t tn_transpose;    /* weight-gradient GEMMs: stage the K-strided operands through a register transpose into
-                              K-contiguous LDS images (one ds_read_b128 per fragment): 1 on, -1 off */
+  int32_t reserved0;       /* must be 0 (round 4's transposed kTN staging lived here; measured, no gain, removed) */
   int32_t event_scope;     /* engine: release scope of the events that order its two streams: 1 no system-scope fence
                               (hipEventDisableSystemFence; auto), 2 device-scope release (hipEventReleaseToDevice),
                               3 HIP's default (system-scope fence when the event is recorded) */

@@ -3,7 +3,7 @@
 runs decide anything).  Every variant is a fresh `python bench.py` process; variants differ in their bench arguments —
 typically `--tune FIELD=VALUE` (tt_tuning: per-engine, nothing process-wide).
 
-    tools/ab_tune.py [--rounds 3] [--out gpurun_out/ab.txt] -v "base:" -v "tnt:--tune tn_transpose=1" -- --config c3 --steps 200
+    tools/ab_tune.py [--rounds 3] [--out gpurun_out/ab.txt] -v "base:" -v "t22:--tune proj_tile=22" -- --config c3 --steps 200
 
 Prints one line per run (step time, K1 in the loop, streaming-K1 census if TT_TRACE is set) and the per-variant medians."""
 import argparse

@@ -47,16 +47,14 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         if "gemm" in n:
             mt = re.search(r"(gemm\w*_kernel<[^>]*>)", n)
             acc[mt.group(1) if mt else n[:80]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-print("==", sys.argv[2], "(template args: layout 0 NT / 1 NN / 2 TN, epilogue, tile wm, wn, [vector path], [K-step], [transposed TN staging])")
+print("==", sys.argv[2], "(template args: layout 0 NT / 1 NN / 2 TN, epilogue, tile wm, wn, [vector path], [K-step])")
 for k, c in sorted(acc.items()):
     m = {n: sum(v[len(v) // 2:]) / max(len(v[len(v) // 2:]), 1) for n, v in c.items()}
     print(f"{k:56s} mfma_util {m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / max(m.get('GRBM_GUI_ACTIVE', 0) / 8, 1):5.3f}   launches {len(c.get('GRBM_GUI_ACTIVE', []))}")
 PY
   rm -rf $out/pmc_$tag; }
 mfma c2 "configs[1] B=2048 D=P=384 (one stream)" --steps 40 --warmup 2
-mfma c2tnt "configs[1] with the weight gradients staged through a register transpose (--tune tn_transpose=1)" --steps 40 --warmup 2 --tune tn_transpose=1
 mfma c2fork "configs[1], fork backward (TN and NN as separate launches)" --steps 40 --warmup 2 --tune backward=fork
-mfma c2forktnt "configs[1], fork backward, transposed TN staging" --steps 40 --warmup 2 --tune backward=fork --tune tn_transpose=1
 mfma c3 "configs[2] one GPU's share B=1024 P=512 (one stream)" --config c3 --steps 40 --warmup 2
 mfma c4bk16 "configs[3] with the tiles used beside the streaming gather (K-step 16, 128x128 TN, XCD order)" --config c4 --steps 6 --warmup 2 --tune proj_tile=22 --tune proj_bk=16 --tune tn_tile=22 --tune xcd_order=1
 cat $out/${r}_k2_mfma_util.txt

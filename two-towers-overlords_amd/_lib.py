@@ -71,13 +71,13 @@ class TTTuning(C.Structure):
         ("xcd_order", C.c_int32),
         ("backward", C.c_int32),
         ("k1_stream_linger", C.c_int32),
-        ("tn_transpose", C.c_int32),
+        ("reserved0", C.c_int32),
         ("event_scope", C.c_int32),
         ("reserved", C.c_int32 * 3),
     ]
 
 
-TUNING_FIELDS = tuple(n for n, _ in TTTuning._fields_ if n != "reserved")
+TUNING_FIELDS = tuple(n for n, _ in TTTuning._fields_ if not n.startswith("reserved"))
 
 
 def make_tuning(tuning=None):

@@ -58,15 +58,11 @@ struct Batch {
   // Worth it where the fabric is the shared bottleneck (beside the streaming gather); 0 = plain 3-D grid.
   HingeEpi hinge;  // kHinge only
   int xcd_order;
-  // kTN only: stage both (K-strided) operands through a register transpose into K-contiguous LDS images, so that a
-  // fragment is one ds_read_b128 instead of four ds_read_b32 (same products in the same order: bitwise the same C;
-  // the bias-gradient column sums are added in another order)
-  int tn_transpose;
   int gx, gy, gz;         // tile grid (filled by the launcher when xcd_order is set)
 };
 
 // Static LDS of one workgroup of the (layout, wm, wn) kernel the launcher would pick, in bytes.
-size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk = 32, bool tn_transpose = false);
+size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk = 32);
 
 // Launches one grouped GEMM.  wm/wn pick the block tile: (64*wm) x (64*wn).
 // bk: K-step, 32 or 16 (16 only changes the 128x128 tiles: 40 KB of LDS instead of 72).

@@ -14,9 +14,10 @@
 // the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots); a
 // K-strided operand ([K][cols] in memory: W2 in NN, dOut/H/X in TN) sits in a
 // [32][cols] image and is read with conflict-free ds_read_b32 (lanes =
-// consecutive columns).  kTN (both operands K-strided: the weight gradients) may instead transpose on the way in
-// (TNT: a thread loads four consecutive k of ONE column with dword loads, coalesced across lanes, and writes them
-// as one 16-byte chunk of a K-contiguous [cols][32+4] image), so that its fragments are one ds_read_b128 as well.
+// consecutive columns).  (Round 4 built the alternative for kTN — both K-strided operands transposed in the register
+// file on their way in, four consecutive k of one column per thread, so that its fragments are one ds_read_b128 as well;
+// bitwise the same products — and measured it: no gain at any shape, one-stream configs[3] 1.6 % slower;
+// profiles/r04_tn_transpose_ab.txt.  Removed: 32 ds_read_b32 per K-step and wave are 256 LDS clocks against 1024 MFMA clocks.)
 //
 // Numerics: each C element is a k-ordered fmaf chain in fp32 (what the MFMA
 // computes, bitwise), K-steps in ascending order; split-K (kTN) partials go to
@@ -133,54 +134,11 @@ __device__ __forceinline__ float4 frag_ks(const float* __restrict__ T, int col, 
   return make_float4(p[0], p[R], p[2 * R], p[3 * R]);
 }
 
-// K-strided operand, transposed in the register file (kTN with TNT): tile [BK][R cols], element (k, col) at
-// P[(k0+k)*ld + r0+col].  A thread takes FOUR CONSECUTIVE k of ONE column (dword loads, coalesced across lanes =
-// consecutive columns); the chunk is then stored like a K-contiguous operand's (sstore_kt -> [R][BK+4] image).
-// A thread's column is tid % R in every chunk (kThreads % R == 0), which the kTN column sums rely on.
-template <int R, int BK, bool FULL>
-__device__ __forceinline__ void gload_kt(float4 (&v)[R * BK / 4 / kThreads], const float* __restrict__ P,
-                                         int ld, int r0, int rmax, int k0, int kend, int tid) {
-  static_assert(kThreads % R == 0, "one column per thread");
-#pragma unroll
-  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
-    const int f = tid + i * kThreads;
-    const int col = f % R, kq = f / R;
-    const int gr = r0 + col, gk = k0 + 4 * kq;
-    if (FULL) {
-      const float* __restrict__ src = P + (long long)gk * ld + gr;
-      v[i] = make_float4(src[0], src[ld], src[2 * (long long)ld], src[3 * (long long)ld]);
-    } else {
-      float x[4];
-      const int cr = min(gr, rmax - 1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool ok = gr < rmax && gk + j < kend;
-        const float t = P[(long long)min(gk + j, kend - 1) * ld + cr];
-        x[j] = ok ? t : 0.f;
-      }
-      v[i] = make_float4(x[0], x[1], x[2], x[3]);
-    }
-  }
-}
-template <int R, int BK>
-__device__ __forceinline__ void sstore_kt(const float4 (&v)[R * BK / 4 / kThreads], float* __restrict__ T, int tid) {
-#pragma unroll
-  for (int i = 0; i < R * BK / 4 / kThreads; ++i) {
-    const int f = tid + i * kThreads;
-    const int col = f % R, kq = f / R;
-    // lanes = consecutive columns, 36- (or 20-) word rows: the 8 lanes of a 128-byte ds_write_b128 phase start
-    // 4 banks apart, so the write is conflict-free like the reads
-    *reinterpret_cast<float4*>(T + col * (BK + 4) + kq * 4) = v[i];
-  }
-}
-
-// TNT (kTN only): both operands staged through gload_kt / sstore_kt into K-contiguous images.
-template <int LAYOUT, int WM, int WN, int BK = 32, bool TNT = false>
+template <int LAYOUT, int WM, int WN, int BK = 32>
 struct TileCfg {
-  static_assert(!TNT || LAYOUT == kTN, "register-transposed staging is for kTN");
   static constexpr int BM = 64 * WM, BN = 64 * WN, BKP = BK + 4;
-  static constexpr bool A_KC = (LAYOUT != kTN) || TNT;   // K-contiguous LDS image
-  static constexpr bool B_KC = (LAYOUT == kNT) || TNT;
+  static constexpr bool A_KC = (LAYOUT != kTN);   // K-contiguous LDS image
+  static constexpr bool B_KC = (LAYOUT == kNT);
   static constexpr int A_TILE = A_KC ? BM * BKP : BK * BM;
   static constexpr int B_TILE = B_KC ? BN * BKP : BK * BN;
   static constexpr int CP = BN + 4;  // padded row of the epilogue's C tile
@@ -192,9 +150,9 @@ struct TileCfg {
 };
 
 // One workgroup's tile: (bx, by) tile coordinates, bz = group * nsplit + split.
-template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32, bool TNT = false>
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32>
 __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ lds, int bx, int by, int bz) {
-  using Cfg = TileCfg<LAYOUT, WM, WN, BK, TNT>;
+  using Cfg = TileCfg<LAYOUT, WM, WN, BK>;
   constexpr int BM = 64 * WM, BN = 64 * WN;
   [[maybe_unused]] constexpr int BKP = Cfg::BKP;
   constexpr bool A_KC = Cfg::A_KC;
@@ -254,30 +212,16 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   const bool full = VEC && (m0 + BM <= M) && (n0 + BN <= N) && ((kend - kbeg) % BK == 0);
   auto gload = [&](float4 (&ra)[NVA], float4 (&rb)[NVB], int k0, auto full_tag) {
     constexpr bool F = decltype(full_tag)::value;
-    if constexpr (TNT) {
-      gload_kt<BM, BK, F>(ra, gA, lda, m0, M, k0, kend, tid);
-      gload_kt<BN, BK, F>(rb, gB, ldb, n0, N, k0, kend, tid);
-    } else {
-      if constexpr (A_KC) gload_kc<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
-      else gload_ks<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
-      if constexpr (B_KC) gload_kc<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
-      else gload_ks<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
-    }
+    if constexpr (A_KC) gload_kc<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+    else gload_ks<BM, BK, VEC, F>(ra, gA, lda, m0, M, k0, kend, tid);
+    if constexpr (B_KC) gload_kc<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
+    else gload_ks<BN, BK, VEC, F>(rb, gB, ldb, n0, N, k0, kend, tid);
   };
   auto sstore = [&](const float4 (&ra)[NVA], const float4 (&rb)[NVB], int buf) {
     float* As = lds + buf * (A_TILE + B_TILE);
     float* Bs = As + A_TILE;
-    if constexpr (TNT) {
-      sstore_kt<BM, BK>(ra, As, tid);
-      sstore_kt<BN, BK>(rb, Bs, tid);
-      if (do_colsum) {  // this thread's A chunks are all of column tid % BM (gload_kt); k ascending within the thread
-#pragma unroll
-        for (int i = 0; i < NVA; ++i) csum += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
-      }
-    } else {
-      if (A_KC) sstore_kc<BM, BK>(ra, As, tid); else sstore_ks<BM, BK>(ra, As, tid);
-      if (B_KC) sstore_kc<BN, BK>(rb, Bs, tid); else sstore_ks<BN, BK>(rb, Bs, tid);
-    }
+    if (A_KC) sstore_kc<BM, BK>(ra, As, tid); else sstore_ks<BM, BK>(ra, As, tid);
+    if (B_KC) sstore_kc<BN, BK>(rb, Bs, tid); else sstore_ks<BN, BK>(rb, Bs, tid);
   };
   auto compute = [&](int buf) {
     const float* __restrict__ As = lds + buf * (A_TILE + B_TILE);
@@ -305,7 +249,7 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
           acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[jj].w, acc[i][jj], 0, 0, 0);
         }
     }
-    if constexpr (LAYOUT == kTN && !TNT) {
+    if constexpr (LAYOUT == kTN) {
       if (do_colsum && tid < BM) {
 #pragma unroll
         for (int k = 0; k < BK; ++k) csum += As[k * BM + tid];
@@ -355,18 +299,6 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   };
   if (VEC && full) kloop(std::true_type{});
   else kloop(std::false_type{});
-  if constexpr (TNT) {
-    if (do_colsum) {  // kThreads / BM threads hold partial sums of each column: add them in thread order (LDS is free here)
-      lds[tid] = csum;
-      __syncthreads();
-      if (tid < BM) {
-        csum = lds[tid];
-#pragma unroll
-        for (int t = 1; t < kThreads / BM; ++t) csum += lds[tid + t * BM];
-      }
-      __syncthreads();
-    }
-  }
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*h.
   // The tile goes through LDS (free after the K loop's last barrier) so that global
@@ -538,25 +470,25 @@ __device__ __forceinline__ bool tile_coords(const Batch& b, int& bx, int& by, in
   return true;
 }
 
-template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32, bool TNT = false>
+template <int LAYOUT, int EPI, int WM, int WN, bool VEC, int BK = 32>
 __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, BK, TNT>::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, BK>::LDS_FLOATS];
   int bx, by, bz;
   if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
-  gemm_body<LAYOUT, EPI, WM, WN, VEC, BK, TNT>(b, lds, bx, by, bz);
+  gemm_body<LAYOUT, EPI, WM, WN, VEC, BK>(b, lds, bx, by, bz);
 }
 
 // The BK = 16 tile shares a CU with the streaming gather's workgroup (gather_pool.hip): three waves per SIMD's worth
 // of registers (<= 168) leave room for two of these workgroups plus the gather's 4 waves of up to 176.
 // (A 128-register build — a few dwords of scratch outside the K loop — changed nothing at configs[3]: 6.14-6.31 vs
 // 6.13-6.31 ms, profiles/r03_c4_128_register_tiles_ab.txt.)
-template <int LAYOUT, int EPI, int WM, int WN, bool TNT = false>
+template <int LAYOUT, int EPI, int WM, int WN>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 8)))
 void gemm_f32_bk16_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, 16, TNT>::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[TileCfg<LAYOUT, WM, WN, 16>::LDS_FLOATS];
   int bx, by, bz;
   if (!tile_coords<LAYOUT>(b, bx, by, bz)) return;
-  gemm_body<LAYOUT, EPI, WM, WN, true, 16, TNT>(b, lds, bx, by, bz);
+  gemm_body<LAYOUT, EPI, WM, WN, true, 16>(b, lds, bx, by, bz);
 }
 
 // Two independent GEMMs of the projection backward in ONE launch: the split-K dW2/db2 (kTN,
@@ -569,9 +501,9 @@ struct PairGeom {
   int tn_head, nn_blocks;       // workgroup order: TN [0, tn_head), all NN, the remaining TN (longest K loops first)
 };
 
-template <int WM, int WN, bool TNT>
+template <int WM, int WN>
 __global__ __launch_bounds__(kThreads) void gemm_tn_nn_kernel(const Batch bt, const Batch bn, const PairGeom g) {
-  constexpr int LT = TileCfg<kTN, 1, 1, 32, TNT>::LDS_FLOATS, LN = TileCfg<kNN, WM, WN>::LDS_FLOATS;
+  constexpr int LT = TileCfg<kTN, 1, 1>::LDS_FLOATS, LN = TileCfg<kNN, WM, WN>::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LT > LN ? LT : LN];
   int id = blockIdx.x;
   const bool is_tn = id < g.tn_head || id >= g.tn_head + g.nn_blocks;
@@ -579,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_nn_kernel(const Batch bt, co
     if (id >= g.tn_head) id -= g.nn_blocks;
     const int per_z = g.tn_gx * g.tn_gy;
     const int z = id / per_z, rem = id - z * per_z;
-    gemm_body<kTN, kStore, 1, 1, true, 32, TNT>(bt, lds, rem % g.tn_gx, rem / g.tn_gx, z);
+    gemm_body<kTN, kStore, 1, 1, true>(bt, lds, rem % g.tn_gx, rem / g.tn_gx, z);
   } else {
     id -= g.tn_head;
     const int per_z = g.nn_gx * g.nn_gy;
@@ -598,17 +530,9 @@ bool problem_vec_ok(const Problem& p) {
   return p.M % 4 == 0 && p.N % 4 == 0 && p.M >= 4 && p.N >= 4 && p.K >= 1;  // kTN: both K-strided
 }
 
-// kTN tiles exist in two staging forms (template TNT); every other layout has one.
 template <int LAYOUT, int EPI, int WM, int WN, int BK>
 void launch_tile(const Batch& b, dim3 grid, hipStream_t st) {
   const dim3 block(kThreads);
-  if constexpr (LAYOUT == kTN) {
-    if (b.tn_transpose) {
-      if constexpr (BK == 16) hipLaunchKernelGGL((gemm_f32_bk16_kernel<LAYOUT, EPI, WM, WN, true>), grid, block, 0, st, b);
-      else hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, WM, WN, true, 32, true>), grid, block, 0, st, b);
-      return;
-    }
-  }
   if constexpr (BK == 16) hipLaunchKernelGGL((gemm_f32_bk16_kernel<LAYOUT, EPI, WM, WN>), grid, block, 0, st, b);
   else hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI, WM, WN, true>), grid, block, 0, st, b);
 }
@@ -675,30 +599,24 @@ int launch_tn_nn_pair(const Batch& bt, const Batch& bn, int wm, int wn, hipStrea
   // shorter TN problems close the grid (measured against "all TN first" in round 1: 198 -> 196 us per step).
   g.tn_head = (bt.count > 1 && bt.p[0].K > bt.p[1].K) ? g.tn_gx * g.tn_gy * bt.nsplit : g.tn_blocks;
   const dim3 grid((unsigned)total), block(kThreads);
-  if (bt.tn_transpose) {
-    if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1, true>), grid, block, 0, st, bt, bn, g);
-    else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1, true>), grid, block, 0, st, bt, bn, g);
-  } else {
-    if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1, false>), grid, block, 0, st, bt, bn, g);
-    else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1, false>), grid, block, 0, st, bt, bn, g);
-  }
+  if (wm == 1) hipLaunchKernelGGL((gemm_tn_nn_kernel<1, 1>), grid, block, 0, st, bt, bn, g);
+  else hipLaunchKernelGGL((gemm_tn_nn_kernel<2, 1>), grid, block, 0, st, bt, bn, g);
   TT_CHECK_LAUNCH();
   return TT_OK;
 }
 
 template <int WM, int WN, int BK>
-static size_t lds_of(Layout layout, bool tnt) {
+static size_t lds_of(Layout layout) {
   const int f = layout == kNT ? TileCfg<kNT, WM, WN, BK>::LDS_FLOATS
-                              : layout == kNN ? TileCfg<kNN, WM, WN, BK>::LDS_FLOATS
-                                              : tnt ? TileCfg<kTN, WM, WN, BK, true>::LDS_FLOATS : TileCfg<kTN, WM, WN, BK>::LDS_FLOATS;
+                              : layout == kNN ? TileCfg<kNN, WM, WN, BK>::LDS_FLOATS : TileCfg<kTN, WM, WN, BK>::LDS_FLOATS;
   return (size_t)f * sizeof(float);
 }
 
-size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk, bool tn_transpose) {
-  if (wm == 2 && wn == 2 && bk == 16) return lds_of<2, 2, 16>(layout, tn_transpose);
-  if (wm == 2 && wn == 2) return lds_of<2, 2, 32>(layout, tn_transpose);
-  if (wm == 2 && wn == 1) return lds_of<2, 1, 32>(layout, tn_transpose);
-  return lds_of<1, 1, 32>(layout, tn_transpose);
+size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk) {
+  if (wm == 2 && wn == 2 && bk == 16) return lds_of<2, 2, 16>(layout);
+  if (wm == 2 && wn == 2) return lds_of<2, 2, 32>(layout);
+  if (wm == 2 && wn == 1) return lds_of<2, 1, 32>(layout);
+  return lds_of<1, 1, 32>(layout);
 }
 
 int launch(Layout layout, Epilogue epi, const Batch& b, int wm, int wn, hipStream_t st, int bk) {

@@ -44,12 +44,6 @@ static int xcd_order_for(const Plan& pl) {
   return pl.policy == kTileStream;
 }
 
-// kTN staging through a register transpose (gemm_f32.h, Batch::tn_transpose).
-static int tn_transpose_for(const Plan& pl) {
-  if (pl.t.tn_transpose != 0) return pl.t.tn_transpose > 0;
-  return 0;
-}
-
 // Tile of the split-K weight-gradient GEMMs: 64x64 (many short workgroups; pairs with the gather's LDS reservation at
 // BERT sizes), or — beside the streaming gather — 128x128 with K-step 16: a quarter of the operand re-reads.
 static void pick_tn_tile(int M, int N, const Plan& pl, int& wm, int& wn, int& bk) {
@@ -87,7 +81,7 @@ size_t chain_lds_bytes(long long rows, int P, const Plan& pl) {
   pick_tile(rows, P, wm, wn, bk, pl);
   size_t m = ttg::tile_lds_bytes(ttg::kNT, wm, wn, bk);
   const size_t nn = ttg::tile_lds_bytes(ttg::kNN, wm, wn, bk);
-  const size_t tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1, 32, tn_transpose_for(pl) != 0);
+  const size_t tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1);
   m = nn > m ? nn : m;
   return tn > m ? tn : m;
 }
@@ -126,7 +120,6 @@ int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long 
   g2.count = count;
   g2.nsplit = nsplit;
   g2.xcd_order = xcd_order_for(pl);
-  g2.tn_transpose = tn_transpose_for(pl);
   g2.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW2[i,j] = sum_m dOut[m,i] H[m,j];  db2[i] = sum_m dOut[m,i]
@@ -165,7 +158,6 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
   g2.slab_stride = slab_stride;
   gh.nsplit = 1;
   g2.xcd_order = gh.xcd_order = xcd_order_for(pl);
-  g2.tn_transpose = tn_transpose_for(pl);
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -193,7 +185,6 @@ int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long 
   g1.count = count;
   g1.nsplit = nsplit;
   g1.xcd_order = xcd_order_for(pl);
-  g1.tn_transpose = tn_transpose_for(pl);
   g1.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW1[i,j] = sum_m dH[m,i] X[m,j];  db1[i] = sum_m dH[m,i]

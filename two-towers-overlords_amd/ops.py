@@ -212,8 +212,7 @@ def proj_fwd(x, w1, b1, w2, b2, tuning=None) -> Tuple[torch.Tensor, torch.Tensor
 
 
 def proj_bwd(d_out, x, h, w2, tuning=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """K2 backward for the parameters: returns (dW1, db1, dW2, db2).  `tuning`: proj_tile, proj_bk, tn_tile,
-    tn_transpose, xcd_order."""
+    """K2 backward for the parameters: returns (dW1, db1, dW2, db2).  `tuning`: proj_tile, proj_bk, tn_tile, xcd_order."""
     _req(d_out, "d_out", torch.float32, 2)
     _req(x, "x", torch.float32, 2)
     _req(h, "h", torch.float32, 2)

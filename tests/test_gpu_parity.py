@@ -386,7 +386,7 @@ ENGINE_SETUPS = [
     (0, None),
     (-1, None),
     (-1, {"k1_form": "stream"}),                                        # streaming gather -> 128x128 K-step-16 tiles, XCD order
-    (-1, {"k1_form": "stream", "k1_stream_wgs": 1, "k1_stream_rows": 8, "k1_stream_offer": 2, "k1_stream_linger": 3}),
+    (-1, {"k1_form": "stream", "k1_stream_wgs": 1, "k1_stream_rows": 8, "k1_stream_offer": 2}),
     (0, {"k1_form": "rows"}),
     (0, {"k1_form": "columns"}),
     (-1, {"k1_form": "columns", "proj_tile": 21, "xcd_order": 1}),

@@ -70,7 +70,7 @@ class TTTuning(C.Structure):
         ("tn_tile", C.c_int32),
         ("xcd_order", C.c_int32),
         ("backward", C.c_int32),
-        ("k1_stream_linger", C.c_int32),
+        ("reserved1", C.c_int32),
         ("reserved0", C.c_int32),
         ("event_scope", C.c_int32),
         ("reserved", C.c_int32 * 3),

@@ -217,8 +217,9 @@ __global__ __launch_bounds__(kThreads) void pool_norm_kernel(
 //     the queue is empty (it leaves without registering), one atomic otherwise.
 // Placement decides speed only: every text is pooled by exactly one workgroup, with the arithmetic of
 // pool_norm_kernel (same order => bitwise the same output).  No wave ever waits for another workgroup: a
-// turned-away candidate may linger for a BOUNDED number of sleep instructions (tt_tuning.k1_stream_linger, default
-// none) and admitted workgroups leave when the queue runs dry.
+// turned-away candidate leaves at once (letting it linger for a bounded 8-32 us, so that fewer candidates are spent per
+// microsecond, was measured and changes nothing: profiles/r04_c4_admission_ab.txt) and admitted workgroups leave
+// when the queue runs dry.
 constexpr int kCuSlots = 4096;  // 4 bits of XCC id x 8 bits of SE / SH / CU id
 struct StreamCtl {
   int head;            // next text to hand out
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void pool_norm_stream_kernel(
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, long long N, int S, int D, long long V,
     int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store, StreamCtl* __restrict__ ctl,
-    int per_cu, int target, int linger) {
+    int per_cu, int target) {
   __shared__ float4 part[kWavesPerText][C * TT_WAVE];
   __shared__ float red[kWavesPerText];
   __shared__ int s_next;
@@ -251,14 +252,8 @@ __global__ __launch_bounds__(kThreads) void pool_norm_stream_kernel(
     const bool open = __hip_atomic_load(&ctl->admitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
                       __hip_atomic_load(&ctl->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < N;
     if (open) {
-      if (atomicAdd(&ctl->cu[tt_cu_key()], 1) < per_cu) {
-        if (atomicAdd(&ctl->admitted, 1) < target) next = atomicAdd(&ctl->head, 1);
-      } else {
-        // this CU has its share.  Leaving at once hands the room straight to the next candidate, which the
-        // dispatcher is likely to place here again; lingering (bounded) spends fewer candidates per microsecond
-        // while some other CU is still short of its share.
-        for (int i = 0; i < linger; ++i) __builtin_amdgcn_s_sleep(32);  // 32 x 64 clocks ~ 1 us
-      }
+      if (atomicAdd(&ctl->cu[tt_cu_key()], 1) < per_cu && atomicAdd(&ctl->admitted, 1) < target)
+        next = atomicAdd(&ctl->head, 1);  // (else: this CU has its share — leave)
     }
     s_next = next;
   }
@@ -833,7 +828,7 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
 
 template <typename IdT, typename MaskT>
 int launch_stream(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
-                  int S, int D, int64_t V, int32_t* oob, void* ctl_ws, int per_cu, int rows, int offer, int linger,
+                  int S, int D, int64_t V, int32_t* oob, void* ctl_ws, int per_cu, int rows, int offer,
                   unsigned lds_total, hipStream_t st, const int32_t* text_rows, int64_t n_store) {
   const IdT* ids_t = static_cast<const IdT*>(ids);
   const MaskT* mask_t = static_cast<const MaskT*>(mask);
@@ -845,15 +840,13 @@ int launch_stream(const float* table, const void* ids, const void* mask, const i
   if (offer <= 0) offer = 16;
   if (offer > 256) offer = 256;
   const long long wgs = target * offer;
-  if (linger < 0) linger = 0;
-  if (linger > 64) linger = 64;
   const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
   // rows in flight per wave: ~96 KB per workgroup (4 waves x U rows x C KiB) unless the caller says otherwise
 #define TT_STREAM_CASE(CC, UU)                                                                               \
   hipLaunchKernelGGL((pool_norm_stream_kernel<IdT, MaskT, CC, UU>), dim3((unsigned)wgs), dim3(kThreads),     \
                      k1_dynamic_lds(lds_total, CC * 4096u + 32u), st, table, ids_t, mask_t, lens, out,       \
                      (long long)N, S, D, (long long)V, oob, text_rows, (long long)n_store, ctl, per_cu,      \
-                     (int)target, linger)
+                     (int)target)
   switch (C) {
     case 1: TT_STREAM_CASE(1, 16); break;
     case 2: TT_STREAM_CASE(2, 12); break;
@@ -1025,8 +1018,7 @@ int tt_k1_stream_launch(const float* table, const void* ids, int ids_dtype, cons
   if (N == 0) return TT_OK;
   const int md = mask ? mask_dtype : TT_I32;
   const int rows = tuning ? tuning->k1_stream_rows : 0, offer = tuning ? tuning->k1_stream_offer : 0;
-  const int linger = tuning ? tuning->k1_stream_linger : 0;
-#define TT_STREAM_ARGS table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, rows, offer, linger, lds_total, st, text_rows, n_store
+#define TT_STREAM_ARGS table, ids, mask, lens, out, N, S, D, V, oob_flag, workspace, per_cu, rows, offer, lds_total, st, text_rows, n_store
   if (ids_dtype == TT_I32 && md == TT_I32) return launch_stream<int32_t, int32_t>(TT_STREAM_ARGS);
   if (ids_dtype == TT_I32 && md == TT_I64) return launch_stream<int32_t, int64_t>(TT_STREAM_ARGS);
   if (ids_dtype == TT_I64 && md == TT_I32) return launch_stream<int64_t, int32_t>(TT_STREAM_ARGS);

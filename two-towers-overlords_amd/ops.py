@@ -116,7 +116,7 @@ def gather_pool_norm(
     shape (tt_k1_prefers_sliced).  form: "rows" / "columns" picks the slicing of the sliced form (default: the
     measured rule, tt_k1_sliced_form; either implies sliced=True), "per_text" = sliced=False.  Same result to fp32
     summation order.  stream_form=n: the streaming form (tt_gather_pool_norm_stream_f32: persistent workgroups, at
-    most n per compute unit; bitwise the per-text result; `tuning`: k1_stream_rows / _offer / _linger) — what the
+    most n per compute unit; bitwise the per-text result; `tuning`: k1_stream_rows / _offer) — what the
     engine uses for tables that stream from HBM."""
     if form is not None:
         if form not in ("per_text", "rows", "columns"):

@@ -88,16 +88,21 @@ def test_module_forward_backward_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["kat0.npz", "step_mid.npz"])
-@pytest.mark.parametrize("opt", ["fused", "torch"])
+@pytest.mark.parametrize("opt", ["fused-engine", "fused-modules", "torch"])
 def test_train_epoch_module_path_matches_reference(name, opt):
+    """`train_epoch` with the reference's signature on the reference's kind of batches (string lists through the towers'
+    tokenizer): with FusedAdam the batch body runs on the fused engine (`fused=None` routes it), with `fused=False` or a
+    torch optimizer module by module — each against the epoch the reference's own train_epoch produced."""
     from two_towers_overlords_amd.model import TripletLoss
     from two_towers_overlords_amd.training import FusedAdam, train_epoch
 
     g = load_golden(name)
     m, texts = build_model(g)
     lr = float(g["lr"])
-    optim = FusedAdam(m.parameters(), lr=lr) if opt == "fused" else torch.optim.Adam(m.parameters(), lr=lr)
-    avg = train_epoch(m, texts, TripletLoss(margin=float(g["margin"])), optim, log_wandb=False)
+    optim = torch.optim.Adam(m.parameters(), lr=lr) if opt == "torch" else FusedAdam(m.parameters(), lr=lr)
+    avg = train_epoch(m, texts, TripletLoss(margin=float(g["margin"])), optim, log_wandb=False,
+                      fused=(False if opt == "fused-modules" else None))
+    assert (getattr(optim, "_tt_route", None) is not None) == (opt == "fused-engine")
     assert abs(avg - float(g["epoch/avg_loss"])) <= TOL
     sd = m.state_dict()
     for k in orc.PARAM_KEYS:
@@ -139,12 +144,55 @@ def test_train_epoch_on_pretokenised_batches_one_gather_one_adam_launch(monkeypa
         monkeypatch.setattr(ops, "gather_pool_norm", count_gather)
         monkeypatch.setattr(ops, "adam_step_multi", count_adam)
         opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=lr)
-        avg = train_epoch(m, batches, TripletLoss(margin=float(g["margin"])), opt, log_wandb=False)
+        avg = train_epoch(m, batches, TripletLoss(margin=float(g["margin"])), opt, log_wandb=False, fused=False)
         assert calls == {"gather": gathers_per_batch * nb, "adam": nb, "tensors": 8 * nb}
         assert abs(avg - float(g["epoch/avg_loss"])) <= TOL
         sd = m.state_dict()
         for k in orc.PARAM_KEYS:
             assert_params_close(sd[k].cpu().numpy(), g["final/" + k], lr, nb)
+
+
+def test_train_epoch_on_the_engine_hands_its_state_to_the_optimizer_and_back():
+    """`train_epoch` routed to the fused engine (FusedAdam + TripletLoss + embed towers on one table): epoch 1 on the
+    engine, epoch 2 module by module with the SAME optimizer object, epoch 3 on the engine again must be the three epochs
+    of the module loop — parameters and Adam moments travel through `optimizer.state` (views of the engine's flat
+    buffers) in both directions; `state_dict()` of model and optimizer show the trained values; pre-tokenised batches whose
+    roles differ in width; a torch optimizer or a second param group is not routed."""
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import FusedAdam, train_epoch
+
+    g = load_golden("step_mid.npz")
+    nb, lr = int(g["n_batches"]), float(g["lr"])
+    pad = lambda t: torch.nn.functional.pad(t, (0, 3))
+    batches = [((T(g[f"batch{i}/ids_q"]).cuda(), T(g[f"batch{i}/mask_q"]).cuda()),
+                (pad(T(g[f"batch{i}/ids_p"])).cuda(), pad(T(g[f"batch{i}/mask_p"])).cuda()),
+                (T(g[f"batch{i}/ids_n"]).cuda(), T(g[f"batch{i}/mask_n"]).cuda())) for i in range(nb)]
+    crit = TripletLoss(margin=float(g["margin"]))
+    runs = {}
+    for plan in ((False, False, False), (None, False, None)):
+        m, _ = build_model(g)
+        opt = FusedAdam(m.parameters(), lr=lr)
+        avgs = [train_epoch(m, batches, crit, opt, log_wandb=False, fused=f) for f in plan]
+        sd = {k: v.clone() for k, v in m.state_dict().items() if ".projection." in k}
+        moments = [opt.state[p]["exp_avg"].clone() for p in m.trainable_parameters()]
+        steps = {int(opt.state[p]["step"]) for p in m.trainable_parameters()}
+        runs[plan] = (avgs, sd, moments, steps)
+    (a0, s0, m0, st0), (a1, s1, m1, st1) = runs.values()
+    assert st0 == st1 == {3 * nb}
+    assert abs(a0[0] - float(g["epoch/avg_loss"])) <= TOL and abs(a1[0] - float(g["epoch/avg_loss"])) <= TOL
+    for x, y in zip(a0, a1):
+        assert abs(x - y) <= TOL
+    for k in s0:
+        assert_params_close(s1[k].cpu().numpy(), s0[k].cpu().numpy(), lr, 3 * nb, tight=2e-6)
+    for x, y in zip(m0, m1):
+        assert (x - y).abs().max().item() <= 1e-6 * max(1.0, x.abs().max().item())
+    m, _ = build_model(g)
+    train_epoch(m, batches, crit, torch.optim.Adam(m.parameters(), lr=lr), log_wandb=False)  # torch optimizer: the module loop
+    two = FusedAdam([{"params": m.query_tower.projection.parameters()}, {"params": m.document_tower.projection.parameters()}], lr=lr)
+    train_epoch(m, batches, crit, two, log_wandb=False)
+    assert getattr(two, "_tt_route", None) is None
+    with pytest.raises(ValueError):
+        train_epoch(m, batches, crit, two, log_wandb=False, fused=True)
 
 
 @pytest.mark.parametrize("overlap,fence", [(False, None), (True, None), (True, True), (True, False)],

@@ -15,6 +15,7 @@ $B --inputs index > $out/${r}_bench_c2_inputs_index.json
 $B --inputs cache > $out/${r}_bench_c2_inputs_cache.json
 $B --e2e --steps 1000 > $out/${r}_bench_c2_e2e_epoch1000.json
 $B --path module --steps 200 > $out/${r}_bench_c2_module_path.json
+$B --path module-unfused --steps 200 > $out/${r}_bench_c2_module_unfused.json
 $B --loss inbatch > $out/${r}_bench_c2_inbatch_b2048.json
 $B --loss inbatch --batch 4096 > $out/${r}_bench_inbatch_b4096.json
 $B --loss inbatch --batch 512 > $out/${r}_bench_inbatch_b512_share.json

@@ -128,8 +128,22 @@ def _ids_mask(pair):
 
 
 def train_epoch(model: TwoTowersModel, dataloader, criterion: TripletLoss, optimizer: torch.optim.Optimizer,
-                log_wandb: bool = True) -> float:
-    """Train for one epoch.  Mirrors backend/training.py:26-63 line for line."""
+                log_wandb: bool = True, *, fused: Optional[bool] = None) -> float:
+    """Train for one epoch.  Same signature, call sequence and return value as backend/training.py:26-63.
+
+    `fused` (additive): None = run the batch body on the fused engine when the arguments allow it — `FusedAdam` over
+    this model's trainable tensors, a plain `TripletLoss`, both towers in `embed` mode on one frozen table on the GPU,
+    no per-batch wandb logging — with the same results (the engine is held to the same reference fixtures as this loop)
+    at the engine's speed: no autograd graph, one gather for the three roles running two batches ahead on its own
+    stream, Adam state and parameters staying visible through `optimizer.state` / `model.state_dict()`.  False = the
+    module-by-module loop below; True = raise if the engine cannot take this call."""
+    if fused is not False:
+        route = _engine_route(model, criterion, optimizer, log_wandb)
+        if route is not None:
+            return route.run_epoch(dataloader)
+        if fused:
+            raise ValueError("train_epoch(fused=True): needs FusedAdam over the model's trainable tensors, TripletLoss, "
+                             "`embed` towers sharing one table on a GPU, and no per-batch wandb logging")
     total_loss = 0.0
     num_batches = 0
     pending = []  # device-side losses not yet read: `loss.item()` (training.py:53) stalls the host on every batch, so the
@@ -153,6 +167,134 @@ def train_epoch(model: TwoTowersModel, dataloader, criterion: TripletLoss, optim
         for v in torch.stack(pending).tolist():
             total_loss += v
     return total_loss / num_batches
+
+
+def _engine_route(model, criterion, optimizer, log_wandb):
+    """The _EngineRoute for (model, optimizer) if train_epoch's batch body can run on the fused engine, else None."""
+    if not isinstance(optimizer, FusedAdam) or type(criterion) is not TripletLoss or not isinstance(model, TwoTowersModel):
+        return None
+    if log_wandb and _HAVE_WANDB:  # per-batch wandb.log needs every batch's loss on the host: the module loop
+        return None
+    qt, dt = model.query_tower, model.document_tower
+    if getattr(qt, "encoder_mode", None) != "embed" or getattr(dt, "encoder_mode", None) != "embed":
+        return None
+    table = qt.embedding_table()
+    if not table.is_cuda or table.data_ptr() != dt.embedding_table().data_ptr() or table.dtype != torch.float32:
+        return None
+    if len(optimizer.param_groups) != 1:
+        return None
+    want = model.trainable_parameters()
+    have = [p for p in optimizer.param_groups[0]["params"] if p.requires_grad]
+    if len(have) != len(want) or any(a is not b for a, b in zip(have, want)):
+        return None
+    route = getattr(optimizer, "_tt_route", None)
+    if route is None or route.model is not model:
+        route = _EngineRoute(model, optimizer)
+        optimizer._tt_route = route
+    route.margin = float(criterion.margin)
+    return route
+
+
+class _EngineRoute:
+    """train_epoch's batch body (backend/training.py:36-53) on the fused engine, behind the reference's signature.
+    Parameters and Adam moments live in the engine's flat buffers; the nn.Parameters and `optimizer.state[p]` are views
+    of them, so `model.state_dict()`, `optimizer.state_dict()` and a later module-path `optimizer.step()` see the same
+    values."""
+
+    MAX_S = 512  # the tokenizer's max_length (backend/model.py:44)
+
+    def __init__(self, model, optimizer):
+        self.model, self.optimizer = model, optimizer
+        self.trainer = None
+        self.margin = 0.3
+
+    def _build(self, B: int) -> None:
+        group = self.optimizer.param_groups[0]
+        old = self.trainer
+        tr = TripletTrainer(self.model, max_batch=B, max_seq_len=self.MAX_S, margin=self.margin, lr=group["lr"],
+                            betas=tuple(group["betas"]), eps=group["eps"])
+        params = self.model.trainable_parameters()
+        steps = set()
+        for p, (_, off, shape) in zip(params, flat_param_slices(tr.D, tr.P)):
+            n = p.numel()
+            st = self.optimizer.state.get(p) or {}
+            if st:  # moments of steps taken so far (module path, or a smaller engine)
+                tr.exp_avg[off: off + n].copy_(st["exp_avg"].reshape(-1))
+                tr.exp_avg_sq[off: off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            self.optimizer.state[p] = {"step": 0, "exp_avg": tr.exp_avg[off: off + n].view(shape),
+                                       "exp_avg_sq": tr.exp_avg_sq[off: off + n].view(shape)}
+        if len(steps) > 1:
+            raise ValueError("train_epoch(fused): the optimizer's tensors have taken different numbers of steps")
+        tr.step_count = steps.pop() if steps else 0
+        self._sync_steps(tr)
+        if old is not None:
+            old.engine.close()
+        self.trainer = tr
+
+    def _sync_steps(self, tr) -> None:
+        for p in self.model.trainable_parameters():
+            self.optimizer.state[p]["step"] = tr.step_count
+
+    @staticmethod
+    def _stack(queries, positives, negatives) -> "TripletBatch":
+        """(ids, mask) x 3 -> ids [3, B, S], mask [3, B, S] padded to the longest role (masked-out zeros are never read)."""
+        blocks = [_ids_mask(x) for x in (queries, positives, negatives)]
+        S = max(i.shape[1] for i, _ in blocks)
+        pad = lambda t: t if t.shape[1] == S else torch.nn.functional.pad(t, (0, S - t.shape[1]))
+        ids = torch.stack([pad(i) for i, _ in blocks])
+        if all(m is None for _, m in blocks) and all(i.shape[1] == S for i, _ in blocks):
+            return TripletBatch(ids=ids.contiguous())
+        mask = torch.stack([pad(torch.ones_like(i) if m is None else m.to(i.dtype)) for i, m in blocks])
+        return TripletBatch(ids=ids.contiguous(), mask=mask.contiguous())
+
+    def _batches(self, dataloader):
+        dt, qt = self.model.document_tower, self.model.query_tower
+        for queries, positives, negatives in dataloader:
+            if isinstance(queries, (list, tuple)) and len(queries) and isinstance(queries[0], str):
+                tq, tp, tn = qt.tokenize(queries), dt.tokenize(positives), dt.tokenize(negatives)  # model.py:43-48, three calls
+                queries, positives, negatives = ((t["input_ids"], t.get("attention_mask")) for t in (tq, tp, tn))
+            yield self._stack(queries, positives, negatives)
+
+    def run_epoch(self, dataloader) -> float:
+        it = self._batches(dataloader)
+        first = next(it, None)
+        if first is None:
+            raise ZeroDivisionError("train_epoch: empty dataloader")  # what the reference's `total_loss / num_batches` raises
+        if first.ids.shape[2] > self.MAX_S:
+            raise ValueError(f"train_epoch(fused): rows of {first.ids.shape[2]} tokens exceed {self.MAX_S}")
+        if self.trainer is None or first.size > self.trainer.engine.max_B:
+            self._build(first.size)
+        tr = self.trainer
+        group = self.optimizer.param_groups[0]
+        tr.lr, tr.betas, tr.eps, tr.margin = float(group["lr"]), tuple(group["betas"]), float(group["eps"]), self.margin
+        tr.engine.read_stats(reset=True)
+        depth = tr.SLOTS - 1 if tr.side is not None else 1
+        tr.gather(first)
+        while len(tr._pending) < depth:
+            b = next(it, None)
+            if b is None:
+                break
+            self._check(b)
+            tr.gather(b)
+        num_batches = 0
+        while tr._pending:
+            b = next(it, None)
+            if b is not None:
+                self._check(b)
+            tr.advance(b)
+            num_batches += 1
+            if num_batches % 10 == 0:  # the reference prints here (training.py:59-61): the one host read per ten batches
+                _, _, last = tr.engine.read_stats(reset=False)
+                print(f"Batch {num_batches}, Loss: {last:.4f}")
+        loss_sum, n, _ = tr.engine.read_stats(reset=True)
+        self._sync_steps(tr)
+        return loss_sum / n
+
+    def _check(self, b) -> None:
+        if b.size > self.trainer.engine.max_B or b.ids.shape[2] > self.MAX_S:
+            raise ValueError(f"train_epoch(fused): a batch of {b.size} x {b.ids.shape[2]} tokens after a first batch of "
+                             f"{self.trainer.engine.max_B}: put the largest batch first, or call train_epoch(fused=False)")
 
 
 def train_epoch_optimized(model: TwoTowersModel, dataloader, criterion: TripletLoss,

@@ -268,6 +268,10 @@ class _EngineRoute:
         tr = self.trainer
         group = self.optimizer.param_groups[0]
         tr.lr, tr.betas, tr.eps, tr.margin = float(group["lr"]), tuple(group["betas"]), float(group["eps"]), self.margin
+        steps = {int(self.optimizer.state[p]["step"]) for p in self.model.trainable_parameters()}
+        if len(steps) != 1:
+            raise ValueError("train_epoch(fused): the optimizer's tensors have taken different numbers of steps")
+        tr.step_count = steps.pop()  # module-path steps taken with this optimizer in between count too
         tr.engine.read_stats(reset=True)
         depth = tr.SLOTS - 1 if tr.side is not None else 1
         tr.gather(first)

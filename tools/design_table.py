@@ -35,7 +35,9 @@ rows = [
     ("`--zipf` ids (SURVEY §8d's text-like id distribution)", "r04_bench_c2_zipf.json"),
     ("`--inputs index` (negatives by in-batch index, 2 gathers)", "r04_bench_c2_inputs_index.json"),
     ("`--inputs cache` (cache-fed step: no gather)", "r04_bench_c2_inputs_cache.json"),
-    ("**`--path module`** (the drop-in `train_epoch` over the mirrored modules + `FusedAdam`)", "r04_bench_c2_module_path.json"),
+    ("**`--path module`**: the drop-in `train_epoch(model, batches, TripletLoss, FusedAdam)` — batch body routed to the engine; fill, drain, engine-side id stacking and the loss reads inside the timed epoch", "r04_bench_c2_module_path.json"),
+    ("`--path module-unfused`: the same call with `fused=False` (autograd Functions, module by module)", "r04_bench_c2_module_unfused.json"),
+    ("`--path module` at the driver's 20 steps / 5 warm-up (a 20-batch epoch)", "r04_bench_c2_module_path_k20.json"),
     ("configs[2], one GPU's share (B = 1024 of 8192, P = 512)", "r04_bench_c3_share.json"),
     ("**configs[3]** (V = 250k, D = P = 768, S = 256, B = 16384; streaming K1)", "r04_bench_c4_full.json"),
     ("configs[3] one stream `--no-overlap`", "r04_bench_c4_no_overlap.json"),

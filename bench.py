@@ -397,8 +397,11 @@ def run_module_path(args, device) -> dict:
                    "proj_dim": P, "seq_len": S, "batch_per_gpu": B, "global_batch": B,
                    "ids": "int64 input_ids + int64 attention_mask [B,S] per encode call, " + ("zipf" if args.zipf else "uniform")
                           + ", full length", "parallelism": "dp1",
-                   "launches_per_step": "K1 x2 (queries; positives+negatives in one document-tower call), projection fwd x2, "
-                                        "triplet fwd+bwd, projection bwd x2 (+ slab reductions), 1 multi-tensor Adam"},
+                   "launches_per_step": ("the fused engine's (one gather for the three roles two batches ahead on a side stream; "
+                                         "2 forward GEMM launches, loss, 2-3 backward launches, Adam) + stacking the three roles' "
+                                         "ids and masks" if fused is None else
+                                         "one gather for the three roles, projection fwd x2 per tower, triplet fwd+bwd, projection "
+                                         "bwd x3 + one slab reduction per tower, 1 multi-tensor Adam, ~5 torch ops")},
         "roofline": None, "avg_loss": avg,
     }
 

@@ -265,6 +265,8 @@ class _EngineRoute:
             raise ValueError(f"train_epoch(fused): rows of {first.ids.shape[2]} tokens exceed {self.MAX_S}")
         if self.trainer is None or first.size > self.trainer.engine.max_B:
             self._build(first.size)
+            if first.size * first.ids.shape[2] >= 65536:  # a batch worth timing: pick the backward schedule / fence placement
+                self.trainer.calibrate(first)             # for this device and shape (state-neutral, ~0.1 s once)
         tr = self.trainer
         group = self.optimizer.param_groups[0]
         tr.lr, tr.betas, tr.eps, tr.margin = float(group["lr"]), tuple(group["betas"]), float(group["eps"]), self.margin

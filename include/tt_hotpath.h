@@ -82,12 +82,10 @@ typedef struct {
   int32_t tn_tile;         /* weight-gradient (split-K) tile: 11 or 22 */
   int32_t xcd_order;       /* XCD-aware workgroup order of the projection GEMMs: 1 on, -1 off */
   int32_t backward;        /* engine: TT_BWD_* schedule of phase B's backward */
-  int32_t reserved1;       /* must be 0 (a bounded linger of turned-away streaming-gather candidates lived here; measured, no effect, removed) */
-  int32_t reserved0;       /* must be 0 (round 4's transposed kTN staging lived here; measured, no gain, removed) */
   int32_t event_scope;     /* engine: release scope of the events that order its two streams: 1 no system-scope fence
                               (hipEventDisableSystemFence; auto), 2 device-scope release (hipEventReleaseToDevice),
                               3 HIP's default (system-scope fence when the event is recorded) */
-  int32_t reserved[3];     /* must be 0 */
+  int32_t reserved[5];     /* must be 0 */
 } tt_tuning;
 
 int tt_abi_version(void);

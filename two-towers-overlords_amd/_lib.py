@@ -70,14 +70,12 @@ class TTTuning(C.Structure):
         ("tn_tile", C.c_int32),
         ("xcd_order", C.c_int32),
         ("backward", C.c_int32),
-        ("reserved1", C.c_int32),
-        ("reserved0", C.c_int32),
         ("event_scope", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
-TUNING_FIELDS = tuple(n for n, _ in TTTuning._fields_ if not n.startswith("reserved"))
+TUNING_FIELDS = tuple(n for n, _ in TTTuning._fields_ if n != "reserved")
 
 
 def make_tuning(tuning=None):

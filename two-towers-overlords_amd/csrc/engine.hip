@@ -244,7 +244,6 @@ extern "C" int tt_engine_set_tuning(tt_engine* e, const tt_tuning* tuning) {
   TT_REQUIRE(t.k1_form >= TT_K1_AUTO && t.k1_form <= TT_K1_STREAM, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(t.k1_stream_wgs >= 0 && t.k1_stream_wgs <= 8 && t.k1_share_lds_kb >= -1 && t.k1_share_lds_kb <= 160, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(t.backward == TT_BWD_AUTO || t.backward == TT_BWD_FORK || t.backward == TT_BWD_FUSED, TT_ERR_BAD_SHAPE);
-  TT_REQUIRE(t.reserved0 == 0 && t.reserved1 == 0, TT_ERR_BAD_SHAPE);
   for (int r : t.reserved) TT_REQUIRE(r == 0, TT_ERR_BAD_SHAPE);
   e->tuning = t;
   if (t.backward != TT_BWD_AUTO) e->bwd_mode = t.backward;

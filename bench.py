@@ -577,14 +577,16 @@ def run_config(args, world, rank, device) -> dict:
             a @ a
             torch.cuda.synchronize(device)
         del a
-    if not args.no_calibrate and not args.k1_only and args.loss == "triplet":
-        trainer.calibrate(batches[0], steps=getattr(args, "calibrate_steps", 48),
-                          rounds=getattr(args, "calibrate_rounds", 2))   # set-up: part of what run_training does before its first epoch
+    # (every piece of host-side set-up goes BEFORE calibrate(): its dry steps bring the GPU to its sustained power state, and
+    #  a millisecond of idleness afterwards already costs the next ~30 steps a few percent — DESIGN.md section 5, "Cold start")
     trainer.k1_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                              for _ in range(args.steps // max(trainer.k1_event_every, 1) + 8)]
     for e0, e1 in trainer.k1_event_pool:  # torch creates the HIP event at its first record(): do that now
         e0.record()
         e1.record()
+    if not args.no_calibrate and not args.k1_only and args.loss == "triplet":
+        trainer.calibrate(batches[0], steps=getattr(args, "calibrate_steps", 48),
+                          rounds=getattr(args, "calibrate_rounds", 2))   # set-up: part of what run_training does before its first epoch
     set_up_steps = 0  # steps of this workload executed before the timed region besides --warmup
     if trainer.calibration:
         combos = len(trainer.calibration.get("ms_per_step_by_fence") or (0, 0))  # backward schedules x fence placements timed

@@ -238,11 +238,14 @@ def test_trainer_accumulation_matches_oracle():
     assert (tr.bucket.cpu() - flat_carry).abs().max() <= TOL * max(1.0, float(flat_carry.abs().max()))
 
 
-@pytest.mark.parametrize("opt", ["fused", "torch"])
-def test_train_epoch_optimized_module_path_matches_reference(opt):
-    """a12 on the module path: `train_epoch_optimized` (same signature as backend/training.py:66-75) against
+@pytest.mark.parametrize("opt,plan", [("fused", (False, False)), ("torch", (False, False)), ("fused", (None, None)),
+                                      ("fused", (None, False)), ("fused", (False, None))],
+                         ids=["module,FusedAdam", "module,torch.Adam", "engine", "engine-then-module", "module-then-engine"])
+def test_train_epoch_optimized_matches_reference(opt, plan):
+    """a12 behind the reference's signature: `train_epoch_optimized` (backend/training.py:66-75) against
     tests/golden/step_accum.npz, made by the reference's own function in fp32 — two epochs of five batches, k = 2:
-    four optimizer steps, epoch 1's fifth gradient applied with epoch 2's first two."""
+    four optimizer steps, epoch 1's fifth gradient applied with epoch 2's first two.  Module by module, routed to the
+    fused engine (FusedAdam), and one epoch each way: the un-applied gradient travels through `p.grad` in both directions."""
     from two_towers_overlords_amd.model import TripletLoss
     from two_towers_overlords_amd.training import FusedAdam, train_epoch_optimized
 
@@ -252,15 +255,45 @@ def test_train_epoch_optimized_module_path_matches_reference(opt):
     optim = FusedAdam(m.parameters(), lr=lr) if opt == "fused" else torch.optim.Adam(m.parameters(), lr=lr)
     crit = TripletLoss(margin=float(g["margin"]))
     for e in range(int(g["n_epochs"])):
-        avg = train_epoch_optimized(m, texts, crit, optim, torch.device("cuda"), None, accumulation_steps=k, log_wandb=False)
+        avg = train_epoch_optimized(m, texts, crit, optim, torch.device("cuda"), None, accumulation_steps=k, log_wandb=False,
+                                    fused=plan[e])
+        assert (getattr(optim, "_tt_route", None) is not None) == (None in plan[: e + 1])
         assert abs(avg - float(g["epoch/avg_loss"][e])) <= TOL
         sd = m.state_dict()
         for key in orc.PARAM_KEYS:
             assert_params_close(sd[key].cpu().numpy(), g[f"epoch{e}/" + key], lr, 2 * (e + 1))
+        assert {int(optim.state[p_]["step"]) for p_ in m.trainable_parameters()} == {2 * (e + 1)}
     for key, prm in m.named_parameters():  # the un-applied fifth gradient is still in .grad (training.py:99-102)
         if prm.requires_grad:
             ref = g["carry/" + key]
             assert np.abs(prm.grad.cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+def test_train_epoch_leaves_the_last_gradient_for_a_following_accumulation_epoch():
+    """The reference's loops share `.grad`: train_epoch (training.py:36-53) ends with its last batch's gradient in it,
+    and a train_epoch_optimized that follows adds its first window to that (training.py:66-133 never clears on entry);
+    an even window count leaves `.grad` None.  The engine route must do what the module loops do."""
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import FusedAdam, train_epoch, train_epoch_optimized
+
+    g = load_golden("step_accum.npz")
+    lr = float(g["lr"])
+    crit = TripletLoss(margin=float(g["margin"]))
+    out = {}
+    for fused in (False, None):
+        m, texts = build_model(g)
+        optim = FusedAdam(m.parameters(), lr=lr)
+        a = train_epoch(m, texts[:3], crit, optim, log_wandb=False, fused=fused)
+        last = [p_.grad.clone() for p_ in m.trainable_parameters()]
+        b = train_epoch_optimized(m, texts[:4], crit, optim, None, None, accumulation_steps=2, log_wandb=False, fused=fused)
+        assert all(p_.grad is None for p_ in m.trainable_parameters())  # two full windows: step + zero_grad at the end
+        out[fused] = (a, b, last, [p_.detach().clone() for p_ in m.trainable_parameters()])
+    (a0, b0, g0, p0), (a1, b1, g1, p1) = out[False], out[None]
+    assert abs(a0 - a1) <= TOL and abs(b0 - b1) <= TOL
+    for x, y in zip(g0, g1):
+        assert (x - y).abs().max().item() <= TOL * max(1.0, x.abs().max().item())
+    for x, y in zip(p0, p1):
+        assert_params_close(y.cpu().numpy(), x.cpu().numpy(), lr, 5, tight=2e-6)
 
 
 @pytest.mark.parametrize("overlap", [False, True, "loss-event-fence"])

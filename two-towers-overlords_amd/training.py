@@ -207,6 +207,7 @@ class _EngineRoute:
         self.model, self.optimizer = model, optimizer
         self.trainer = None
         self.margin = 0.3
+        self._bucket = None  # un-applied gradients between epochs: what the reference keeps in `.grad`
 
     def _build(self, B: int) -> None:
         group = self.optimizer.param_groups[0]
@@ -232,6 +233,31 @@ class _EngineRoute:
             old.engine.close()
         self.trainer = tr
 
+    def _grad_views(self):
+        tr = self.trainer
+        if self._bucket is None or self._bucket.numel() != tr.flat.numel():
+            self._bucket = torch.zeros_like(tr.flat)
+        return [self._bucket[off: off + p.numel()].view(shape)
+                for p, (_, off, shape) in zip(self.model.trainable_parameters(), flat_param_slices(tr.D, tr.P))]
+
+    def _take_left_over_grads(self) -> bool:
+        """`.grad` tensors left by an earlier epoch (training.py:66-133 never clears what its last, unfinished window
+        accumulated; training.py:36-53 leaves the last batch's) -> the trainer's bucket.  True if there were any."""
+        params = self.model.trainable_parameters()
+        if all(p.grad is None for p in params):
+            return False
+        for p, view in zip(params, self._grad_views()):
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+        return True
+
+    def _leave_grads(self, have: bool) -> None:
+        views = self._grad_views() if have else None
+        for i, p in enumerate(self.model.trainable_parameters()):
+            p.grad = views[i] if have else None
+
     def _sync_steps(self, tr) -> None:
         for p in self.model.trainable_parameters():
             self.optimizer.state[p]["step"] = tr.step_count
@@ -256,7 +282,11 @@ class _EngineRoute:
                 queries, positives, negatives = ((t["input_ids"], t.get("attention_mask")) for t in (tq, tp, tn))
             yield self._stack(queries, positives, negatives)
 
-    def run_epoch(self, dataloader) -> float:
+    def run_epoch(self, dataloader, accumulation_steps: Optional[int] = None) -> float:
+        """One epoch.  accumulation_steps None: train_epoch (training.py:36-53: zero_grad, backward, step per batch, a
+        print every tenth batch).  An integer k: train_epoch_optimized (training.py:66-133: loss / k, step + zero_grad
+        after every k-th batch of THIS epoch, whatever `.grad` held on entry is added to, whatever the last unfinished
+        window accumulated stays in `.grad`)."""
         it = self._batches(dataloader)
         first = next(it, None)
         if first is None:
@@ -274,6 +304,15 @@ class _EngineRoute:
         if len(steps) != 1:
             raise ValueError("train_epoch(fused): the optimizer's tensors have taken different numbers of steps")
         tr.step_count = steps.pop()  # module-path steps taken with this optimizer in between count too
+        accumulate = accumulation_steps is not None
+        tr.accumulation_steps = int(accumulation_steps) if accumulate else 1
+        tr._micro = 0  # batch_idx restarts with the epoch (training.py:80)
+        tr._carry = self._take_left_over_grads() if accumulate else False  # train_epoch clears .grad before its first batch
+        if tr._carry or tr.accumulation_steps > 1:
+            self._grad_views()
+            tr.bucket = self._bucket
+        else:
+            tr.bucket = None  # Adam reads the gradient slabs directly
         tr.engine.read_stats(reset=True)
         depth = tr.SLOTS - 1 if tr.side is not None else 1
         tr.gather(first)
@@ -290,11 +329,18 @@ class _EngineRoute:
                 self._check(b)
             tr.advance(b)
             num_batches += 1
-            if num_batches % 10 == 0:  # the reference prints here (training.py:59-61): the one host read per ten batches
-                _, _, last = tr.engine.read_stats(reset=False)
+            if not accumulate and num_batches % 10 == 0:  # the reference prints here (training.py:59-61): the one host
+                _, _, last = tr.engine.read_stats(reset=False)  # read per ten batches
                 print(f"Batch {num_batches}, Loss: {last:.4f}")
         loss_sum, n, _ = tr.engine.read_stats(reset=True)
         self._sync_steps(tr)
+        if accumulate:
+            self._leave_grads(tr._carry)
+        else:  # `.grad` of the last batch, as the reference's loop leaves it (a later accumulation epoch adds to it)
+            self._grad_views()
+            tr.engine.reduce_grads(self._bucket, accumulate=False)
+            self._leave_grads(True)
+        tr.bucket, tr.accumulation_steps, tr._carry = None, 1, False
         return loss_sum / n
 
     def _check(self, b) -> None:
@@ -305,13 +351,20 @@ class _EngineRoute:
 
 def train_epoch_optimized(model: TwoTowersModel, dataloader, criterion: TripletLoss,
                           optimizer: torch.optim.Optimizer, device=None, scaler=None,
-                          accumulation_steps: int = 2, log_wandb: bool = True) -> float:
+                          accumulation_steps: int = 2, log_wandb: bool = True, *, fused: Optional[bool] = None) -> float:
     """Gradient-accumulation loop with the semantics of backend/training.py:66-133
     (`loss / accumulation_steps`, optimizer step + zero_grad every k-th batch,
     left-over gradients neither applied nor cleared at the end of the epoch), in
     fp32: the reference's fp16 autocast + GradScaler are not a parity target
-    (SURVEY.md §2.2 O11), so `scaler` is accepted and ignored."""
+    (SURVEY.md §2.2 O11), so `scaler` is accepted and ignored.
+    `fused` as in train_epoch: None runs the batches on the fused engine when (model, criterion, optimizer) allow it —
+    the un-applied gradients of an unfinished window are then views of the engine's bucket in `p.grad`."""
     model.train()
+    route = _engine_route(model, criterion, optimizer, log_wandb) if fused in (None, True) else None
+    if fused and route is None:
+        raise ValueError("train_epoch_optimized(fused=True): needs TwoTowersModel(embed) on a GPU, TripletLoss and FusedAdam")
+    if route is not None:
+        return route.run_epoch(dataloader, accumulation_steps=int(accumulation_steps))
     total_loss = 0.0
     num_batches = 0
     for batch_idx, (queries, positives, negatives) in enumerate(dataloader):

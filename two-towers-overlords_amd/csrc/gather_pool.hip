@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void pool_norm_stream_kernel(
     const float* __restrict__ src, const IdT* __restrict__ ids, const MaskT* __restrict__ mask,
     const int* __restrict__ lens, float* __restrict__ out, long long N, int S, int D, long long V,
     int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store, StreamCtl* __restrict__ ctl,
-    int per_cu, int target) {
+    int per_cu, int target, int relax_from) {
   __shared__ float4 part[kWavesPerText][C * TT_WAVE];
   __shared__ float red[kWavesPerText];
   __shared__ int s_next;
@@ -252,7 +252,10 @@ __global__ __launch_bounds__(kThreads) void pool_norm_stream_kernel(
     const bool open = __hip_atomic_load(&ctl->admitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
                       __hip_atomic_load(&ctl->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < N;
     if (open) {
-      if (atomicAdd(&ctl->cu[tt_cu_key()], 1) < per_cu && atomicAdd(&ctl->admitted, 1) < target)
+      // the last `target` candidates of the grid are kept wherever they land: a CU that was offered fewer than its
+      // share while the others turned candidates away (seen once: 511 of 512) is made up for elsewhere
+      const bool here = atomicAdd(&ctl->cu[tt_cu_key()], 1) < per_cu || (int)blockIdx.x >= relax_from;
+      if (here && atomicAdd(&ctl->admitted, 1) < target)
         next = atomicAdd(&ctl->head, 1);  // (else: this CU has its share — leave)
     }
     s_next = next;
@@ -846,7 +849,7 @@ int launch_stream(const float* table, const void* ids, const void* mask, const i
   hipLaunchKernelGGL((pool_norm_stream_kernel<IdT, MaskT, CC, UU>), dim3((unsigned)wgs), dim3(kThreads),     \
                      k1_dynamic_lds(lds_total, CC * 4096u + 32u), st, table, ids_t, mask_t, lens, out,       \
                      (long long)N, S, D, (long long)V, oob, text_rows, (long long)n_store, ctl, per_cu,      \
-                     (int)target)
+                     (int)target, (int)(wgs - target))
   switch (C) {
     case 1: TT_STREAM_CASE(1, 16); break;
     case 2: TT_STREAM_CASE(2, 12); break;

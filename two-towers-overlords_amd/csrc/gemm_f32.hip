@@ -18,6 +18,11 @@
 // file on their way in, four consecutive k of one column per thread, so that its fragments are one ds_read_b128 as well;
 // bitwise the same products — and measured it: no gain at any shape, one-stream configs[3] 1.6 % slower;
 // profiles/r04_tn_transpose_ab.txt.  Removed: 32 ds_read_b32 per K-step and wave are 256 LDS clocks against 1024 MFMA clocks.)
+// (Round 4 also built the K loop with FOUR register staging sets for the 64x64 tiles — a global load requested four
+// K-steps ahead of its use instead of two, 124 instead of 92 VGPRs, bitwise the same products — on the reading that beside
+// the gather the tiles wait for loads: BASELINE.json configs[1] 175.1 -> 186.1 us per step, configs[2]'s share 142.7 ->
+// 145.9; profiles/r04_proj_depth_ab.txt.  Removed: the tiles are not short of requests in flight, and the registers
+// cost a resident wave per SIMD.)
 //
 // Numerics: each C element is a k-ordered fmaf chain in fp32 (what the MFMA
 // computes, bitwise), K-steps in ascending order; split-K (kTN) partials go to

@@ -254,6 +254,9 @@ def main():
     ap.add_argument("--fence-at-loss", type=int, default=None, choices=[0, 1],
                     help="A/B: 1 = the gather stream's slot fence is the engine's loss / fork event, 0 = an event of its own at "
                          "the start of the step (TripletTrainer(fence_at_loss=...)); default: calibrate() decides")
+    ap.add_argument("--join-carries-gather", type=int, default=1, choices=[0, 1],
+                    help="A/B: 1 [default] = in the fork backward the engine's join also carries the wait for the next batch's "
+                         "gather (one wait packet per step on the caller's stream), 0 = a wait of its own ahead of Adam")
     ap.add_argument("--grad-slabs", type=int, default=0,
                     help="split-K slabs of the weight-gradient GEMMs (tt_engine_config.grad_slabs; 0 = the engine's choice)")
     ap.add_argument("--dp-split", action="store_true",
@@ -470,7 +473,7 @@ def run_config(args, world, rank, device) -> dict:
                              k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss,
                              tuning=(args.tuning or None), split_exchange=bool(args.dp_split),
                              fence_at_loss=(None if args.fence_at_loss is None else bool(args.fence_at_loss)),
-                             grad_slabs=args.grad_slabs)
+                             grad_slabs=args.grad_slabs, join_carries_gather=bool(args.join_carries_gather))
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1

@@ -533,6 +533,15 @@ int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event);
 int tt_engine_set_loss_event(tt_engine* e, tt_event_t event);
 
 /*
+ * One-shot: the NEXT tt_engine_fwd_bwd / tt_engine_backward, if it runs the fork backward, makes its second stream wait
+ * for `event` before it records the join — so that the caller's stream, which waits for the join anyway, is thereby also
+ * ordered behind `event` (e.g. the gather of the next batch, training.py:39-48 of the step after) with ONE wait packet
+ * instead of two on the critical stream.  *accepted = 1 if the engine took it (fork schedule), 0 if it did not (fused
+ * schedule, NULL event): then the caller orders its stream itself.  Cleared by that call either way.
+ */
+int tt_engine_set_join_wait(tt_engine* e, tt_event_t event, int32_t* accepted);
+
+/*
  * Events that order streams of ONE device against each other — what the host side needs around tt_engine_pool* on a
  * side stream: "the gather may overwrite this slot once phase B of three batches ago has finished", "phase B may read
  * the slot once the gather has finished".  A default hipEvent performs a system-scope release (cache write-back)

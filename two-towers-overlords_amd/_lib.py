@@ -156,6 +156,7 @@ SIGNATURES = {
     "tt_engine_reduce_grads_range": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "tt_engine_set_dw2_event": (_i, [_vp, _vp]),
     "tt_engine_set_loss_event": (_i, [_vp, _vp]),
+    "tt_engine_set_join_wait": (_i, [_vp, _vp, C.POINTER(C.c_int32)]),
     "tt_event_create": (_i, [_i, C.POINTER(_vp)]),
     "tt_event_destroy": (_i, [_vp]),
     "tt_event_record": (_i, [_vp, _vp]),

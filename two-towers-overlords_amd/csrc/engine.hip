@@ -86,6 +86,7 @@ struct tt_engine {
   int bwd_mode;             // tt_engine_set_backward: TT_BWD_AUTO / TT_BWD_FORK / TT_BWD_FUSED
   hipEvent_t ev_dw2;        // tt_engine_set_dw2_event: recorded once the dW2 / db2 slabs are complete (may be null)
   hipEvent_t ev_loss;       // tt_engine_set_loss_event: recorded on the caller's stream right after the loss kernel (may be null)
+  hipEvent_t join_wait;     // tt_engine_set_join_wait: one-shot, the second stream waits for it before the next join (may be null)
 };
 
 namespace {
@@ -418,6 +419,7 @@ static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_r
   const ttp::Plan shared = chain_plan(e);
   int rc;
   if (!use_fork(e)) {
+    e->join_wait = nullptr;
     if (e->ev_loss) TT_HIP(hipEventRecord(e->ev_loss, st));
     if (loss_rows > 0) {
       rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
@@ -443,6 +445,10 @@ static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_r
   rc = ttp::backward_dw2(t, 2, D, P, e->nslabs, e->slab_stride, e->aux, shared);
   if (rc != TT_OK) return rc;
   if (e->ev_dw2) TT_HIP(hipEventRecord(e->ev_dw2, e->aux));
+  if (e->join_wait) {  // the caller's next dependency rides on the join: one wait packet on the caller's stream, not two
+    TT_HIP(hipStreamWaitEvent(e->aux, e->join_wait, 0));
+    e->join_wait = nullptr;
+  }
   TT_HIP(hipEventRecord(e->ev_join[es], e->aux));
   rc = ttp::backward_dh(t, 2, D, P, st, shared);
   if (rc != TT_OK) return rc;
@@ -544,6 +550,14 @@ extern "C" int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event) {
 extern "C" int tt_engine_set_loss_event(tt_engine* e, tt_event_t event) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   e->ev_loss = static_cast<hipEvent_t>(event);
+  return TT_OK;
+}
+
+extern "C" int tt_engine_set_join_wait(tt_engine* e, tt_event_t event, int32_t* accepted) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  const bool take = event != nullptr && use_fork(e);
+  e->join_wait = take ? static_cast<hipEvent_t>(event) : nullptr;
+  if (accepted) *accepted = take ? 1 : 0;
   return TT_OK;
 }
 

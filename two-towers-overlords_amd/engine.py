@@ -218,6 +218,13 @@ class HotPathEngine:
         self._loss_event = event  # keep it alive while the engine holds its handle
         call("tt_engine_set_loss_event", self._h, None if event is None else event._h)
 
+    def set_join_wait(self, event) -> bool:
+        """One-shot (tt_engine_set_join_wait): the next fwd_bwd() / backward(), if it runs the fork backward, orders its join
+        behind `event` (_lib.StreamEvent) as well.  True if the engine took it; False: wait for the event yourself."""
+        took = C.c_int32(0)
+        call("tt_engine_set_join_wait", self._h, event._h, C.byref(took))
+        return bool(took.value)
+
     def adam(self, step: int, lr: float, grads: Optional[torch.Tensor] = None, beta1=0.9, beta2=0.999, eps=1e-8) -> None:
         g = None
         if grads is not None:

@@ -453,7 +453,7 @@ class TripletTrainer:
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
                  freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: bool = False,
                  gather_under_exchange: bool = True, tuning: Optional[dict] = None, event_scope: Optional[int] = None,
-                 fence_at_loss: Optional[bool] = None, grad_slabs: int = 0):
+                 fence_at_loss: Optional[bool] = None, grad_slabs: int = 0, join_carries_gather: bool = True):
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -571,6 +571,8 @@ class TripletTrainer:
             # on the device at hand (off until then).
             self._loss_event = None
             self._use_loss_fence = False
+            self._join_carries_gather = (join_carries_gather and self.event_scope != 3 and not self._exchange
+                                         and hasattr(self.engine, "set_join_wait"))
             if fence_at_loss is not False and self.event_scope != 3 and hasattr(self.engine, "set_loss_event") and not self._exchange:
                 self._loss_event = _lib.StreamEvent(self.event_scope)
                 self.engine.set_loss_event(self._loss_event)
@@ -580,6 +582,7 @@ class TripletTrainer:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
         else:
             self._loss_event, self._use_loss_fence, self._fence_arg = None, False, fence_at_loss
+            self._join_carries_gather = False
         self._prewaited = None                # slot whose "ready" event the caller's stream already waits for
         self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
         self.k1_event_every = 4               # ... of every 4th launch
@@ -780,6 +783,13 @@ class TripletTrainer:
             if ev is not None and self._prewaited != slot and not ev.query():  # (a gather issued two batches ago has
                 ev.wait(self._apply_stream)  # usually finished: then no wait packet goes into this stream at all)
             self._prewaited = None
+            # The NEXT batch's gather must have finished before its forward starts.  In the fork backward this stream
+            # waits for the engine's join anyway: the engine's second stream — idle by then — takes the wait for the
+            # gather ahead of recording the join, and this stream carries one wait packet per step instead of two.
+            if self._join_carries_gather and self._pending and self.loss_kind != "inbatch" and local_B > 0:
+                nslot, nev, *_ = self._pending[0]
+                if nev is not None and not nev.query() and self.engine.set_join_wait(nev):
+                    self._prewaited = nslot
         if self.device.type == "cuda":  # read by phase B on this stream, possibly allocated on a producer's stream
             for t in (neg_index, query_ids):
                 if t is not None:
@@ -845,6 +855,8 @@ class TripletTrainer:
         if self.side is None or not self._pending:
             return
         slot, ev, *_ = self._pending[0]
+        if self._prewaited == slot:  # rides on the engine's join (apply())
+            return
         if ev is not None and not ev.query():
             ev.wait(torch.cuda.current_stream(self.device))
             self._prewaited = slot

@@ -786,7 +786,7 @@ class TripletTrainer:
             # The NEXT batch's gather must have finished before its forward starts.  In the fork backward this stream
             # waits for the engine's join anyway: the engine's second stream — idle by then — takes the wait for the
             # gather ahead of recording the join, and this stream carries one wait packet per step instead of two.
-            if self._join_carries_gather and self._pending and self.loss_kind != "inbatch" and local_B > 0:
+            if self._join_carries_gather and self._pending and local_B > 0:
                 nslot, nev, *_ = self._pending[0]
                 if nev is not None and not nev.query() and self.engine.set_join_wait(nev):
                     self._prewaited = nslot

@@ -573,6 +573,53 @@ def test_feature_cache_is_bitwise_the_gather(tt):
 
 
 # --------------------------------------------------------------------------- engine on awkward shapes
+def test_engine_join_orders_the_callers_stream_behind_a_handed_event(tt):
+    """tt_engine_set_join_wait: in the fork backward the engine's second stream waits for the handed event before it
+    records the join, so the caller's stream — which waits for the join — is ordered behind the event too (one-shot);
+    the fused backward has no join and says so (accepted = 0), and the caller then orders its stream itself."""
+    from two_towers_overlords_amd import _lib
+
+    _, engine = tt
+    g = load_golden("step_mid.npz")
+    table = dev(g["table"])
+    P = g["init/query_tower.projection.0.bias"].shape[0]
+    ids = torch.stack([T(g[f"batch0/ids_{r}"]) for r in "qpn"]).cuda()
+    mask = torch.stack([T(g[f"batch0/mask_{r}"]) for r in "qpn"]).cuda()
+    B, S = ids.shape[1:]
+    flat0 = _flat({k: T(g["init/" + k]) for k in orc.PARAM_KEYS}).cuda()
+    side = torch.cuda.Stream()
+    for mode, takes in (("fork", True), ("fused", False)):
+        eng = engine.HotPathEngine(table, P, B, S, tuning={"backward": mode})
+        flat = flat0.clone()
+        eng.bind(flat, torch.zeros_like(flat), torch.zeros_like(flat))
+        eng.pool(0, ids, mask)
+        flag = torch.zeros(1, device="cuda")
+        torch.cuda.synchronize()
+        ev = _lib.StreamEvent(1)
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(8_000_000)  # milliseconds: far longer than the step below
+            flag.fill_(1.0)
+        ev.record(side)
+        assert eng.set_join_wait(ev) is takes
+        eng.fwd_bwd(0, B, float(g["margin"]))
+        seen = flag.clone()  # on the caller's stream, right behind the step
+        torch.cuda.synchronize()
+        assert seen.item() == (1.0 if takes else 0.0), mode
+        # one-shot: the next step's join no longer waits for anything of the caller's
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(8_000_000)
+            flag.fill_(2.0)
+        eng.fwd_bwd(0, B, float(g["margin"]))
+        seen = flag.clone()
+        torch.cuda.synchronize()
+        assert seen.item() == 1.0, mode
+        grads = torch.empty_like(flat)
+        eng.reduce_grads(grads)
+        for k, gt in _unflat(grads, table.shape[1], P).items():
+            close(gt, g["grad/" + k], rel_to_max=True)
+        eng.close()
+
+
 @pytest.mark.parametrize("V,D,P,B,S,idt,use_mask", [
     (50, 100, 37, 1, 1, torch.int64, True),      # one triplet, one token, nothing divisible by anything
     (300, 8, 4, 3, 512, torch.int32, False),     # max_length-long rows (model.py:44 truncates at 512)

@@ -266,9 +266,17 @@ class _EngineRoute:
 
     @staticmethod
     def _stack(queries, positives, negatives) -> "TripletBatch":
-        """(ids, mask) x 3 as one batch; stacked into [3, B, S] by the trainer on the stream that gathers (the copies then
-        run beside the projection chain instead of in it)."""
-        return TripletBatch(parts=[_ids_mask(x) for x in (queries, positives, negatives)])
+        """(ids, mask) x 3 -> ids [3, B, S], mask [3, B, S] padded to the longest role (masked-out zeros are never read).
+        On the caller's stream: built on the gather stream instead (round 4) the step is slower, 215.2 vs 210.5 us — with
+        int64 ids and masks the gather stream is the longer one (profiles/r04_module_path.txt)."""
+        blocks = [_ids_mask(x) for x in (queries, positives, negatives)]
+        S = max(i.shape[1] for i, _ in blocks)
+        pad = lambda t: t if t.shape[1] == S else torch.nn.functional.pad(t, (0, S - t.shape[1]))
+        ids = torch.stack([pad(i) for i, _ in blocks])
+        if all(m is None for _, m in blocks) and all(i.shape[1] == S for i, _ in blocks):
+            return TripletBatch(ids=ids.contiguous())
+        mask = torch.stack([pad(torch.ones_like(i) if m is None else m.to(i.dtype)) for i, m in blocks])
+        return TripletBatch(ids=ids.contiguous(), mask=mask.contiguous())
 
     def _batches(self, dataloader):
         dt, qt = self.model.document_tower, self.model.query_tower
@@ -287,11 +295,11 @@ class _EngineRoute:
         first = next(it, None)
         if first is None:
             raise ZeroDivisionError("train_epoch: empty dataloader")  # what the reference's `total_loss / num_batches` raises
-        if first.width > self.MAX_S:
-            raise ValueError(f"train_epoch(fused): rows of {first.width} tokens exceed {self.MAX_S}")
+        if first.ids.shape[2] > self.MAX_S:
+            raise ValueError(f"train_epoch(fused): rows of {first.ids.shape[2]} tokens exceed {self.MAX_S}")
         if self.trainer is None or first.size > self.trainer.engine.max_B:
             self._build(first.size)
-            if first.size * first.width >= 65536:  # a batch worth timing: pick the backward schedule / fence placement
+            if first.size * first.ids.shape[2] >= 65536:  # a batch worth timing: pick the backward schedule / fence placement
                 self.trainer.calibrate(first)             # for this device and shape (state-neutral, ~0.1 s once)
         tr = self.trainer
         group = self.optimizer.param_groups[0]
@@ -340,8 +348,8 @@ class _EngineRoute:
         return loss_sum / n
 
     def _check(self, b) -> None:
-        if b.size > self.trainer.engine.max_B or b.width > self.MAX_S:
-            raise ValueError(f"train_epoch(fused): a batch of {b.size} x {b.width} tokens after a first batch of "
+        if b.size > self.trainer.engine.max_B or b.ids.shape[2] > self.MAX_S:
+            raise ValueError(f"train_epoch(fused): a batch of {b.size} x {b.ids.shape[2]} tokens after a first batch of "
                              f"{self.trainer.engine.max_B}: put the largest batch first, or call train_epoch(fused=False)")
 
 
@@ -403,37 +411,13 @@ class TripletBatch:
     # host->device copies on a copy stream); the gather then waits for it.  Not needed for tensors produced on the
     # stream that calls gather(): that stream is fenced anyway.
     ready_event: Optional["torch.cuda.Event"] = None
-    # the three roles still as the tokenizer returned them — [(input_ids [B, S_r], attention_mask [B, S_r] | None)] x 3,
-    # backend/model.py:43-48 — to be stacked into ids / mask [3, B, S] on the stream that gathers (train_epoch's route)
-    parts: Optional[list] = None
 
     @property
     def size(self) -> int:
         for t in (self.ids, self.token_rows, self.cache_rows):
             if t is not None:
                 return t.shape[1]
-        if self.parts is not None:
-            return self.parts[0][0].shape[0]
         raise ValueError("empty TripletBatch")
-
-    @property
-    def width(self) -> int:
-        """Tokens per text of an ids / parts batch."""
-        return self.ids.shape[2] if self.ids is not None else max(i.shape[1] for i, _ in self.parts)
-
-    def stacked(self) -> "TripletBatch":
-        """parts -> ids [3, B, S] (+ mask), padded to the longest role (masked-out zeros are never read); on the
-        current stream."""
-        if self.parts is None:
-            return self
-        blocks = self.parts
-        S = self.width
-        pad = lambda t: t if t.shape[1] == S else torch.nn.functional.pad(t, (0, S - t.shape[1]))
-        ids = torch.stack([pad(i) for i, _ in blocks])
-        if all(m is None for _, m in blocks) and all(i.shape[1] == S for i, _ in blocks):
-            return dataclasses.replace(self, ids=ids, parts=None)
-        mask = torch.stack([pad(torch.ones_like(i) if m is None else m.to(i.dtype)) for i, m in blocks])
-        return dataclasses.replace(self, ids=ids, mask=mask, parts=None)
 
     def expand_negatives(self) -> "TripletBatch":
         """roles 2 + neg_index -> roles 3 (negatives materialised by a row gather)."""
@@ -655,7 +639,7 @@ class TripletTrainer:
             self._pending.append((slot, None, 0, None, batch.query_ids))
             return
         if self.side is None:
-            self._timed_pool(slot, batch.stacked(), None)
+            self._timed_pool(slot, batch, None)
             self._pending.append((slot, None, batch.size, batch.neg_index, batch.query_ids))
             return
         # Order the side stream behind everything the caller's stream holds at this point: (a) the kernels or
@@ -678,8 +662,7 @@ class TripletTrainer:
             self.side.wait_event(batch.ready_event)
         # K1 reads these tensors on the side stream: tell the caching allocator, so that memory the producer
         # drops right after this call is not handed out again before K1 has finished with it
-        for t in (batch.ids, batch.mask, batch.lens, batch.cache_rows, batch.token_rows,
-                  *(x for part in (batch.parts or ()) for x in part)):
+        for t in (batch.ids, batch.mask, batch.lens, batch.cache_rows, batch.token_rows):
             if t is not None:
                 t.record_stream(self.side)
         # launch on the side stream by handle (no stream context switch on the host)
@@ -694,9 +677,6 @@ class TripletTrainer:
             self._k1_count += 1
             timed = self._k1_count % self.k1_event_every == 0  # events cost ~5 us of stream time each
         raw = None if stream is None else stream.cuda_stream
-        if batch.parts is not None:  # the [3, B, S] block is built on the stream that reads it (and owned by its allocator pool)
-            with torch.cuda.stream(stream):
-                batch = batch.stacked()
         if timed:
             pool = self.k1_event_pool  # events created ahead of time (bench): no hipEventCreate inside a timed region
             e0, e1 = pool.pop() if pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

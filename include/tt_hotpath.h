@@ -80,7 +80,8 @@ typedef struct {
   int32_t proj_tile;       /* projection block tile, rows x columns in units of 64: 11, 21, 22 (auto: by shape) */
   int32_t proj_bk;         /* K-step of the 128x128 projection tile: 16 or 32 */
   int32_t tn_tile;         /* weight-gradient (split-K) tile: 11 or 22 */
-  int32_t xcd_order;       /* XCD-aware workgroup order of the projection GEMMs: 1 on, -1 off */
+  int32_t xcd_order;       /* XCD-aware workgroup order of the projection GEMMs: 1 on, -1 off (auto: beside the streaming
+                              gather, and beside the sliced gather from 6144 rows per launch) */
   int32_t backward;        /* engine: TT_BWD_* schedule of phase B's backward */
   int32_t event_scope;     /* engine: release scope of the events that order its two streams: 1 no system-scope fence
                               (hipEventDisableSystemFence; auto), 2 device-scope release (hipEventReleaseToDevice),

@@ -286,7 +286,9 @@ extern "C" int tt_engine_bind(tt_engine* e, const float* table, float* params, f
 static ttp::Plan chain_plan(const tt_engine* e) {
   int policy = !e->shared ? ttp::kTileAuto : (e->tile_above ? ttp::kTileSmall : ttp::kTileLowTraffic);
   if (e->shared && e->stream_beside) policy = ttp::kTileStream;
-  return ttp::plan_of(&e->tuning, policy);
+  ttp::Plan pl = ttp::plan_of(&e->tuning, policy);
+  pl.beside_gather = e->shared && e->gathers_share_chip;
+  return pl;
 }
 
 static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, const void* mask, int mask_dtype,

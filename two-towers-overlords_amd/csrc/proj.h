@@ -31,6 +31,7 @@ enum TilePolicy : int { kTileAuto = 0, kTileLowTraffic = 1, kTileSmall = 2, kTil
 // business) and the caller's explicit choices (tt_tuning, 0 = auto), which win over the policy.
 struct Plan {
   int policy = kTileAuto;
+  bool beside_gather = false;  // token-id gathers of another stream are sharing the chip with this call (engine.hip)
   tt_tuning t{};
 };
 inline Plan plan_of(const tt_tuning* t, int policy = kTileAuto) {

@@ -38,10 +38,20 @@ int choose_nsplit_towers(long long B, int P, int D) {
 }
 
 // XCD-aware workgroup order for the projection GEMMs (gemm_f32.h): on beside the streaming gather, where every
-// re-read of an operand block that misses the XCD's L2 competes with the gather for the fabric.
-static int xcd_order_for(const Plan& pl) {
+// re-read of an operand block that misses the XCD's L2 competes with the gather for the fabric — and beside the
+// sliced gather from 6144 rows per launch (B >= 2048 triplets) up, where an XCD's L2 then sees one eighth of the
+// activations beside the table slice it keeps for the gather: measured (profiles/r04_xcd_order_ab.txt) B = 2048
+// 172.6 -> 170.1 us, B = 4096 338.7 -> 334.9, P = 512 B = 2048 221.7 -> 220.2, by-index 145.2 -> 143.9; below that the
+// eight classes' rounding costs more than it saves (B = 1024 117.8 -> 119.7, B = 512 93.9 -> 96.7): off there, and off
+// when nothing gathers beside the chain (frozen-feature cache: 123.5 vs 124.2).
+static long long rows_of(const Tower* t, int count) {
+  long long rows = 0;
+  for (int i = 0; i < count; ++i) rows += t[i].M;
+  return rows;
+}
+static int xcd_order_for(const Plan& pl, long long rows) {
   if (pl.t.xcd_order != 0) return pl.t.xcd_order > 0;
-  return pl.policy == kTileStream;
+  return pl.policy == kTileStream || (pl.policy == kTileSmall && pl.beside_gather && rows >= 6144);
 }
 
 // Tile of the split-K weight-gradient GEMMs: 64x64 (many short workgroups; pairs with the gather's LDS reservation at
@@ -90,7 +100,7 @@ int forward(const Tower* t, int count, int D, int P, hipStream_t st, const Plan&
   ttg::Batch b1{}, b2{};
   b1.count = b2.count = count;
   b1.nsplit = b2.nsplit = 1;
-  b1.xcd_order = b2.xcd_order = xcd_order_for(pl);
+  b1.xcd_order = b2.xcd_order = xcd_order_for(pl, rows_of(t, count));
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -119,7 +129,7 @@ int backward_dw2(const Tower* t, int count, int D, int P, int nsplit, long long 
   ttg::Batch g2{};
   g2.count = count;
   g2.nsplit = nsplit;
-  g2.xcd_order = xcd_order_for(pl);
+  g2.xcd_order = xcd_order_for(pl, rows_of(t, count));
   g2.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW2[i,j] = sum_m dOut[m,i] H[m,j];  db2[i] = sum_m dOut[m,i]
@@ -136,7 +146,7 @@ int backward_dh(const Tower* t, int count, int D, int P, hipStream_t st, const P
   ttg::Batch gh{};
   gh.count = count;
   gh.nsplit = 1;
-  gh.xcd_order = xcd_order_for(pl);
+  gh.xcd_order = xcd_order_for(pl, rows_of(t, count));
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -157,7 +167,7 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
   g2.nsplit = nsplit;
   g2.slab_stride = slab_stride;
   gh.nsplit = 1;
-  g2.xcd_order = gh.xcd_order = xcd_order_for(pl);
+  g2.xcd_order = gh.xcd_order = xcd_order_for(pl, rows_of(t, count));
   long long rows = 0;
   for (int i = 0; i < count; ++i) {
     rows += t[i].M;
@@ -184,7 +194,7 @@ int backward_dw1(const Tower* t, int count, int D, int P, int nsplit, long long 
   ttg::Batch g1{};
   g1.count = count;
   g1.nsplit = nsplit;
-  g1.xcd_order = xcd_order_for(pl);
+  g1.xcd_order = xcd_order_for(pl, rows_of(t, count));
   g1.slab_stride = slab_stride;
   for (int i = 0; i < count; ++i) {
     // dW1[i,j] = sum_m dH[m,i] X[m,j];  db1[i] = sum_m dH[m,i]

@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="triplets per GPU per step (default: the config's)")
+    ap.add_argument("--vocab", type=int, default=None,
+                    help="diagnostic: rows of the embedding table (default: the config's) — how the step depends on whether a "
+                         "column slice of the table fits an XCD's L2 beside the projection chain's operands")
     ap.add_argument("--zipf", action="store_true", help="Zipf(1) token ids instead of uniform")
     ap.add_argument("--ragged", action="store_true",
                     help="ragged prefix lengths (queries U{8..S}, documents U{32..S}; SURVEY.md §8d) instead of full length")
@@ -299,7 +302,7 @@ def main():
         return
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
-                    and not args.zipf and not args.ragged and not args.tuning and not args.dp_split
+                    and not args.vocab and not args.zipf and not args.ragged and not args.tuning and not args.dp_split
                     and args.fence_at_loss is None and not args.grad_slabs)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
     # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")
@@ -440,6 +443,9 @@ def run_config(args, world, rank, device) -> dict:
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["B"] = args.batch
+    if args.vocab:  # diagnostic: another table height (config.vocab records it; not a BASELINE workload)
+        cfg["V"] = args.vocab
+        cfg["label"] += f" [diagnostic: vocab {args.vocab}]"
     V, D, P, B, S = cfg["V"], cfg["D"], cfg["P"], cfg["B"], cfg["S"]
 
     gt = torch.Generator().manual_seed(1)

@@ -575,8 +575,8 @@ def test_feature_cache_is_bitwise_the_gather(tt):
 # --------------------------------------------------------------------------- engine on awkward shapes
 def test_engine_join_orders_the_callers_stream_behind_a_handed_event(tt):
     """tt_engine_set_join_wait: in the fork backward the engine's second stream waits for the handed event before it
-    records the join, so the caller's stream — which waits for the join — is ordered behind the event too (one-shot);
-    the fused backward has no join and says so (accepted = 0), and the caller then orders its stream itself."""
+    records the join, so the caller's stream — which waits for the join — is ordered behind the event too; the fused
+    backward has no join and says so (accepted = 0), and the caller then orders its stream itself."""
     from two_towers_overlords_amd import _lib
 
     _, engine = tt
@@ -604,15 +604,8 @@ def test_engine_join_orders_the_callers_stream_behind_a_handed_event(tt):
         eng.fwd_bwd(0, B, float(g["margin"]))
         seen = flag.clone()  # on the caller's stream, right behind the step
         torch.cuda.synchronize()
-        assert seen.item() == (1.0 if takes else 0.0), mode
-        # one-shot: the next step's join no longer waits for anything of the caller's
-        with torch.cuda.stream(side):
-            torch.cuda._sleep(8_000_000)
-            flag.fill_(2.0)
-        eng.fwd_bwd(0, B, float(g["margin"]))
-        seen = flag.clone()
-        torch.cuda.synchronize()
-        assert seen.item() == 1.0, mode
+        if takes:  # (the converse — "not ordered" — is not asserted: streams may share a hardware queue)
+            assert seen.item() == 1.0, mode
         grads = torch.empty_like(flat)
         eng.reduce_grads(grads)
         for k, gt in _unflat(grads, table.shape[1], P).items():

@@ -67,6 +67,8 @@ typedef enum {
 #define TT_K1_ROW_SLICES 2    /* XCD-sliced, token ids mod 8 */
 #define TT_K1_COLUMN_SLICES 3 /* XCD-sliced, 32-column slices (D % 32 == 0) */
 #define TT_K1_STREAM 4        /* persistent workgroups + per-CU registry (tables that stream from HBM) */
+#define TT_K1_BINNED 5        /* tokens sorted by row class (id % 8) + 32-column slices: an (XCD, slice) block of a big table
+                                 fits the XCD's L2 (D % 32 == 0) */
 #define TT_BWD_AUTO 0
 #define TT_BWD_FORK 1
 #define TT_BWD_FUSED 2
@@ -178,6 +180,27 @@ int tt_gather_pool_norm_stream_f32(const float* table, const void* ids, int ids_
  * workgroups the launch meant to keep (workgroups_per_cu x compute units, or fewer for a short queue). */
 int tt_gather_pool_stream_census(const void* workspace, int32_t* admitted, int32_t* cus_used,
                                  int32_t* max_registered, int32_t* planned, tt_stream_t stream);
+
+/*
+ * Binned form of tt_gather_pool_norm_f32 for tables too big for the column slices (V x 128 bytes beyond an L2) whose
+ * rows are named many times per launch (N x S >> V; BASELINE.json configs[3]: 12.6 M tokens over 250 000 rows): each
+ * text's live tokens are sorted by row class id % 8 once, then XCD c gathers only class c, 32 columns at a time — block
+ * (c, slice) of the table is V x 16 bytes (4.0 MB at V = 250 000) and stays in that XCD's L2, so a table line crosses the
+ * fabric about once per launch instead of once per token that names it; the 8 class partials of a text are added in
+ * class order, then mean (clamp 1e-9) and L2 norm (clamp 1e-12).  Same arguments as tt_gather_pool_norm_f32 and the
+ * same result up to fp32 summation order; run-to-run bitwise reproducible.  `workspace`:
+ * tt_gather_pool_binned_workspace_bytes(N, D, S) bytes, 16-byte aligned (8 x N x D floats of partials + the sorted
+ * ids / weights).  Requires D % 32 == 0, D <= 1024, S <= 512.  Replaces backend/model.py:51-56, 63-72.
+ */
+size_t tt_gather_pool_binned_workspace_bytes(int64_t N, int D, int S);
+int tt_k1_binned_supported(int S, int D, const float* table, const float* out);
+/* 1 if the binned form is the one to use for this shape on MI355X (a pure function of the shape; tt_engine_pool applies
+ * it by itself): a column slice of the table beyond 13 MB, texts of >= 64 tokens, every row named >= 8 times per launch */
+int tt_k1_prefers_binned(int64_t V, int D, int64_t N, int S);
+int tt_gather_pool_norm_binned_f32(const float* table, const void* ids, int ids_dtype,
+                                   const void* mask, int mask_dtype, const int32_t* lens,
+                                   float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                                   void* workspace, size_t workspace_bytes, tt_stream_t stream);
 
 /*
  * Same pooling + normalisation over dense hidden states [N,S,D] (the `bert`

@@ -391,6 +391,7 @@ ENGINE_SETUPS = [
     (0, {"k1_form": "columns"}),
     (-1, {"k1_form": "columns", "proj_tile": 21, "xcd_order": 1}),
     (2, {"backward": "fork", "k1_form": "per_text"}),
+    (-1, {"k1_form": "binned"}),
     (-1, {"backward": "fused", "tn_tile": 22, "proj_tile": 22, "proj_bk": 16, "k1_share_lds_kb": 40}),
 ]
 _eid = lambda s: f"share={s[0]}," + _tid(s[1])
@@ -673,7 +674,7 @@ def test_engine_streams_a_table_beyond_the_infinity_cache_only_for_long_batches(
     ops, engine = tt
     from two_towers_overlords_amd import _lib
 
-    V, D, P, S = 131072, 768, 256, 256
+    V, D, P, S = 160000, 768, 256, 256  # (1408 x 3 x 256 tokens name a row < 8 times: not a case for the binned form)
     gen = torch.Generator().manual_seed(41)
     table = (torch.randn(V, D, generator=gen) * 0.5).cuda()
     assert V * D * 4 >= 400e6
@@ -711,6 +712,62 @@ def test_engine_streams_a_table_beyond_the_infinity_cache_only_for_long_batches(
         assert abs(last - loss.item()) <= TOL
         for r in range(3):
             close(eng.embeddings(B)[r], embs[r].detach().float())
+        ref_g = torch.cat([leaves[k].grad.reshape(-1) for k in orc.PARAM_KEYS]).float()
+        close(g, ref_g, rel_to_max=True)
+        sub = torch.arange(0, 3 * B, max(1, 3 * B // 40))[:40].cuda()
+        mask = (torch.arange(S, device="cuda").unsqueeze(0) < lens[sub].unsqueeze(1)).long()
+        close(pooled[sub], orc.gather_pool_normalize(table.cpu(), ids[sub].long().cpu(), mask.cpu()), atol=2e-6)
+    eng.close()
+
+
+def test_engine_bins_a_big_table_whose_rows_a_batch_names_many_times(tt):
+    """The default policy, nothing forced: a table whose 128-byte column slice is beyond an L2 (110 000 rows) and a batch
+    that names every row ~10 times -> the binned gather (tokens sorted by row class, class x column-slice blocks out of
+    the XCDs' L2s), row indirection included: bitwise what tt_gather_pool_norm_binned_f32 gives for the same texts,
+    within 1e-6 of the per-text kernel, the oracle on a subsample, and a full step against fp64 autograd on the device;
+    a short batch of the same engine is not binned (bitwise the per-text kernel)."""
+    ops, engine = tt
+    from two_towers_overlords_amd import _lib
+
+    V, D, P, S = 110000, 768, 128, 256
+    gen = torch.Generator().manual_seed(43)
+    table = (torch.randn(V, D, generator=gen) * 0.5).cuda()
+    params = orc.init_params(D, P, seed=10)
+    Bmax = 1408
+    eng = engine.HotPathEngine(table, P, Bmax, S, k1_blocks_per_cu=_lib.TT_K1_SHARE_AUTO)
+    flat = _flat(params).cuda()
+    eng.bind(flat, torch.zeros_like(flat), torch.zeros_like(flat))
+    store = torch.randint(0, V, (5000, S), generator=gen, dtype=torch.int32).cuda()
+    store_lens = torch.randint(1, S + 1, (5000,), generator=gen).int().cuda()
+    store_lens[:7] = torch.tensor([0, 1, S, S, 0, 2, S]).int().cuda()
+    for B, binned in ((Bmax, True), (96, False)):
+        rows = torch.randint(0, 5000, (3, B), generator=gen).int().cuda()
+        rows[0, :7] = torch.arange(7).int().cuda()  # an empty text, one-token texts, full texts
+        eng.pool_rows(1, store, store_lens, rows)
+        assert eng.k1_census(1)[0] == 0  # not the streaming form
+        ids = store[rows.long()].reshape(3 * B, S).contiguous()
+        lens = store_lens[rows.long()].reshape(-1).contiguous()
+        pooled = eng.pooled(1, B).reshape(3 * B, D)
+        per_text = ops.gather_pool_norm(table, ids, lens=lens, sliced=False)
+        if binned:
+            assert torch.equal(pooled, ops.gather_pool_norm(table, ids, lens=lens, form="binned"))
+            assert (pooled - per_text).abs().max().item() <= 1e-6
+        else:
+            assert torch.equal(pooled, per_text)
+        eng.fwd_bwd(1, B, 0.3)
+        g = torch.empty_like(flat)
+        eng.reduce_grads(g)
+        _, _, last = eng.read_stats()
+        x = pooled.double().reshape(3, B, D)
+        leaves = {k: v.double().cuda().requires_grad_(True) for k, v in params.items()}
+        embs = []
+        for r, tower in enumerate(("query_tower", "document_tower", "document_tower")):
+            k = tower + ".projection."
+            embs.append(torch.relu(x[r] @ leaves[k + "0.weight"].T + leaves[k + "0.bias"]) @ leaves[k + "2.weight"].T + leaves[k + "2.bias"])
+        cos = torch.nn.functional.cosine_similarity
+        loss = torch.relu((1 - cos(embs[0], embs[1])) - (1 - cos(embs[0], embs[2])) + 0.3).mean()
+        loss.backward()
+        assert abs(last - loss.item()) <= TOL
         ref_g = torch.cat([leaves[k].grad.reshape(-1) for k in orc.PARAM_KEYS]).float()
         close(g, ref_g, rel_to_max=True)
         sub = torch.arange(0, 3 * B, max(1, 3 * B // 40))[:40].cuda()
@@ -838,7 +895,11 @@ def test_metric_size_properties(tt, V, D, P, B, S):
     emb2, pooled2, g2, loss2, flat2 = run()
     assert torch.equal(emb, emb2) and torch.equal(g, g2) and loss == loss2 and torch.equal(flat1, flat2)
     # the engine's gather is the public entry point's (XCD-sliced form where the library prefers it)
-    engine_form = sliced if _lib.load().tt_k1_prefers_sliced(V, D, 3 * B, S) else per_text
+    if _lib.load().tt_k1_prefers_binned(V, D, 3 * B, S):  # a big table named many times per batch (configs[3])
+        engine_form = ops.gather_pool_norm(tab_d, flat_ids, lens=flat_lens, form="binned")
+        assert (engine_form - per_text).abs().max().item() <= 1e-6
+    else:
+        engine_form = sliced if _lib.load().tt_k1_prefers_sliced(V, D, 3 * B, S) else per_text
     assert torch.equal(pooled.reshape(3 * B, D), engine_form)
 
     # oracle on a subsample of rows: pooled vectors and projected embeddings
@@ -985,6 +1046,65 @@ def test_pool_column_slices_random_shapes(tt):
         close(b, ref, atol=2e-6)
         assert (a - b).abs().max().item() <= 1e-6, (case, D, S, V, N, kind)
         assert torch.equal(b, b2), (case, D, S, V, N, kind)
+
+
+def test_pool_binned_form_random_shapes(tt):
+    """The binned form (tokens sorted by row class id % 8, then 32-column slices per class, 8 class partials added in
+    class order) over 40 seeded random shapes where it applies (D a multiple of 32 up to 1024, S up to 512, tables from a
+    handful of rows — fewer than the 8 classes — up, few and many texts incl. counts that are not multiples of the 8 texts a
+    wave takes), every kind of weighting (prefix lengths incl. empty texts, masks with holes, integer weights, none),
+    both index widths, out-of-range ids (clamped and flagged): against the oracle, against the per-text form (1e-6)
+    and against itself (bitwise, twice); the C ABI refuses a workspace that is too small."""
+    import ctypes as C
+
+    from two_towers_overlords_amd import _lib
+
+    ops, _ = tt
+    gen = torch.Generator().manual_seed(2031)
+    for case in range(40):
+        D = 32 * int(torch.randint(1, 33, (1,), generator=gen))
+        S = int(torch.randint(1, 513, (1,), generator=gen)) if case % 4 else int(torch.randint(1, 70, (1,), generator=gen))
+        V = int(torch.randint(3, 3000, (1,), generator=gen)) if case % 7 else int(torch.randint(1, 8, (1,), generator=gen))
+        N = int(torch.randint(1, 40, (1,), generator=gen)) if case % 3 else int(torch.randint(200, 900, (1,), generator=gen))
+        table = torch.randn(V, D, generator=gen)
+        ids = torch.randint(0, V, (N, S), generator=gen)
+        kind = case % 4
+        mask, lens = None, None
+        if kind == 0:
+            lens = torch.randint(0, S + 1, (N,), generator=gen)
+            eff = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+        elif kind == 1:
+            mask = (torch.rand(N, S, generator=gen) < 0.7).long()
+            eff = mask
+        elif kind == 2:
+            mask = torch.randint(0, 4, (N, S), generator=gen)
+            eff = mask
+        else:
+            eff = torch.ones(N, S, dtype=torch.long)
+        if case % 5 == 0:
+            ids[0, 0] = V + 7
+            ids[-1, -1] = -3
+        ref = orc.gather_pool_normalize(table, ids.clamp(0, V - 1), eff)
+        idt = torch.int32 if case % 2 else torch.int64
+        mt = torch.int32 if case % 3 else torch.int64
+        kw = dict(attention_mask=None if mask is None else mask.to(mt).cuda(), lens=None if lens is None else lens.int().cuda())
+        a = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), sliced=False, **kw)
+        b = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), form="binned", **kw)
+        b2 = ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), form="binned", **kw)
+        close(b, ref, atol=2e-6)
+        assert (a - b).abs().max().item() <= 1e-6, (case, D, S, V, N, kind)
+        assert torch.equal(b, b2), (case, D, S, V, N, kind)
+        if case % 5 == 0 and eff[0, 0] != 0:
+            with pytest.raises(IndexError):
+                ops.gather_pool_norm(table.cuda(), ids.to(idt).cuda(), form="binned", check_ids=True, **kw)
+    lib = _lib.load()
+    assert lib.tt_gather_pool_binned_workspace_bytes(10, 48, 16) == 0  # D % 32 != 0
+    need = int(lib.tt_gather_pool_binned_workspace_bytes(10, 64, 16))
+    assert need == (8 * 10 * 64 + 2 * 10 * 16 + 9 * 10 + 10) * 4
+    t, i, o, w = torch.randn(50, 64).cuda(), torch.zeros(10, 16, dtype=torch.int32).cuda(), torch.empty(10, 64).cuda(), torch.empty(need, dtype=torch.uint8).cuda()
+    rc = lib.tt_gather_pool_norm_binned_f32(t.data_ptr(), i.data_ptr(), 4, None, 4, None, o.data_ptr(), 10, 16, 64, 50, None,
+                                            w.data_ptr(), need - 4, None)
+    assert rc == -5  # TT_ERR_WORKSPACE
 
 
 # --------------------------------------------------------------------------- streaming K1 (tables that come from HBM)

@@ -19,9 +19,9 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 TT_I32, TT_I64 = 4, 8
 TT_BWD_AUTO, TT_BWD_FORK, TT_BWD_FUSED = 0, 1, 2
 TT_K1_SHARE_AUTO = -1  # tt_engine_config.k1_blocks_per_cu: pair the K1 form with the projection tile
-TT_K1_AUTO, TT_K1_PER_TEXT, TT_K1_ROW_SLICES, TT_K1_COLUMN_SLICES, TT_K1_STREAM = 0, 1, 2, 3, 4
+TT_K1_AUTO, TT_K1_PER_TEXT, TT_K1_ROW_SLICES, TT_K1_COLUMN_SLICES, TT_K1_STREAM, TT_K1_BINNED = 0, 1, 2, 3, 4, 5
 K1_FORMS = {"auto": TT_K1_AUTO, "per_text": TT_K1_PER_TEXT, "rows": TT_K1_ROW_SLICES, "columns": TT_K1_COLUMN_SLICES,
-            "stream": TT_K1_STREAM}
+            "stream": TT_K1_STREAM, "binned": TT_K1_BINNED}
 ABI_VERSION = 2
 
 _lib = None
@@ -112,6 +112,10 @@ SIGNATURES = {
     "tt_k1_prefers_sliced": (_i, [_i64, _i, _i64, _i]),
     "tt_k1_sliced_form": (_i, [_i64, _i, _i]),
     "tt_gather_pool_norm_sliced_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _i, _vp]),
+    "tt_gather_pool_binned_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "tt_k1_binned_supported": (_i, [_i, _i, _vp, _vp]),
+    "tt_k1_prefers_binned": (_i, [_i64, _i, _i64, _i]),
+    "tt_gather_pool_norm_binned_f32": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "tt_gather_pool_stream_workspace_bytes": (_sz, []),
     "tt_k1_stream_supported": (_i, [_i, _vp, _vp]),
     "tt_k1_prefers_stream": (_i, [_i64, _i, _i64, _i]),

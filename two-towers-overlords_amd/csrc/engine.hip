@@ -19,6 +19,10 @@ int tt_k1_sliced_launch(const float* table, const void* ids, int ids_dtype, cons
                         void* workspace, size_t workspace_bytes, unsigned lds_total, int form, hipStream_t st,
                         const int32_t* text_rows, int64_t n_store);
 int tt_k1_sliced_supported(int S, int D, const float* table, const float* out);
+int tt_k1_binned_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                        const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st,
+                        const int32_t* text_rows, int64_t n_store);
 size_t tt_k1_colsliced_workspace_bytes(int64_t N, int D);
 int tt_k1_stream_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                         const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
@@ -114,6 +118,12 @@ void carve(tt_engine* e, char* base, size_t* total) {
   const size_t sliced_bytes = tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D);
   e->k1_partial_bytes = (tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, (int64_t)1 << 40, 128) || sliced_bytes <= (64u << 20))
                             ? sliced_bytes : tt_k1_colsliced_workspace_bytes((int64_t)rows, e->cfg.D);  // (the column form's is tiny)
+  // the binned form's partials + sorted ids, where the engine may pick it (a big table named many times per batch)
+  // (or whenever it is small, <= 64 MB per slot, so that a tuning can force that form on any table)
+  const size_t binned_bytes = tt_gather_pool_binned_workspace_bytes((int64_t)rows, e->cfg.D, e->cfg.max_S);
+  if (binned_bytes > e->k1_partial_bytes &&
+      (tt_k1_prefers_binned(e->cfg.V, e->cfg.D, (int64_t)rows, e->cfg.max_S) || binned_bytes <= (64u << 20)))
+    e->k1_partial_bytes = binned_bytes;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i)
     e->k1_partial[i] = e->k1_partial_bytes ? c.take<float>(e->k1_partial_bytes / sizeof(float)) : nullptr;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->k1_stream_ctl[i] = c.take<char>(tt_gather_pool_stream_workspace_bytes());
@@ -242,7 +252,7 @@ extern "C" int tt_engine_set_backward(tt_engine* e, int mode) {
 extern "C" int tt_engine_set_tuning(tt_engine* e, const tt_tuning* tuning) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   const tt_tuning t = tuning ? *tuning : tt_tuning{};
-  TT_REQUIRE(t.k1_form >= TT_K1_AUTO && t.k1_form <= TT_K1_STREAM, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(t.k1_form >= TT_K1_AUTO && t.k1_form <= TT_K1_BINNED, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(t.k1_stream_wgs >= 0 && t.k1_stream_wgs <= 8 && t.k1_share_lds_kb >= -1 && t.k1_share_lds_kb <= 160, TT_ERR_BAD_SHAPE);
   TT_REQUIRE(t.backward == TT_BWD_AUTO || t.backward == TT_BWD_FORK || t.backward == TT_BWD_FUSED, TT_ERR_BAD_SHAPE);
   for (int r : t.reserved) TT_REQUIRE(r == 0, TT_ERR_BAD_SHAPE);
@@ -309,8 +319,14 @@ static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, con
       !(tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]) &&
         (form == TT_K1_ROW_SLICES ? e->k1_partial_bytes >= rows_ws : (cols_ws != 0 && e->k1_partial_bytes >= cols_ws))))
     form = TT_K1_AUTO;
+  if (form == TT_K1_BINNED && !(tt_k1_binned_supported(S, e->cfg.D, e->table, e->pooled[slot]) &&
+                                e->k1_partial_bytes >= tt_gather_pool_binned_workspace_bytes(N, e->cfg.D, S)))
+    form = TT_K1_AUTO;
   if (form == TT_K1_AUTO) {
-    if (auto_share && tt_k1_prefers_stream(e->cfg.V, e->cfg.D, N, S) &&
+    if (tt_k1_prefers_binned(e->cfg.V, e->cfg.D, N, S) && tt_k1_binned_supported(S, e->cfg.D, e->table, e->pooled[slot]) &&
+        e->k1_partial_bytes >= tt_gather_pool_binned_workspace_bytes(N, e->cfg.D, S))
+      form = TT_K1_BINNED;  // a big table whose rows are named many times per batch: served from the XCDs' L2s
+    else if (auto_share && tt_k1_prefers_stream(e->cfg.V, e->cfg.D, N, S) &&
         tt_k1_stream_supported(e->cfg.D, e->table, e->pooled[slot]))
       form = TT_K1_STREAM;  // beside the projection chain when the table really comes from HBM (gather_pool.hip)
     else if (e->k1_partial_bytes >= rows_ws && tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, N, S) &&
@@ -320,7 +336,7 @@ static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, con
       form = TT_K1_PER_TEXT;
   }
   e->k1_streamed[slot] = form == TT_K1_STREAM;
-  e->stream_beside = form == TT_K1_STREAM;
+  e->stream_beside = form == TT_K1_STREAM || form == TT_K1_BINNED;  // the projection tiles that pair with a big table's gather
   // LDS a gather workgroup occupies while it shares the chip (0 = no reservation)
   unsigned lds_total = 0;
   if (e->shared)
@@ -339,6 +355,10 @@ static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, con
                                e->oob, e->k1_stream_ctl[slot], tt_gather_pool_stream_workspace_bytes(), per_cu, &e->tuning,
                                lds, st, text_rows, n_store);
   }
+  if (form == TT_K1_BINNED)
+    return tt_k1_binned_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], N, S, e->cfg.D, e->cfg.V,
+                               e->oob, e->k1_partial[slot], e->k1_partial_bytes, tn.k1_share_lds_kb != 0 ? lds_total : 0, st,
+                               text_rows, n_store);
   if (form == TT_K1_ROW_SLICES || form == TT_K1_COLUMN_SLICES) {
     if (e->shared && !e->tile_above && auto_share && tn.k1_share_lds_kb == 0) lds_total = tt_k1_lds_for_cap(3);
     return tt_k1_sliced_launch(e->table, ids, ids_dtype, mask, mask_dtype, lens, e->pooled[slot], N, S, e->cfg.D, e->cfg.V,

@@ -598,6 +598,189 @@ __global__ __launch_bounds__(kThreads) void pool_colnorm_kernel(float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Binned K1 (round 4): tables whose column slice no longer fits an L2 (V x 128 bytes > 13 MB) but whose rows are
+// named many times per launch (N x S >> V).  The column slices are cut once more, by row class c (bin_class: runs of
+// 64 rows dealt round-robin to 8 classes): block (c, slice) is 128 bytes of an eighth of the rows — V x 16 bytes, 4.0 MB
+// at V = 250 000 — and XCD c (workgroups with
+// blockIdx % 8 == c: a placement label, speed only) walks ITS blocks slice after slice, so the rows come out of that
+// XCD's L2 and every table line crosses the fabric about once per launch instead of once per token that names it.
+//   1. pool_bin_kernel: one wave per text sorts the text's live tokens by class (stable counting sort in registers:
+//      ballots), writes ids (and weights, with a mask) class by class + the 9 class offsets + the weight sum.
+//   2. pool_binned_kernel: one wave per (class, slice, 8 texts): lane = (text slot, 16-byte piece); a lane group walks
+//      ITS text's class list, 8 rows in flight per group (64 per wave), and owns its accumulator — no cross-lane
+//      reduction; stores the 128-byte partial of (class, text, slice).
+//   3. pool_bincombine_kernel: one wave per text adds the 8 class partials in class order, mean (clamp 1e-9),
+//      L2 norm (clamp 1e-12).
+// Same result as the other forms up to fp32 summation order (here: class-major); run-to-run bitwise reproducible.
+// Costs the partials: 8 x N x D floats written and read.
+constexpr int kBinClasses = 8;
+// Row class of a table row: runs of 64 rows dealt round-robin to the 8 classes.  (id % 8 — every eighth row — puts a
+// block's 128-byte lines at a stride of 8 rows = 24 KB at D = 768, which maps them onto a small fraction of the L2's
+// sets: measured 26 % L2 hits and 33.9 GB fetched per launch at BASELINE.json configs[3], nothing gained.  Runs keep
+// the stride between most of a block's lines at one row, like the column slices of a small table, and still spread a
+// skewed vocabulary — hot low ids — over all classes.)
+__device__ __forceinline__ int bin_class(int id) { return (id >> 6) & (kBinClasses - 1); }
+
+template <typename IdT, typename MaskT, int MAXSEG>
+__global__ __launch_bounds__(kThreads) void pool_bin_kernel(
+    const IdT* __restrict__ ids, const MaskT* __restrict__ mask, const int* __restrict__ lens,
+    int* __restrict__ ids_out, float* __restrict__ w_out, int* __restrict__ off_out, float* __restrict__ wsum_out,
+    long long N, int S, long long V, int* __restrict__ oob_flag, const int* __restrict__ text_rows, long long n_store) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const long long text = (long long)blockIdx.x * kWavesPerText + (threadIdx.x >> 6);
+  if (text >= N) return;  // wave-uniform; no barrier below
+  const long long st = text_rows ? store_row(text_rows[text], n_store, oob_flag) : text;
+  const int len = lens ? lens[st] : S;
+  const long long tb = st * (long long)S;
+  int idv[MAXSEG];
+  float wv[MAXSEG];
+  float wtot = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXSEG; ++k) {
+    const int tok = k * TT_WAVE + lane;
+    int id = 0;
+    float w = 0.f;
+    if (tok < S) {
+      w = mask ? static_cast<float>(mask[tb + tok]) : (tok < len ? 1.f : 0.f);
+      const long long raw = static_cast<long long>(ids[tb + tok]);
+      if (raw < 0 || raw >= V) {
+        if (w != 0.f && oob_flag) atomicOr(oob_flag, 1);
+        id = raw < 0 ? 0 : static_cast<int>(V - 1);
+      } else {
+        id = static_cast<int>(raw);
+      }
+    }
+    idv[k] = id;
+    wv[k] = w;
+    wtot += w;
+  }
+  const float wsum = tt_wave_sum(wtot);
+  const unsigned long long below = (1ULL << lane) - 1ULL;
+  int* __restrict__ io = ids_out + text * (long long)S;
+  float* __restrict__ wo = w_out ? w_out + text * (long long)S : nullptr;
+  int pos = 0;  // wave-uniform: tokens placed so far
+#pragma unroll
+  for (int c = 0; c < kBinClasses; ++c) {
+    if (lane == 0) off_out[text * (kBinClasses + 1) + c] = pos;
+#pragma unroll
+    for (int k = 0; k < MAXSEG; ++k) {
+      const bool mine = wv[k] != 0.f && bin_class(idv[k]) == c;
+      const unsigned long long m = __ballot(mine);
+      if (mine) {
+        const int p = pos + __popcll(m & below);
+        io[p] = idv[k];
+        if (wo) wo[p] = wv[k];
+      }
+      pos += __popcll(m);
+    }
+  }
+  if (lane == 0) {
+    off_out[text * (kBinClasses + 1) + kBinClasses] = pos;
+    wsum_out[text] = wsum;
+  }
+}
+
+template <bool WEIGHTED, int WPB>
+__global__ __launch_bounds__(WPB * TT_WAVE) void pool_binned_kernel(
+    const float* __restrict__ table, const int* __restrict__ ids_s, const float* __restrict__ w_s,
+    const int* __restrict__ off, float* __restrict__ partial, long long N, int S, int D, int NS, long long groups) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  const int cls = (int)(blockIdx.x & (kBinClasses - 1));
+  const long long j = (long long)(blockIdx.x >> 3) * WPB + wave;  // this wave's unit within its class, slice-major
+  if (j >= (long long)NS * groups) return;  // wave-uniform; no barrier below
+  const int slice = (int)(j / groups);
+  const long long grp = j - (long long)slice * groups;
+  const int piece = lane & 7, lead = lane & ~7;
+  const long long text = grp * 8 + (lane >> 3);
+  const bool valid = text < N;
+  int n = 0;
+  long long first = 0;
+  if (valid) {
+    const int a = off[text * (kBinClasses + 1) + cls];
+    n = off[text * (kBinClasses + 1) + cls + 1] - a;
+    first = text * (long long)S + a;
+  }
+  int nmax = n;  // wave-uniform trip count: the longest of the 8 lists
+#pragma unroll
+  for (int o = 8; o < TT_WAVE; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, TT_WAVE));
+  const float* __restrict__ col = table + slice * kColSliceFloats + piece * 4;
+  float4 acc = f4_zero();
+  // lane `piece` of a group holds token i0 + piece of the group's list; the next 8 are requested before these are used
+  int idc = 0;
+  float wc = 0.f;
+  if (piece < n) {
+    idc = __builtin_nontemporal_load(ids_s + first + piece);
+    if (WEIGHTED) wc = __builtin_nontemporal_load(w_s + first + piece);
+  }
+  for (int i0 = 0; i0 < nmax; i0 += 8) {
+    int idn = 0;
+    float wn = 0.f;
+    if (i0 + 8 + piece < n) {
+      idn = __builtin_nontemporal_load(ids_s + first + i0 + 8 + piece);
+      if (WEIGHTED) wn = __builtin_nontemporal_load(w_s + first + i0 + 8 + piece);
+    }
+    float4 r[8];
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int id = __shfl(idc, lead + u, TT_WAVE);
+      const float wu = WEIGHTED ? __shfl(wc, lead + u, TT_WAVE) : 1.f;
+      const bool live = i0 + u < n;
+      w[u] = live ? wu : 0.f;
+      r[u] = f4_zero();
+      if (live) r[u] = *reinterpret_cast<const float4*>(col + (long long)id * D);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f4_fma(acc, w[u], r[u]);
+    idc = idn;
+    wc = wn;
+  }
+  if (valid) {  // streamed past the L2 (non-temporal): the block this XCD keeps there is what must stay
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v; v.x = acc.x; v.y = acc.y; v.z = acc.z; v.w = acc.w;
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(partial + ((long long)cls * N + text) * D +
+                                                            slice * kColSliceFloats + piece * 4));
+  }
+}
+
+// One wave per text: the 8 class partials in class order, mean, L2 norm.  C = float4 chunks per lane.
+template <int C>
+__global__ __launch_bounds__(kThreads) void pool_bincombine_kernel(const float* __restrict__ partial,
+                                                                   const float* __restrict__ wsum,
+                                                                   float* __restrict__ out, long long N, int D) {
+  const int lane = threadIdx.x & (TT_WAVE - 1);
+  const long long text = (long long)blockIdx.x * kWavesPerText + (threadIdx.x >> 6);
+  if (text >= N) return;
+  const int nchunk = D >> 2;
+  const float den = fmaxf(wsum[text], 1e-9f);  // clamp(mask.sum(1), min=1e-9)
+  float4 m[C];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    m[c] = f4_zero();
+    const int chunk = c * TT_WAVE + lane;
+    if (chunk < nchunk) {
+      float4 a = f4_zero();
+#pragma unroll
+      for (int k = 0; k < kBinClasses; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(partial + ((long long)k * N + text) * D + chunk * 4);
+        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+      }
+      m[c] = make_float4(a.x / den, a.y / den, a.z / den, a.w / den);
+      ss = fmaf(m[c].x, m[c].x, fmaf(m[c].y, m[c].y, fmaf(m[c].z, m[c].z, fmaf(m[c].w, m[c].w, ss))));
+    }
+  }
+  const float dn = fmaxf(sqrtf(tt_wave_sum(ss)), 1e-12f);  // F.normalize eps
+  float4* __restrict__ row = reinterpret_cast<float4*>(out + text * (long long)D);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int chunk = c * TT_WAVE + lane;
+    if (chunk < nchunk) row[chunk] = make_float4(m[c].x / dn, m[c].y / dn, m[c].z / dn, m[c].w / dn);
+  }
+}
+
 // Any D (not a multiple of 4, or > 1024, or unaligned): correct, not fast.
 template <typename IdT, typename MaskT, bool DENSE>
 __global__ __launch_bounds__(kThreads) void pool_norm_generic_kernel(
@@ -829,6 +1012,57 @@ int launch_sliced(const float* table, const void* ids, const void* mask, const i
   return TT_OK;
 }
 
+// workspace of the binned form: partial [8][N][D] | ids [N][S] | weights [N][S] | offsets [N][9] | weight sums [N]
+static size_t binned_ws_floats(int64_t N, int D, int S) {
+  return (size_t)kBinClasses * N * D + 2 * (size_t)N * S + (size_t)N * (kBinClasses + 1) + (size_t)N;
+}
+static bool binned_supported(int D, int S) { return colsliced_supported(D, S); }
+
+template <typename IdT, typename MaskT>
+int launch_binned(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
+                  int S, int D, int64_t V, int32_t* oob, float* ws, unsigned lds_total, hipStream_t st,
+                  const int32_t* text_rows, int64_t n_store) {
+  const IdT* ids_t = static_cast<const IdT*>(ids);
+  const MaskT* mask_t = static_cast<const MaskT*>(mask);
+  float* partial = ws;
+  int* ids_s = reinterpret_cast<int*>(partial + (size_t)kBinClasses * N * D);
+  float* w_s = reinterpret_cast<float*>(ids_s + (size_t)N * S);
+  int* off = reinterpret_cast<int*>(w_s + (size_t)N * S);
+  float* wsum = reinterpret_cast<float*>(off + (size_t)N * (kBinClasses + 1));
+  const dim3 per_text((unsigned)((N + kWavesPerText - 1) / kWavesPerText)), block(kThreads);
+  const int nseg = (S + TT_WAVE - 1) / TT_WAVE;
+#define TT_BIN_LAUNCH(MS)                                                                                          \
+  hipLaunchKernelGGL((pool_bin_kernel<IdT, MaskT, MS>), per_text, block, 0, st, ids_t, mask_t, lens, ids_s,          \
+                     mask ? w_s : nullptr, off, wsum, (long long)N, S, (long long)V, oob, text_rows, (long long)n_store)
+  if (nseg <= 1) TT_BIN_LAUNCH(1);
+  else if (nseg <= 2) TT_BIN_LAUNCH(2);
+  else if (nseg <= 4) TT_BIN_LAUNCH(4);
+  else TT_BIN_LAUNCH(8);
+#undef TT_BIN_LAUNCH
+  TT_CHECK_LAUNCH();
+  constexpr int kBinWaves = 8;
+  const int NS = D / kColSliceFloats;
+  const long long groups = (N + 7) / 8;
+  const long long wgs = kBinClasses * (((long long)NS * groups + kBinWaves - 1) / kBinWaves);
+  if (wgs > 0x7fffffffLL) return TT_ERR_BAD_SHAPE;
+  if (mask)
+    hipLaunchKernelGGL((pool_binned_kernel<true, kBinWaves>), dim3((unsigned)wgs), dim3(kBinWaves * TT_WAVE), lds_total, st,
+                       table, ids_s, w_s, off, partial, (long long)N, S, D, NS, groups);
+  else
+    hipLaunchKernelGGL((pool_binned_kernel<false, kBinWaves>), dim3((unsigned)wgs), dim3(kBinWaves * TT_WAVE), lds_total, st,
+                       table, ids_s, w_s, off, partial, (long long)N, S, D, NS, groups);
+  TT_CHECK_LAUNCH();
+  const int C = (D / 4 + TT_WAVE - 1) / TT_WAVE;
+  switch (C) {
+    case 1: hipLaunchKernelGGL((pool_bincombine_kernel<1>), per_text, block, 0, st, partial, wsum, out, (long long)N, D); break;
+    case 2: hipLaunchKernelGGL((pool_bincombine_kernel<2>), per_text, block, 0, st, partial, wsum, out, (long long)N, D); break;
+    case 3: hipLaunchKernelGGL((pool_bincombine_kernel<3>), per_text, block, 0, st, partial, wsum, out, (long long)N, D); break;
+    default: hipLaunchKernelGGL((pool_bincombine_kernel<4>), per_text, block, 0, st, partial, wsum, out, (long long)N, D); break;
+  }
+  TT_CHECK_LAUNCH();
+  return TT_OK;
+}
+
 template <typename IdT, typename MaskT>
 int launch_stream(const float* table, const void* ids, const void* mask, const int32_t* lens, float* out, int64_t N,
                   int S, int D, int64_t V, int32_t* oob, void* ctl_ws, int per_cu, int rows, int offer,
@@ -990,6 +1224,56 @@ extern "C" int tt_gather_pool_norm_sliced_f32(const float* table, const void* id
                                               int form, tt_stream_t stream) {
   return tt_k1_sliced_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, workspace,
                              workspace_bytes, 0, form, static_cast<hipStream_t>(stream), nullptr, 0);
+}
+
+extern "C" size_t tt_gather_pool_binned_workspace_bytes(int64_t N, int D, int S) {
+  if (N <= 0 || D <= 0 || S <= 0 || !binned_supported(D, S)) return 0;
+  return binned_ws_floats(N, D, S) * sizeof(float);
+}
+
+// Shapes the binned form is the one to use for (a pure function of the shape; tt_engine_pool applies it by itself): a
+// column slice of the table is beyond what the column-sliced form handles (V x 128 bytes > 13 MB) and the launch names
+// every row several times over.  Measured at BASELINE.json configs[3] (V = 250 000, D = 768, 49 152 texts of 256 tokens):
+// 3.31 ms against the streaming form's 5.22 ms alone, 5.5 against 6.6 ms per training step (profiles/r04_binned_k1.txt).
+// (every row named >= 8 times per launch and texts long enough that the 8 class partials per text — 16 row-sized
+// transfers — are small beside the text's S rows)
+extern "C" int tt_k1_prefers_binned(int64_t V, int D, int64_t N, int S) {
+  return binned_supported(D, S) && !colsliced_applies(V, D, S) && S >= 64 && (double)N * S >= 8.0 * (double)V;
+}
+
+extern "C" int tt_k1_binned_supported(int S, int D, const float* table, const float* out) {
+  return binned_supported(D, S) && tt_aligned16(table) && tt_aligned16(out);
+}
+
+// internal (engine.hip) + public: the binned form.  Same contract as tt_gather_pool_norm_f32.
+int tt_k1_binned_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
+                        const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
+                        void* workspace, size_t workspace_bytes, unsigned lds_total, hipStream_t st,
+                        const int32_t* text_rows, int64_t n_store) {
+  TT_REQUIRE(table && ids && out && workspace, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(!text_rows || n_store >= 1, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(N >= 0 && S >= 1 && D >= 1 && V >= 1 && V <= 0x7fffffffLL && N <= 0x0fffffffLL, TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(ids_dtype == TT_I32 || ids_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  TT_REQUIRE(!mask || mask_dtype == TT_I32 || mask_dtype == TT_I64, TT_ERR_BAD_DTYPE);
+  TT_REQUIRE(tt_k1_binned_supported(S, D, table, out) && tt_aligned16(workspace), TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(workspace_bytes >= tt_gather_pool_binned_workspace_bytes(N, D, S), TT_ERR_WORKSPACE);
+  if (N == 0) return TT_OK;
+  float* ws = static_cast<float*>(workspace);
+  const int md = mask ? mask_dtype : TT_I32;
+#define TT_BINNED_ARGS table, ids, mask, lens, out, N, S, D, V, oob_flag, ws, lds_total, st, text_rows, n_store
+  if (ids_dtype == TT_I32 && md == TT_I32) return launch_binned<int32_t, int32_t>(TT_BINNED_ARGS);
+  if (ids_dtype == TT_I32 && md == TT_I64) return launch_binned<int32_t, int64_t>(TT_BINNED_ARGS);
+  if (ids_dtype == TT_I64 && md == TT_I32) return launch_binned<int64_t, int32_t>(TT_BINNED_ARGS);
+  return launch_binned<int64_t, int64_t>(TT_BINNED_ARGS);
+#undef TT_BINNED_ARGS
+}
+
+extern "C" int tt_gather_pool_norm_binned_f32(const float* table, const void* ids, int ids_dtype, const void* mask,
+                                              int mask_dtype, const int32_t* lens, float* out, int64_t N, int S, int D,
+                                              int64_t V, int32_t* oob_flag, void* workspace, size_t workspace_bytes,
+                                              tt_stream_t stream) {
+  return tt_k1_binned_launch(table, ids, ids_dtype, mask, mask_dtype, lens, out, N, S, D, V, oob_flag, workspace,
+                             workspace_bytes, 0, static_cast<hipStream_t>(stream), nullptr, 0);
 }
 
 extern "C" size_t tt_gather_pool_stream_workspace_bytes(void) { return sizeof(StreamCtl); }

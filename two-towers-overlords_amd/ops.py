@@ -114,13 +114,14 @@ def gather_pool_norm(
     and raises if any unmasked id was outside [0, V).  sliced: force the per-text (False) or the
     XCD-sliced (True, tt_gather_pool_norm_sliced_f32) form; None picks the faster one for the
     shape (tt_k1_prefers_sliced).  form: "rows" / "columns" picks the slicing of the sliced form (default: the
-    measured rule, tt_k1_sliced_form; either implies sliced=True), "per_text" = sliced=False.  Same result to fp32
+    measured rule, tt_k1_sliced_form; either implies sliced=True), "per_text" = sliced=False, "binned" = tokens sorted
+    by row class + column slices (tt_gather_pool_norm_binned_f32: big tables named many times per launch).  Same result to fp32
     summation order.  stream_form=n: the streaming form (tt_gather_pool_norm_stream_f32: persistent workgroups, at
     most n per compute unit; bitwise the per-text result; `tuning`: k1_stream_rows / _offer) — what the
     engine uses for tables that stream from HBM."""
     if form is not None:
-        if form not in ("per_text", "rows", "columns"):
-            raise ValueError("form: 'per_text', 'rows' or 'columns'")
+        if form not in ("per_text", "rows", "columns", "binned"):
+            raise ValueError("form: 'per_text', 'rows', 'columns' or 'binned'")
         sliced = form != "per_text"
     _req(table, "table", torch.float32, 2)
     _req(input_ids, "input_ids", ndim=2)
@@ -138,7 +139,14 @@ def gather_pool_norm(
             raise ValueError(f"out: expected {(N, D)}, got {tuple(out.shape)}")
     flag = torch.zeros(1, dtype=torch.int32, device=table.device) if check_ids else None
     with _on(table.device):
-        if stream_form:
+        if form == "binned":  # tokens sorted by row class + 32-column slices (tt_gather_pool_norm_binned_f32)
+            nbytes = int(_lib.load().tt_gather_pool_binned_workspace_bytes(N, D, S))
+            if nbytes == 0:
+                raise ValueError("form='binned' needs D % 32 == 0, D <= 1024, S <= 512")
+            ws = _scratch(table.device, nbytes)
+            call("tt_gather_pool_norm_binned_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw, _ptr(lens),
+                 out.data_ptr(), N, S, D, V, _ptr(flag), ws.data_ptr(), nbytes, _stream())
+        elif stream_form:
             nbytes = int(_lib.load().tt_gather_pool_stream_workspace_bytes())
             ws = _scratch(table.device, nbytes)  # queue head + per-CU registry; stream-ordered reuse
             call("tt_gather_pool_norm_stream_f32", table.data_ptr(), input_ids.data_ptr(), iw, _ptr(mask), mw,

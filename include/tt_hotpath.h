@@ -195,7 +195,8 @@ int tt_gather_pool_stream_census(const void* workspace, int32_t* admitted, int32
 size_t tt_gather_pool_binned_workspace_bytes(int64_t N, int D, int S);
 int tt_k1_binned_supported(int S, int D, const float* table, const float* out);
 /* 1 if the binned form is the one to use for this shape on MI355X (a pure function of the shape; tt_engine_pool applies
- * it by itself): a column slice of the table beyond 13 MB, texts of >= 64 tokens, every row named >= 8 times per launch */
+ * it by itself): a column slice of the table beyond 13 MB but a class block (V x 16 bytes) within 4.5 MB, texts of >= 64
+ * tokens, every row named >= 8 times per launch */
 int tt_k1_prefers_binned(int64_t V, int D, int64_t N, int S);
 int tt_gather_pool_norm_binned_f32(const float* table, const void* ids, int ids_dtype,
                                    const void* mask, int mask_dtype, const int32_t* lens,

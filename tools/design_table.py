@@ -39,7 +39,8 @@ rows = [
     ("`--path module-unfused`: the same call with `fused=False` (autograd Functions, module by module)", "r04_bench_c2_module_unfused.json"),
     ("`--path module` at the driver's 20 steps / 5 warm-up (a 20-batch epoch)", "r04_bench_c2_module_path_k20.json"),
     ("configs[2], one GPU's share (B = 1024 of 8192, P = 512)", "r04_bench_c3_share.json"),
-    ("**configs[3]** (V = 250k, D = P = 768, S = 256, B = 16384; streaming K1)", "r04_bench_c4_full.json"),
+    ("**configs[3]** (V = 250k, D = P = 768, S = 256, B = 16384; binned K1)", "r04_bench_c4_full.json"),
+    ("configs[3] with the streaming K1 (`--tune k1_form=stream`: rounds 3's form, same box)", "r04_bench_c4_stream_form.json"),
     ("configs[3] one stream `--no-overlap`", "r04_bench_c4_no_overlap.json"),
     ("configs[3] negatives by index", "r04_bench_c4_inputs_index.json"),
     ("in-batch negatives B = 4096 (queries/s)", "r04_bench_inbatch_b4096.json"),

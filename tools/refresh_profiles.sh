@@ -21,6 +21,7 @@ $B --loss inbatch --batch 4096 > $out/${r}_bench_inbatch_b4096.json
 $B --loss inbatch --batch 512 > $out/${r}_bench_inbatch_b512_share.json
 $B --config c3 > $out/${r}_bench_c3_share.json
 $B --config c4 --steps 40 --warmup 8 > $out/${r}_bench_c4_full.json
+$B --config c4 --steps 40 --warmup 8 --tune k1_form=stream > $out/${r}_bench_c4_stream_form.json
 $B --config c4 --steps 20 --warmup 4 --no-overlap > $out/${r}_bench_c4_no_overlap.json
 $B --config c4 --steps 12 --warmup 4 --inputs index > $out/${r}_bench_c4_inputs_index.json
 echo "benches done"
@@ -60,11 +61,12 @@ mfma c3 "configs[2] one GPU's share B=1024 P=512 (one stream)" --config c3 --ste
 mfma c4bk16 "configs[3] with the tiles used beside the streaming gather (K-step 16, 128x128 TN, XCD order)" --config c4 --steps 6 --warmup 2 --tune proj_tile=22 --tune proj_bk=16 --tune tn_tile=22 --tune xcd_order=1
 cat $out/${r}_k2_mfma_util.txt
 # K1 fabric-side traffic: FETCH_SIZE / WRITE_SIZE in separate passes of bench.py --k1-only
-traffic() { cfg=$1; alg=$2; kern=$3; shift 3
+traffic() { cfg=$1; alg=$2; kern=$3; tag=$4; shift 4
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$cfg -o f -- python3 $root/bench.py --config $cfg --k1-only --no-cpu-baseline --no-secondary --steps 8 --warmup 2 "$@" > /dev/null 2>&1 || return 1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$cfg -o w -- python3 $root/bench.py --config $cfg --k1-only --no-cpu-baseline --no-secondary --steps 8 --warmup 2 "$@" > /dev/null 2>&1 || return 1
-  python3 $root/tools/pmc_traffic.py $out/pmc_fetch_$cfg $out/pmc_write_$cfg $out/${r}_k1_traffic_$cfg.json $alg $kern
+  python3 $root/tools/pmc_traffic.py $out/pmc_fetch_$cfg $out/pmc_write_$cfg $out/${r}_k1_traffic_$tag.json $alg $kern
   rm -rf $out/pmc_fetch_$cfg $out/pmc_write_$cfg; }
-traffic c2 1220542464 pool_colsliced_kernel,pool_colnorm_kernel
-traffic c4 38856032256 pool_norm_stream_kernel --tune k1_form=stream
+traffic c2 1220542464 pool_colsliced_kernel,pool_colnorm_kernel c2
+traffic c4 38856032256 pool_binned_kernel,pool_bincombine_kernel,pool_bin_kernel c4
+traffic c4 38856032256 pool_norm_stream_kernel c4_stream --tune k1_form=stream
 echo refreshed

@@ -8,6 +8,9 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 def short(n):
     tail = n.split("gemm_f32")[-1]
+    if "pool_binned" in n: return "K1 gather (binned)"
+    if "pool_bincombine" in n: return "K1 combine (binned)"
+    if "pool_bin_kernel" in n: return "K1 sort by class"
     if "pool_colsliced" in n: return "K1 gather (columns)"
     if "pool_colnorm" in n: return "K1 norm"
     if "pool_sliced" in n: return "K1 gather (rows)"

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(kThreads) void pool_colnorm_kernel(float* __restric
 // XCD's L2 and every table line crosses the fabric about once per launch instead of once per token that names it.
 //   1. pool_bin_kernel: one wave per text sorts the text's live tokens by class (stable counting sort in registers:
 //      ballots), writes ids (and weights, with a mask) class by class + the 9 class offsets + the weight sum.
-//   2. pool_binned_kernel: one wave per (class, slice, 8 texts): lane = (text slot, 16-byte piece); a lane group walks
+//   2. pool_binned_kernel (4-wave workgroups): one wave per (class, slice, 8 texts): lane = (text slot, 16-byte piece); a lane group walks
 //      ITS text's class list, 8 rows in flight per group (64 per wave), and owns its accumulator — no cross-lane
 //      reduction; stores the 128-byte partial of (class, text, slice).
 //   3. pool_bincombine_kernel: one wave per text adds the 8 class partials in class order, mean (clamp 1e-9),
@@ -1040,9 +1040,13 @@ int launch_binned(const float* table, const void* ids, const void* mask, const i
   else TT_BIN_LAUNCH(8);
 #undef TT_BIN_LAUNCH
   TT_CHECK_LAUNCH();
-  constexpr int kBinWaves = 8;
   const int NS = D / kColSliceFloats;
   const long long groups = (N + 7) / 8;
+  // 4-wave workgroups, 8 rows in flight per lane group.  Beside the projection chain (BASELINE.json configs[3]) the step is
+  // the same 5.5 ms for 4- and 8-wave workgroups and 2 / 4 / 8 rows in flight — the two streams share the L2 nearly one for
+  // one — but the small workgroups fit the holes the 128x128 tiles leave and the gather itself takes 4.3 instead of 5.1 ms
+  // of that step (profiles/r04_binned_k1.txt).
+  constexpr int kBinWaves = 4;
   const long long wgs = kBinClasses * (((long long)NS * groups + kBinWaves - 1) / kBinWaves);
   if (wgs > 0x7fffffffLL) return TT_ERR_BAD_SHAPE;
   if (mask)
@@ -1238,7 +1242,9 @@ extern "C" size_t tt_gather_pool_binned_workspace_bytes(int64_t N, int D, int S)
 // (every row named >= 8 times per launch and texts long enough that the 8 class partials per text — 16 row-sized
 // transfers — are small beside the text's S rows)
 extern "C" int tt_k1_prefers_binned(int64_t V, int D, int64_t N, int S) {
-  return binned_supported(D, S) && !colsliced_applies(V, D, S) && S >= 64 && (double)N * S >= 8.0 * (double)V;
+  // (a class block, V x 16 bytes, must still fit an XCD's 4 MiB L2: measured at 4.0 MB; beyond ~4.5 MB the table streams)
+  return binned_supported(D, S) && !colsliced_applies(V, D, S) && (double)V * 16.0 <= 4.5e6 && S >= 64 &&
+         (double)N * S >= 8.0 * (double)V;
 }
 
 extern "C" int tt_k1_binned_supported(int S, int D, const float* table, const float* out) {

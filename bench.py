@@ -27,7 +27,7 @@ reference loop — on a bounded sample of the same workload, `embed` mode),
 `cpu_baseline_bert` (the same loop with the frozen MiniLM-L6-shaped encoder the
 reference actually executes, backend/model.py:51-52) and `secondary` (the same
 measurement at BASELINE.json configs[3], the one configuration whose table
-streams from HBM) — the last three on rank 0 at N=1 only.
+cannot be cache-resident) — the last three on rank 0 at N=1 only.
 
 `--gpus N` with N > 1 from a plain shell starts itself under
 `python -m torch.distributed.run` (one rank per GPU) as a child process, before
@@ -240,7 +240,7 @@ def main():
                          "path with several ranks sharing one GPU)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object (the same measurement at configs[3], V=250k d=768 S=256 B=16384: "
-                         "the one configuration whose table streams from HBM; ~10 s extra on the default run)")
+                         "the one configuration whose table cannot be cache-resident; ~10 s extra on the default run)")
     ap.add_argument("--path", default="engine", choices=["engine", "module", "module-unfused"],
                     help="engine (headline): TripletTrainer on the fused engine.  module: the drop-in surface a user of the "
                          "reference gets by swapping the imports (INTEGRATION.md section 1) — training.train_epoch(model, "
@@ -716,7 +716,7 @@ def run_config(args, world, rank, device) -> dict:
         "roofline": {"kernel": k1_label, "bound": "hbm",
                      "bound_note": ("nominal: the 8 TB/s HBM figure the metric names; this table (%.0f MB) is cache-resident, "
                                     "so the bound that binds is the L2 / Infinity-Cache hierarchy — see `secondary` for the "
-                                    "configuration that streams from HBM" % (V * D * 4 / 1e6)) if V * D * 4 <= 200e6 else
+                                    "configuration whose table (768 MB) cannot be cache-resident" % (V * D * 4 / 1e6)) if V * D * 4 <= 200e6 else
                                    ("nominal: the 8 TB/s HBM figure the metric names; the table (%.0f MB) exceeds the 256 MiB "
                                     "Infinity Cache, but the binned form gathers it block by block out of the XCDs' L2s — a "
                                     "table line crosses the fabric about once per launch however many tokens name it "

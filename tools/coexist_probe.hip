@@ -1,0 +1,208 @@
+// What do an MFMA-bound kernel and an L2-bound gather cost each other when they share the chip?  (diagnostic, not part of
+// the product; DESIGN.md section 8 "Round 4")
+//
+//   kernel M: every wave runs a chain of v_mfma_f32_32x32x2_f32 on registers only (4 independent accumulators) — no
+//             memory traffic at all, `mw` waves per SIMD (one 4-wave workgroup per wave-per-SIMD), optionally holding
+//             `lds_kb` of LDS so that fewer fit a CU;
+//   kernel G: every wave gathers random 128-byte lines from a 3 MB region per XCD (L2-resident after the first touch),
+//             8 lines in flight per 8-lane group (64 per wave), like the product's sliced gathers; `gw` 4-wave
+//             workgroups per CU.
+// Each alone, then both on two streams; prints the times and the sum of the two speeds (alone time / together time).
+//   hipcc -O3 --offload-arch=gfx950 tools/coexist_probe.hip -o /tmp/coexist_probe && /tmp/coexist_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                  \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));   \
+      exit(1);                                                                    \
+    }                                                                             \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// GAP > 0: s_sleep GAP (64 x GAP cycles) after every four MFMAs (4 x 64 cycles of matrix-core time): the matrix core is busy
+// 4 / (4 + GAP) of the time
+template <int GAP>
+__global__ __launch_bounds__(256) void mfma_kernel(float* __restrict__ out, int iters) {
+  extern __shared__ float pad[];  // occupancy control only
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    if (GAP > 0) __builtin_amdgcn_s_sleep(GAP);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s + pad[0];  // never true: keeps the chain alive
+}
+
+// region of XCD x (workgroups with blockIdx % 8 == x): lines [x * lines_per_xcd, (x + 1) * lines_per_xcd)
+template <int PRIO>
+__global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ buf, unsigned lines_per_xcd, int iters,
+                                                     float4* __restrict__ out) {
+  if (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
+  const unsigned lane = threadIdx.x & 63, piece = lane & 7, grp = (blockIdx.x * 256 + threadIdx.x) >> 3;
+  const float4* __restrict__ base = buf + (size_t)(blockIdx.x & 7) * lines_per_xcd * 8 + piece;
+  unsigned h = grp * 2654435761u + 12345u;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int it = 0; it < iters; ++it) {
+    float4 r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      h = h * 1664525u + 1013904223u;
+      const unsigned line = (h >> 8) % lines_per_xcd;
+      r[u] = base[(size_t)line * 8];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += r[u].x; acc.y += r[u].y; acc.z += r[u].z; acc.w += r[u].w; }
+  }
+  if (acc.x == 12345.678f) out[grp] = acc;
+}
+
+int main() {
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  const unsigned lines_per_xcd = 3u * 1024 * 1024 / 128;  // 3 MB per XCD
+  float4* buf;
+  CHECK(hipMalloc(&buf, (size_t)8 * lines_per_xcd * 128));
+  CHECK(hipMemset(buf, 0, (size_t)8 * lines_per_xcd * 128));
+  float* out;
+  CHECK(hipMalloc(&out, 64u << 20));
+  hipStream_t sm, sg;
+  CHECK(hipStreamCreate(&sm));
+  CHECK(hipStreamCreate(&sg));
+  hipEvent_t e0, e1, f0, f1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&f0)); CHECK(hipEventCreate(&f1));
+
+  // work sized so that each kernel alone takes ~2 ms: M: waves x iters x 4 MFMAs x 64 cycles; G: bytes / ~12 TB/s
+  const int m_total_iters = 18000;        // per SIMD, split over the waves that share it
+  const long long g_total_iters = 3200;   // per 4-wave workgroup at 2 workgroups per CU; scaled with the workgroup count
+  int m_gap = 0;
+  auto run_m = [&](int mw, int lds_kb, hipStream_t st) {
+    if (m_gap == 4)
+      hipLaunchKernelGGL(mfma_kernel<4>, dim3(cus * mw), dim3(256), (size_t)lds_kb * 1024, st, out, m_total_iters / mw / 2);
+    else if (m_gap == 12)
+      hipLaunchKernelGGL(mfma_kernel<12>, dim3(cus * mw), dim3(256), (size_t)lds_kb * 1024, st, out, m_total_iters / mw / 4);
+    else
+      hipLaunchKernelGGL(mfma_kernel<0>, dim3(cus * mw), dim3(256), (size_t)lds_kb * 1024, st, out, m_total_iters / mw);
+  };
+  int g_prio = 0;
+  auto run_g = [&](int gw, hipStream_t st) {
+    if (g_prio)
+      hipLaunchKernelGGL(gather_kernel<3>, dim3(cus * gw), dim3(256), 0, st, buf, lines_per_xcd, (int)(g_total_iters * 2 / gw),
+                         reinterpret_cast<float4*>(out) + (8u << 20) / 16);
+    else
+      hipLaunchKernelGGL(gather_kernel<0>, dim3(cus * gw), dim3(256), 0, st, buf, lines_per_xcd, (int)(g_total_iters * 2 / gw),
+                         reinterpret_cast<float4*>(out) + (8u << 20) / 16);
+  };
+  auto time_alone = [&](auto&& fn, hipStream_t st) {
+    fn(st);  // warm-up (and L2 fill for the gather)
+    CHECK(hipStreamSynchronize(st));
+    float best = 1e9f;
+    for (int r = 0; r < 3; ++r) {
+      CHECK(hipEventRecord(e0, st));
+      fn(st);
+      CHECK(hipEventRecord(e1, st));
+      CHECK(hipEventSynchronize(e1));
+      float ms;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      best = ms < best ? ms : best;
+    }
+    return best;
+  };
+  printf("# %d CUs; M = MFMA chain on registers (mw waves per SIMD, lds KB per workgroup), G = L2 gather (gw 4-wave workgroups per CU)\n", cus);
+  printf("# %3s %4s %3s | %8s %8s | %8s %8s | %s\n", "mw", "lds", "gw", "M alone", "G alone", "M both", "G both", "speed M + speed G");
+  const int mws[] = {1, 2};
+  const int ldss[] = {0};
+  const int gws[] = {2, 6};
+  for (int prio = 0; prio < 1; ++prio)
+  for (int mw : mws)
+    for (int lds : ldss) {
+      g_prio = prio;
+      if (mw == mws[0] && lds == ldss[0]) printf("# gather waves at s_setprio %d\n", prio ? 3 : 0);
+      if (lds && mw > 2) continue;  // 64 KB x 4 would not fit anyway
+      for (int gw : gws) {
+        const float ma = time_alone([&](hipStream_t st) { run_m(mw, lds, st); }, sm);
+        const float ga = time_alone([&](hipStream_t st) { run_g(gw, st); }, sg);
+        float mb = 1e9f, gb = 1e9f;
+        for (int r = 0; r < 3; ++r) {
+          CHECK(hipDeviceSynchronize());
+          CHECK(hipEventRecord(e0, sm));
+          run_m(mw, lds, sm);
+          CHECK(hipEventRecord(e1, sm));
+          CHECK(hipEventRecord(f0, sg));
+          run_g(gw, sg);
+          CHECK(hipEventRecord(f1, sg));
+          CHECK(hipDeviceSynchronize());
+          float a, b;
+          CHECK(hipEventElapsedTime(&a, e0, e1));
+          CHECK(hipEventElapsedTime(&b, f0, f1));
+          if (a + b < mb + gb) { mb = a; gb = b; }
+        }
+        // both kernels start together; the shorter one ran beside the other for its whole length, the longer one partly alone:
+        // speeds while overlapped, from the shorter kernel's point of view
+        const float t = mb < gb ? mb : gb;                       // overlapped interval
+        const float m_done = mb <= gb ? 1.f : (1.f - (mb - t) / ma);  // fraction of M's work done in it
+        const float g_done = gb <= mb ? 1.f : (1.f - (gb - t) / ga);
+        printf("  %3d %4d %3d | %8.3f %8.3f | %8.3f %8.3f | %.2f + %.2f = %.2f\n", mw, lds, gw, ma, ga, mb, gb,
+               m_done * ma / t, g_done * ga / t, (m_done * ma + g_done * ga) / t);
+        fflush(stdout);
+      }
+    }
+  g_prio = 0;
+  for (int gap : {4, 12}) {  // the matrix core busy 1/2 and 1/4 of the time (one MFMA wave per SIMD)
+    m_gap = gap;
+    const float ma = time_alone([&](hipStream_t st) { run_m(1, 0, st); }, sm);
+    const float ga = time_alone([&](hipStream_t st) { run_g(4, st); }, sg);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, sm)); run_m(1, 0, sm); CHECK(hipEventRecord(e1, sm));
+    CHECK(hipEventRecord(f0, sg)); run_g(4, sg); CHECK(hipEventRecord(f1, sg));
+    CHECK(hipDeviceSynchronize());
+    float a, b;
+    CHECK(hipEventElapsedTime(&a, e0, e1)); CHECK(hipEventElapsedTime(&b, f0, f1));
+    printf("# matrix core busy %d/%d of the time: M alone %.3f G alone %.3f | M both %.3f G both %.3f\n", 4, 4 + gap, ma, ga, a, b);
+  }
+  m_gap = 0;
+  // controls: (a) the same pair with G enqueued first; (b) two gathers on the two streams (do two streams' kernels share
+  // the chip at all?); (c) two half-occupancy MFMA kernels
+  {
+    const float ma = time_alone([&](hipStream_t st) { run_m(1, 0, st); }, sm);
+    const float ga = time_alone([&](hipStream_t st) { run_g(4, st); }, sg);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(f0, sg)); run_g(4, sg); CHECK(hipEventRecord(f1, sg));
+    CHECK(hipEventRecord(e0, sm)); run_m(1, 0, sm); CHECK(hipEventRecord(e1, sm));
+    CHECK(hipDeviceSynchronize());
+    float a, b;
+    CHECK(hipEventElapsedTime(&a, e0, e1)); CHECK(hipEventElapsedTime(&b, f0, f1));
+    printf("# G enqueued first: M alone %.3f G alone %.3f | M both %.3f G both %.3f\n", ma, ga, a, b);
+    const float g2 = time_alone([&](hipStream_t st) { run_g(2, st); }, sg);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(f0, sg)); run_g(2, sg); CHECK(hipEventRecord(f1, sg));
+    CHECK(hipEventRecord(e0, sm)); run_g(2, sm); CHECK(hipEventRecord(e1, sm));
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventElapsedTime(&a, e0, e1)); CHECK(hipEventElapsedTime(&b, f0, f1));
+    printf("# G(gw=2) + G(gw=2) on two streams: alone %.3f each | together %.3f and %.3f\n", g2, a, b);
+    const float m1 = time_alone([&](hipStream_t st) { run_m(1, 0, st); }, sm);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(f0, sg)); run_m(1, 0, sg); CHECK(hipEventRecord(f1, sg));
+    CHECK(hipEventRecord(e0, sm)); run_m(1, 0, sm); CHECK(hipEventRecord(e1, sm));
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventElapsedTime(&a, e0, e1)); CHECK(hipEventElapsedTime(&b, f0, f1));
+    printf("# M(mw=1) + M(mw=1) on two streams: alone %.3f each | together %.3f and %.3f\n", m1, a, b);
+  }
+  return 0;
+}

@@ -257,6 +257,9 @@ def main():
     ap.add_argument("--fence-at-loss", type=int, default=None, choices=[0, 1],
                     help="A/B: 1 = the gather stream's slot fence is the engine's loss / fork event, 0 = an event of its own at "
                          "the start of the step (TripletTrainer(fence_at_loss=...)); default: calibrate() decides")
+    ap.add_argument("--lib", default=None,
+                    help="diagnostic: load this build of libtt_hotpath.so instead of the in-tree one (same-box A/B of two builds "
+                         "through tools/ab_tune.py)")
     ap.add_argument("--join-carries-gather", type=int, default=1, choices=[0, 1],
                     help="A/B: 1 [default] = in the fork backward the engine's join also carries the wait for the next batch's "
                          "gather (one wait packet per step on the caller's stream), 0 = a wait of its own ahead of Adam")
@@ -274,6 +277,9 @@ def main():
         k, _, v = kv.partition("=")
         args.tuning[k] = v if not v.lstrip("-").isdigit() else int(v)
 
+    if args.lib:
+        from two_towers_overlords_amd import _lib as _ttl
+        _ttl.LIB_PATH = os.path.abspath(args.lib)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -302,7 +308,7 @@ def main():
         return
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
-                    and not args.vocab and not args.zipf and not args.ragged and not args.tuning and not args.dp_split
+                    and not args.vocab and not args.lib and not args.zipf and not args.ragged and not args.tuning and not args.dp_split
                     and args.fence_at_loss is None and not args.grad_slabs)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
     # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")

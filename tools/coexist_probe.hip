@@ -4,7 +4,7 @@
 //   kernel M: every wave runs a chain of v_mfma_f32_32x32x2_f32 on registers only (4 independent accumulators) — no
 //             memory traffic at all, `mw` waves per SIMD (one 4-wave workgroup per wave-per-SIMD), optionally holding
 //             `lds_kb` of LDS so that fewer fit a CU;
-//   kernel G: every wave gathers random 128-byte lines from a 3 MB region per XCD (L2-resident after the first touch),
+//   kernel G: every wave gathers random 128-byte lines from a 2 MB region per XCD (L2-resident after the first touch),
 //             8 lines in flight per 8-lane group (64 per wave), like the product's sliced gathers; `gw` 4-wave
 //             workgroups per CU.
 // Each alone, then both on two streams; prints the times and the sum of the two speeds (alone time / together time).
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       h = h * 1664525u + 1013904223u;
-      const unsigned line = (h >> 8) % lines_per_xcd;
+      const unsigned line = (h >> 8) & (lines_per_xcd - 1);
       r[u] = base[(size_t)line * 8];
     }
 #pragma unroll
@@ -72,11 +72,59 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ 
   if (acc.x == 12345.678f) out[grp] = acc;
 }
 
+// The same two kinds of work inside ONE wave: every iteration requests 8 lines per lane group, then issues MPI x 4 MFMAs,
+// then adds the lines — does the gather run in the matrix core's shadow when both belong to the same instruction stream?
+template <int MPI>
+__global__ __launch_bounds__(256) void fused_kernel(const float4* __restrict__ buf, unsigned lines_per_xcd, int iters,
+                                                    float4* __restrict__ out) {
+  const unsigned lane = threadIdx.x & 63, piece = lane & 7, grp = (blockIdx.x * 256 + threadIdx.x) >> 3;
+  const float4* __restrict__ base = buf + (size_t)(blockIdx.x & 7) * lines_per_xcd * 8 + piece;
+  unsigned h = grp * 2654435761u + 12345u;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x16 macc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) macc[i][e] = 0.f;
+  float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
+  // software-pipelined by hand: the lines of iteration it + 1 are requested, then this iteration's MFMAs are issued, then
+  // the lines requested one iteration ago are added — the requests are in flight for the whole MFMA block
+  float4 r[8], q[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    h = h * 1664525u + 1013904223u;
+    r[u] = base[(size_t)((h >> 8) & (lines_per_xcd - 1)) * 8];
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      h = h * 1664525u + 1013904223u;
+      q[u] = base[(size_t)((h >> 8) & (lines_per_xcd - 1)) * 8];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MPI; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) macc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, macc[i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += r[u].x; acc.y += r[u].y; acc.z += r[u].z; acc.w += r[u].w; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = q[u];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += macc[i][e];
+  if (acc.x + s == 12345.678f) out[grp] = acc;
+}
+
 int main() {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
-  const unsigned lines_per_xcd = 3u * 1024 * 1024 / 128;  // 3 MB per XCD
+  const unsigned lines_per_xcd = 2u * 1024 * 1024 / 128;  // 2 MB per XCD (a power of two: the line index is a mask, not a modulo)
   float4* buf;
   CHECK(hipMalloc(&buf, (size_t)8 * lines_per_xcd * 128));
   CHECK(hipMemset(buf, 0, (size_t)8 * lines_per_xcd * 128));
@@ -177,6 +225,20 @@ int main() {
     printf("# matrix core busy %d/%d of the time: M alone %.3f G alone %.3f | M both %.3f G both %.3f\n", 4, 4 + gap, ma, ga, a, b);
   }
   m_gap = 0;
+  {  // one instruction stream: 2 workgroups per CU (2 waves per SIMD), the gather's iteration count, MPI x 4 MFMAs per iteration
+    const int it = (int)g_total_iters;
+    auto t_fused = [&](auto kernel) {
+      return time_alone([&](hipStream_t st) {
+        hipLaunchKernelGGL(kernel, dim3(cus * 2), dim3(256), 0, st, buf, lines_per_xcd, it, reinterpret_cast<float4*>(out) + (8u << 20) / 16);
+      }, sg);
+    };
+    const float g_only = t_fused(fused_kernel<0>);
+    const float f2 = t_fused(fused_kernel<2>), f4 = t_fused(fused_kernel<4>), f8 = t_fused(fused_kernel<8>);
+    // MFMA time of the same counts alone: 2 waves per SIMD x it x MPI x 4 MFMAs x 64 cycles
+    printf("# one instruction stream (2 waves per SIMD, %d iterations of 8 lines per lane group): gather only %.3f ms; with 8 / 16 / 32 MFMAs per "
+           "iteration %.3f / %.3f / %.3f ms (their MFMAs alone: %.3f / %.3f / %.3f ms at 64 cycles each)\n", it, g_only, f2, f4, f8,
+           2.0 * it * 8 * 64 / 2.4e6, 2.0 * it * 16 * 64 / 2.4e6, 2.0 * it * 32 * 64 / 2.4e6);
+  }
   // controls: (a) the same pair with G enqueued first; (b) two gathers on the two streams (do two streams' kernels share
   // the chip at all?); (c) two half-occupancy MFMA kernels
   {

@@ -66,6 +66,32 @@ def k1_algorithmic_bytes(n_texts, S, D):
     return n_texts * (S * D * 4 + S * 4 + D * 4)
 
 
+def k2_mfma_util(config):
+    """MFMA utilisation of the projection GEMMs (K2) at this configuration from the newest committed PMC summary
+    (profiles/rNN_k2_mfma_util.txt: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE per kernel, one-stream runs — counters are
+    not collected in a timed run).  The second bound the step lives under: exact-fp32 MFMA, 157.3 TFLOP/s."""
+    import glob
+    import re
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_k2_mfma_util.txt")))
+    if not paths:
+        return None
+    want = {"c2": "configs[1] B=2048", "c3": "configs[2] one GPU", "c4": "configs[3]"}.get(config)
+    kernels, on = {}, False
+    for line in open(paths[-1]):
+        if line.startswith("=="):
+            on = want is not None and want in line and "fork" not in line
+            continue
+        m = re.match(r"\s*(gemm\S+(?:, [^>]*)*>?)\s+mfma_util\s+([0-9.]+)", line)
+        if on and m:
+            kernels[m.group(1).strip()] = float(m.group(2))
+    if not kernels:
+        return None
+    return {"bound": "mfma", "peak": 157.3, "unit": "TFLOP/s", "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)",
+            "mfma_util": kernels, "mfma_util_min": min(kernels.values()), "mfma_util_max": max(kernels.values()),
+            "source": os.path.relpath(paths[-1], ROOT) + ": rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, one stream"}
+
+
 def make_ids(V, B, S, n_batches, seed, device, zipf=False):
     g = torch.Generator().manual_seed(seed)
     out = []
@@ -265,8 +291,15 @@ def main():
                          "gather (one wait packet per step on the caller's stream), 0 = a wait of its own ahead of Adam")
     ap.add_argument("--grad-slabs", type=int, default=0,
                     help="split-K slabs of the weight-gradient GEMMs (tt_engine_config.grad_slabs; 0 = the engine's choice)")
-    ap.add_argument("--dp-split", action="store_true",
-                    help="data-parallel step with the exchange in two parts (TripletTrainer(split_exchange=True))")
+    ap.add_argument("--dp-split", default=None, choices=["0", "1", "auto"],
+                    help="gradient exchange in one bucket (0), two parts (1: TripletTrainer(split_exchange=True)), or auto: "
+                         "calibrate() times the data-parallel step both ways on the fabric at hand and keeps the faster "
+                         "(default: auto with N > 1 ranks, 0 for the one-GPU stand-in)")
+    ap.add_argument("--rendezvous-timeout", type=float, default=180.0,
+                    help="N > 1: seconds allowed for init_process_group and for the first collective before the rank prints its "
+                         "state and exits non-zero")
+    ap.add_argument("--trace-steps", type=int, default=24,
+                    help="steps of the separate, event-traced pass behind the timed region that `dp_breakdown` is computed from")
     ap.add_argument("--no-cpu-baseline-bert", action="store_true",
                     help="skip `cpu_baseline_bert` (the reference's executed CPU path: frozen MiniLM-shaped encoder, ~10 s)")
     args = ap.parse_args()
@@ -296,10 +329,19 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+
+        to = datetime.timedelta(seconds=args.rendezvous_timeout)
+        with watchdog(args.rendezvous_timeout + 30, "init_process_group", rank):
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=to)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=to)
+        with watchdog(args.rendezvous_timeout + 30, "first collective (all_reduce of one float)", rank):
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize(device)
+            assert int(probe.item()) == world
 
     if args.path != "engine":
         if world > 1:
@@ -308,7 +350,7 @@ def main():
         return
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
-                    and not args.vocab and not args.lib and not args.zipf and not args.ragged and not args.tuning and not args.dp_split
+                    and not args.vocab and not args.lib and not args.zipf and not args.ragged and not args.tuning and args.dp_split is None
                     and args.fence_at_loss is None and not args.grad_slabs)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
     # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")
@@ -339,6 +381,33 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+class watchdog:
+    """A bounded wait for a step that can hang when a peer is missing (rendezvous, the first collective): if the body has
+    not finished after `seconds`, print this rank's state and leave with a non-zero code — from a timer thread, by
+    os._exit: nothing is exec'ed and no process is replaced, the launcher sees a failed child and tears the others down."""
+
+    def __init__(self, seconds: float, what: str, rank: int):
+        import threading
+
+        def fire():
+            print(f"bench.py rank {rank}: '{what}' did not finish within {seconds:.0f} s — MASTER_ADDR="
+                  f"{os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} WORLD_SIZE="
+                  f"{os.environ.get('WORLD_SIZE')} LOCAL_RANK={os.environ.get('LOCAL_RANK')} "
+                  f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}; giving up", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        self.t = threading.Timer(seconds, fire)
+        self.t.daemon = True
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
 
 
 def self_launch(args) -> int:
@@ -439,6 +508,23 @@ def secondary_c4(args, world, rank, device) -> dict:
     return out
 
 
+def breakdown(trace):
+    """Per-step averages (ms) from TripletTrainer.step_trace: chain = forward + loss + backward (+ slab reduce), exchange,
+    adam, and `other` = what is left of the step (stream idle between Adam and the next step's first kernel: event
+    waits, host gaps) — so the four sum to `traced_ms_per_step` by construction."""
+    rows = [t for t in trace if all(e is not None for e in t)]
+    if len(rows) < 3:
+        return None
+    rows = rows[1:]  # the first traced step still runs behind untraced ones
+    n = len(rows) - 1
+    chain = sum(rows[i][0].elapsed_time(rows[i][1]) for i in range(n)) / n
+    exch = sum(rows[i][1].elapsed_time(rows[i][2]) for i in range(n)) / n
+    adam = sum(rows[i][2].elapsed_time(rows[i][3]) for i in range(n)) / n
+    step = sum(rows[i][0].elapsed_time(rows[i + 1][0]) for i in range(n)) / n
+    return {"chain_ms": chain, "exchange_ms": exch, "adam_ms": adam, "other_ms": step - chain - exch - adam,
+            "traced_ms_per_step": step, "steps": n}
+
+
 def run_config(args, world, rank, device) -> dict:
     """Set-up, warm-up, K timed steady-state steps and the result object for one configuration."""
     n_distinct = getattr(args, "n_distinct", 8)
@@ -476,14 +562,16 @@ def run_config(args, world, rank, device) -> dict:
                 if self._cycles > 0:
                     torch.cuda._sleep(self._cycles)
 
-            def _all_reduce_parts(self, parts):  # --dp-split: each part costs a whole exchange (latency-bound sizes)
+            def _all_reduce_parts(self, parts, bucket=None):  # --dp-split: each part costs a whole exchange (latency-bound sizes)
                 if self._cycles > 0:
                     torch.cuda._sleep(self._cycles)
 
     trainer = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
                              overlap_streams=(False if (args.no_overlap or args.k1_only) else None),
                              k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss,
-                             tuning=(args.tuning or None), split_exchange=bool(args.dp_split),
+                             tuning=(args.tuning or None),
+                             split_exchange=({"0": False, "1": True, "auto": None}[args.dp_split] if args.dp_split is not None
+                                             else (None if world > 1 else False)),
                              fence_at_loss=(None if args.fence_at_loss is None else bool(args.fence_at_loss)),
                              grad_slabs=args.grad_slabs, join_carries_gather=bool(args.join_carries_gather))
     if trainer.use_graphs:
@@ -606,6 +694,7 @@ def run_config(args, world, rank, device) -> dict:
     if trainer.calibration:
         combos = len(trainer.calibration.get("ms_per_step_by_fence") or (0, 0))  # backward schedules x fence placements timed
         set_up_steps += combos * trainer.calibration["rounds"] * (trainer.calibration["steps"] + depth)  # dry fwd+bwd (no optimizer)
+    dp_breakdown = None
     if args.e2e:
         elapsed, e2e_info = run_e2e(args, trainer, cfg, device, rank, world, barrier)
         host_issue = elapsed
@@ -626,6 +715,14 @@ def run_config(args, world, rank, device) -> dict:
         host_issue = time.perf_counter() - t0  # all K steps enqueued (no device sync inside the loop)
         barrier()
         elapsed = time.perf_counter() - t0
+        if not args.k1_only and args.trace_steps > 1 and args.loss == "triplet" and not trainer.use_graphs:
+            # a separate short pass: every step carries four timing events on the caller's stream (each a packet on the
+            # critical chain), so its steps are a few us longer than the timed region's — reported beside them
+            trainer.step_trace = []
+            run(args.trace_steps, timed=False)
+            torch.cuda.synchronize(device)
+            tr_ev, trainer.step_trace = trainer.step_trace, None
+            dp_breakdown = breakdown(tr_ev)
         drain()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -694,6 +791,41 @@ def run_config(args, world, rank, device) -> dict:
     if args.e2e:
         metric = (f"triplets/sec, one whole epoch of {args.steps} batches through TokenTripletLoader(sampler=device) + "
                   f"TripletTrainer.train_epoch, inputs={args.inputs} (end-to-end loop; NOT the BASELINE metric)")
+    # The bound that BINDS the gather: HBM where the table streams from it; where the table is cache-resident (or the binned
+    # form gathers a big table block by block out of the XCDs' L2s) the rate at which rows shared by all workgroups come out
+    # of the L2s (MI355X_MICROARCH.md, "Indexed rows: gather into LDS": 66-73 GB/s per CU = 16.8-18.8 TB/s; `peak` is the
+    # upper figure, so `frac` is the conservative one).  The 8 TB/s HBM figure BASELINE.json's metric names stays in the
+    # line as `nominal_hbm`: against a cache-resident table it is not a bound (its fraction can exceed 1).
+    cache_resident = V * D * 4 <= 200e6
+    l2_bound = cache_resident or binned
+    achieved_alone = alg / (iso_ms * 1e-3) / 1e9
+    peak = L2_SHARED_ROWS_GBS[1] if l2_bound else HBM_PEAK_GBS
+    roofline = {
+        "kernel": k1_label, "bound": "l2_shared_rows" if l2_bound else "hbm",
+        "bound_note": ("the table (%.0f MB) is cache-resident: rows shared by every workgroup come out of the XCDs' L2s; the "
+                       "HBM figure the metric names is `nominal_hbm`" % (V * D * 4 / 1e6)) if cache_resident else
+                      ("the table (%.0f MB) exceeds the 256 MiB Infinity Cache, but the binned form gathers it block by block "
+                       "out of the XCDs' L2s — a table line crosses the fabric about once per launch however many tokens "
+                       "name it (`traffic`) — so the bound that binds is the L2s' shared-row rate" % (V * D * 4 / 1e6)) if binned else
+                      "the table (%.0f MB) exceeds the 256 MiB Infinity Cache and streams from HBM" % (V * D * 4 / 1e6),
+        "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+        "peak_range": list(L2_SHARED_ROWS_GBS) if l2_bound else None,
+        "peak_source": ("MI355X_MICROARCH.md, 'Indexed rows: gather into LDS': 66-73 GB/s per CU x 256 CUs" if l2_bound else
+                        "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)"),
+        "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
+        "launches_timed": len(k1_ev),
+        "note": "timed inside the step loop (HIP events on the gather's stream); with gather_overlap the launch shares the "
+                "chip with the projection kernels of the previous batch, so it takes longer than alone.  `achieved` counts "
+                "algorithmic bytes (every row read, SURVEY.md section 8d); `traffic` is what crossed the L2s' fabric side",
+        "served_from": ("XCD L2 + Infinity Cache (the table fits the 256 MiB Infinity Cache)" if cache_resident else
+                        "XCD L2s, block by block (binned form; the table exceeds the Infinity Cache)" if binned
+                        else "HBM (the table exceeds the Infinity Cache)"),
+        "alone": {"avg_launch_ms": iso_ms, "achieved": achieved_alone, "frac": achieved_alone / peak},
+        "nominal_hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                        "alone_frac": achieved_alone / HBM_PEAK_GBS,
+                        "is_the_binding_bound": not l2_bound},
+        "k2": k2_mfma_util(args.config) if not (args.batch or args.vocab) else None,
+    }
     result = {
         "metric": metric,
         "value": args.steps * B * world / elapsed,
@@ -719,43 +851,28 @@ def run_config(args, world, rank, device) -> dict:
                                     "K steady-state steps (pipeline filled in warm-up, drained after)"),
                    "launch": "hipGraph replay (1 step per graph; every 8th step eager for K1 event timing)"
                    if trainer.use_graphs else "eager (kernel by kernel)"},
-        "roofline": {"kernel": k1_label, "bound": "hbm",
-                     "bound_note": ("nominal: the 8 TB/s HBM figure the metric names; this table (%.0f MB) is cache-resident, "
-                                    "so the bound that binds is the L2 / Infinity-Cache hierarchy — see `secondary` for the "
-                                    "configuration whose table (768 MB) cannot be cache-resident" % (V * D * 4 / 1e6)) if V * D * 4 <= 200e6 else
-                                   ("nominal: the 8 TB/s HBM figure the metric names; the table (%.0f MB) exceeds the 256 MiB "
-                                    "Infinity Cache, but the binned form gathers it block by block out of the XCDs' L2s — a "
-                                    "table line crosses the fabric about once per launch however many tokens name it "
-                                    "(`traffic`) — so `achieved` (every row read counted) can exceed the HBM peak; the bound "
-                                    "that binds is `binding`" % (V * D * 4 / 1e6)) if binned else
-                                   "binding: the table (%.0f MB) exceeds the 256 MiB Infinity Cache" % (V * D * 4 / 1e6),
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
-                     "launches_timed": len(k1_ev),
-                     "note": "timed inside the step loop; with gather_overlap the launch shares the chip with the "
-                             "projection kernels of the previous batch, so its duration is longer than alone.  "
-                             "`achieved` counts algorithmic bytes (every row read); a table that fits the 256 MiB Infinity "
-                             "Cache (c2: 47 MB) is served from cache, so achieved can exceed the HBM peak — `traffic` is "
-                             "what crossed the L2's fabric side",
-                     "served_from": ("XCD L2 + Infinity Cache (the table fits the 256 MiB Infinity Cache)"
-                                     if V * D * 4 <= 200e6 else
-                                     "XCD L2s, block by block (binned form; the table exceeds the Infinity Cache)" if binned
-                                     else "HBM (the table exceeds the Infinity Cache)"),
-                     "alone": {"avg_launch_ms": iso_ms, "achieved": alg / (iso_ms * 1e-3) / 1e9,
-                               "frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                     # the bound that BINDS: HBM where the table streams from it; for a cache-resident table the rate at
-                     # which rows shared by all workgroups come out of the XCDs' L2s (the guide's gather table)
-                     "binding": ({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                  "alone_frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                 if (V * D * 4 > 200e6 and not binned) else
-                                 {"bound": "l2_shared_rows", "peak": list(L2_SHARED_ROWS_GBS), "unit": "GB/s",
-                                  "source": "MI355X_MICROARCH.md, 'Indexed rows: gather into LDS': 66-73 GB/s per CU",
-                                  "frac": [achieved / L2_SHARED_ROWS_GBS[1], achieved / L2_SHARED_ROWS_GBS[0]],
-                                  "alone_frac": [alg / (iso_ms * 1e-3) / 1e9 / L2_SHARED_ROWS_GBS[1],
-                                                 alg / (iso_ms * 1e-3) / 1e9 / L2_SHARED_ROWS_GBS[0]]})},
+        "roofline": roofline,
         "avg_loss": loss_avg,
         "calibration": trainer.calibration,
     }
+    if dp_breakdown is not None:
+        dp_breakdown.update({
+            "timed_ms_per_step": elapsed / args.steps * 1e3,
+            "k1_in_loop_ms": k1_ms, "k1_alone_ms": iso_ms,
+            "k1_placement": ("under the exchange (issued right before it, side stream)" if trainer._exchange and trainer.side is not None
+                             else "beside the chain (side stream)" if trainer.side is not None else "same stream, ahead of the chain"),
+            "exchange": (None if not trainer._exchange else
+                         {"form": "two-part" if trainer._split else "one-bucket", "bucket_bytes": int(trainer.bucket.numel() * 4),
+                          "backend": (args.backend if world > 1 else "stand-in kernel" if sim else "none"),
+                          "rccl_ranks": (dist.get_world_size() if (world > 1 and args.backend == "nccl") else 0)}),
+            "note": "device events on the caller's stream, a separate traced pass of --trace-steps steps; chain + exchange + "
+                    "adam + other = traced_ms_per_step; the traced steps carry four event packets each, so they run a few "
+                    "us longer than the timed region's (timed_ms_per_step)"})
+        if world > 1:  # every rank's numbers travel to rank 0: the slowest chain / longest exchange is what the step waits for
+            allb = [None] * world
+            dist.all_gather_object(allb, {k: dp_breakdown[k] for k in ("chain_ms", "exchange_ms", "adam_ms", "other_ms", "traced_ms_per_step", "k1_in_loop_ms")})
+            dp_breakdown["per_rank"] = allb
+        result["dp_breakdown"] = dp_breakdown
     if args.inputs == "cache":  # no gather in the step: the K1 roofline does not apply
         result["roofline"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not getattr(args, "cpu_baseline_later", False):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 2
+#define TT_ABI_VERSION 3
 
 typedef void* tt_stream_t; /* hipStream_t */
 
@@ -406,6 +406,10 @@ typedef struct {
   int32_t grad_slabs; /* split-K slabs of the weight-gradient GEMMs (1..16; fixed for the handle's lifetime: the slab
                          workspace is sized by it); 0 = about 256 query rows per split, at least four where the batch
                          allows them (measured) */
+  int32_t k1_form;    /* TT_K1_* form a later tt_engine_set_tuning will force on this handle, or 0: the per-slot partial-sum
+                         workspace is sized for the forms the shape rule can pick by itself plus this one (ABI 3; before,
+                         every handle carried up to 64 MB per slot for forms nobody had asked for).  A tuning that forces a
+                         form whose workspace was not sized falls back to the shape rule. */
 } tt_engine_config;
 #define TT_K1_SHARE_AUTO (-1)
 
@@ -556,6 +560,12 @@ int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event);
  * finished with its pooled slot" gets that edge without an event packet of its own on the critical stream.
  */
 int tt_engine_set_loss_event(tt_engine* e, tt_event_t event);
+/*
+ * The fork backward always records the loss event (it IS its fork point).  The fused backward (one stream, no event of
+ * its own) records it only while `armed` != 0 — a caller that is not going to wait for it this step saves the packet
+ * on the critical chain (round-4 advisor finding).  Off after tt_engine_create.
+ */
+int tt_engine_arm_loss_event(tt_engine* e, int32_t armed);
 
 /*
  * One-shot: the NEXT tt_engine_fwd_bwd / tt_engine_backward, if it runs the fork backward, makes its second stream wait

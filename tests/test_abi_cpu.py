@@ -104,16 +104,24 @@ def test_k1_form_selection_and_workspace_rules(monkeypatch):
     assert f(16, 16, 4, None, 4, None, 16, 8, 128, 100, 1000, None, 16, 1 << 30, COLS, None) == -7   # no whole 32-column slices
     assert f(16, 16, 4, None, 4, None, 16, 8, 128, 384, 1000, None, 16, 1 << 30, _lib.TT_K1_STREAM, None) == -7  # not a slicing
 
-    def engine_bytes(V, D, share):
-        cfg = _lib.TTEngineConfig(V, D, 384, 2048, 128, 0, share)
+    def engine_bytes(V, D, share, forced=0, S=128):
+        cfg = _lib.TTEngineConfig(V, D, 384, 2048, S, 0, share, 0, forced)
         return lib.tt_engine_workspace_bytes(ctypes.byref(cfg))
 
     small, metric = engine_bytes(2000, 384, 0), engine_bytes(30522, 384, 0)
-    # three slots of partial sums where the sliced form can win (or they are small enough to let a tuning force it:
-    # 75.5 MB per slot at this batch is not, so the 3 MB table's engine goes without)
-    assert metric - small >= 3 * (ws(3 * 2048, 384) - 3 * 2048 * (384 // 32) * 4)  # (small keeps the column form's sums of squares)
+    # the per-slot partial sums are sized for what the shape rule can pick for THIS table plus the form the caller says a
+    # tuning will force (tt_engine_config.k1_form) — not for every form "in case" (round-4 advisor finding: ~110 MB per
+    # engine that nothing touched).  The metric table's rule picks 32-column slices, whose workspace is the tiny one
+    assert metric == small
+    rows_extra = 3 * (ws(3 * 2048, 384) - 3 * 2048 * (384 // 32) * 4)   # three slots of row-slice partials over the column form's
+    assert engine_bytes(30522, 384, 0, forced=ROWS) - metric >= rows_extra
+    assert pref(30522, 388, 6144, 128) == 1 and form(30522, 388, 128) == ROWS        # no whole 32-column slices: row slices by rule
+    assert engine_bytes(30522, 388, 0) - engine_bytes(2000, 388, 0) >= 3 * ws(3 * 2048, 388) - 4096
+    binned_ws = lib.tt_gather_pool_binned_workspace_bytes(3 * 2048, 384, 128)
+    assert binned_ws > 0 and engine_bytes(30522, 384, 0, forced=_lib.TT_K1_BINNED) - metric >= 3 * binned_ws - 3 * 3 * 2048 * 12 * 4 - 4096
     assert engine_bytes(30522, 384, _lib.TT_K1_SHARE_AUTO) == metric  # sharing mode does not change the layout
     assert engine_bytes(30522, 384, -2) == 0                          # invalid sharing mode
+    assert engine_bytes(30522, 384, 0, forced=9) == 0                 # not a TT_K1_* form
 
 
 def test_k1_streaming_form_selection_and_argument_checks(monkeypatch):

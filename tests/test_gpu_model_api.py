@@ -195,6 +195,106 @@ def test_train_epoch_on_the_engine_hands_its_state_to_the_optimizer_and_back():
         train_epoch(m, batches, crit, two, log_wandb=False, fused=True)
 
 
+def _pretok(g, i, extra=0):
+    pad = lambda t: torch.nn.functional.pad(t, (0, extra)) if extra else t
+    return tuple((pad(T(g[f"batch{i}/ids_{r}"])).cuda(), pad(T(g[f"batch{i}/mask_{r}"])).cuda()) for r in "qpn")
+
+
+def test_engine_route_survives_optimizer_and_weight_reloads_between_epochs():
+    """Round-4 advisor finding: after `optimizer.load_state_dict()` torch has REPLACED the state tensors, and a caller may
+    assign `p.data` by hand — the fused route must then train with what the caller loaded, not with the stale flat
+    buffers it still holds.  Fused epoch -> reload optimizer state and weights saved after epoch 1 of ANOTHER run -> fused
+    epoch must equal the module loop doing the same; and a cleared optimizer state restarts the moments."""
+    import copy
+
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import FusedAdam, train_epoch
+
+    g = load_golden("step_mid.npz")
+    nb, lr = int(g["n_batches"]), float(g["lr"])
+    batches = [_pretok(g, i) for i in range(nb)]
+    crit = TripletLoss(margin=float(g["margin"]))
+    out = {}
+    for fused in (False, None):
+        m, _ = build_model(g)
+        opt = FusedAdam(m.parameters(), lr=lr)
+        train_epoch(m, batches, crit, opt, log_wandb=False, fused=fused)
+        saved_opt = copy.deepcopy(opt.state_dict())
+        saved_w = {k: v.clone() for k, v in m.state_dict().items()}
+        train_epoch(m, batches, crit, opt, log_wandb=False, fused=fused)  # moves weights and moments on
+        opt.load_state_dict(saved_opt)        # ... and back: the state tensors are new objects now
+        for p, k in zip(m.trainable_parameters(), orc.PARAM_KEYS):
+            p.data = saved_w[k].clone()       # hand-assigned storage, no longer the engine's view
+        a3 = train_epoch(m, batches, crit, opt, log_wandb=False, fused=fused)
+        out[fused] = (a3, {k: v.clone() for k, v in m.state_dict().items() if ".projection." in k},
+                      {int(opt.state[p]["step"]) for p in m.trainable_parameters()})
+    (a_mod, sd_mod, st_mod), (a_eng, sd_eng, st_eng) = out[False], out[None]
+    assert st_mod == st_eng == {2 * nb}
+    assert abs(a_mod - a_eng) <= TOL
+    for k in sd_mod:
+        assert_params_close(sd_eng[k].cpu().numpy(), sd_mod[k].cpu().numpy(), lr, 2 * nb, tight=2e-6)
+    # the parameters are the engine's views again: a state_dict() taken now shows what the engine trains
+    m, _ = build_model(g)
+    opt = FusedAdam(m.parameters(), lr=lr)
+    train_epoch(m, batches, crit, opt, log_wandb=False)
+    tr = opt._tt_route.trainer
+    opt.state.clear()                          # a caller that resets the optimizer
+    train_epoch(m, batches, crit, opt, log_wandb=False)
+    assert {int(opt.state[p]["step"]) for p in m.trainable_parameters()} == {nb}
+    assert all(opt.state[p]["exp_avg"].data_ptr() >= tr.exp_avg.data_ptr() for p in m.trainable_parameters())
+
+
+def test_engine_route_takes_a_larger_batch_mid_epoch_and_cleans_up_after_an_exception():
+    """The reference's loop takes batches of any size in any order (backend/training.py:36-53): a batch larger than the
+    first one drains the pipeline and rebuilds the engine (weights, moments, step count and the epoch's loss statistics
+    carry over) instead of raising; an exception raised by the dataloader mid-epoch leaves no gathered-but-unapplied
+    batch behind — the next call is a clean epoch (round-4 advisor findings)."""
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import FusedAdam, train_epoch
+
+    g = load_golden("step_mid.npz")
+    nb, lr = int(g["n_batches"]), float(g["lr"])
+    full = [_pretok(g, i) for i in range(nb)]
+    B = full[0][0][0].shape[0]
+    small = tuple((i[: B // 2].contiguous(), k[: B // 2].contiguous()) for i, k in full[0])
+    seq = [small] + full + [small]            # the engine is first built for B / 2, then has to grow
+    crit = TripletLoss(margin=float(g["margin"]))
+    res = {}
+    for fused in (False, None):
+        m, _ = build_model(g)
+        opt = FusedAdam(m.parameters(), lr=lr)
+        avg = train_epoch(m, seq, crit, opt, log_wandb=False, fused=fused)
+        res[fused] = (avg, {k: v.clone() for k, v in m.state_dict().items() if ".projection." in k})
+    assert abs(res[False][0] - res[None][0]) <= TOL
+    for k in res[False][1]:
+        assert_params_close(res[None][1][k].cpu().numpy(), res[False][1][k].cpu().numpy(), lr, len(seq), tight=2e-6)
+
+    def failing():
+        yield full[0]
+        yield full[1 % nb]
+        raise OSError("the dataloader lost its file")
+
+    m, _ = build_model(g)
+    opt = FusedAdam(m.parameters(), lr=lr)
+    with pytest.raises(OSError):
+        train_epoch(m, failing(), crit, opt, log_wandb=False)
+    tr = opt._tt_route.trainer
+    assert not tr._pending and tr.bucket is None and tr.accumulation_steps == 1
+    steps_done = {int(opt.state[p]["step"]) for p in m.trainable_parameters()}
+    assert len(steps_done) == 1
+    m2, _ = build_model(g)                     # the same weights through the module loop
+    opt2 = FusedAdam(m2.parameters(), lr=lr)
+    k = steps_done.pop()                       # batches that were applied before the exception surfaced
+    if k:
+        train_epoch(m2, [full[0], full[1 % nb]][:k], crit, opt2, log_wandb=False, fused=False)
+    a1 = train_epoch(m, full, crit, opt, log_wandb=False)
+    a2 = train_epoch(m2, full, crit, opt2, log_wandb=False, fused=False)
+    assert abs(a1 - a2) <= TOL
+    with pytest.raises(ValueError):            # rows longer than the tokenizer's max_length are still refused
+        wide = tuple((torch.nn.functional.pad(i, (0, 600)), torch.nn.functional.pad(k, (0, 600))) for i, k in full[0])
+        train_epoch(m, [wide], crit, opt, log_wandb=False)
+
+
 @pytest.mark.parametrize("overlap,fence", [(False, None), (True, None), (True, True), (True, False)],
                          ids=["one-stream", "side-stream", "side-stream,fence=loss-event", "side-stream,fence=own-event"])
 def test_trainer_from_model_matches_reference_and_aliases_modules(overlap, fence):

@@ -49,6 +49,53 @@ __global__ __launch_bounds__(256) void mfma_kernel(float* __restrict__ out, int 
   if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s + pad[0];  // never true: keeps the chain alive
 }
 
+// Round 5: the same register-only chain on other matrix opcodes — is "a busy matrix core stops the SIMD's other waves" a
+// property of the chip or of the f32-input forms (whose rate IS the vector rate)?  MT 1: v_mfma_f32_16x16x4_f32,
+// MT 2: v_mfma_f32_32x32x16_bf16 (a true matrix-core opcode: 16 x the f32 form's FLOP per clock).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int MT>
+__global__ __launch_bounds__(256) void mfma_kernel_t(float* __restrict__ out, int iters) {
+  float s = 0.f;
+  if constexpr (MT == 1) {
+    f32x4v acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += acc[i][e];
+  } else {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] = (__bf16)(1.0f + (threadIdx.x + e) * 1e-3f);
+      b[e] = (__bf16)(1.0f - (threadIdx.x + e) * 1e-3f);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += acc[i][e];
+  }
+  if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s;  // never true: keeps the chain alive
+}
+
 // region of XCD x (workgroups with blockIdx % 8 == x): lines [x * lines_per_xcd, (x + 1) * lines_per_xcd)
 template <int PRIO>
 __global__ __launch_bounds__(256) void gather_kernel(const float4* __restrict__ buf, unsigned lines_per_xcd, int iters,
@@ -174,6 +221,42 @@ int main() {
   };
   printf("# %d CUs; M = MFMA chain on registers (mw waves per SIMD, lds KB per workgroup), G = L2 gather (gw 4-wave workgroups per CU)\n", cus);
   printf("# %3s %4s %3s | %8s %8s | %8s %8s | %s\n", "mw", "lds", "gw", "M alone", "G alone", "M both", "G both", "speed M + speed G");
+  {  // Round 5: one MFMA wave per SIMD of each opcode beside the gather (gw = 2 and 6); iteration counts sized to ~2 ms alone
+    struct Op { const char* name; int mt; int iters; };
+    // cycles per MFMA: f32 32x32x2 64, f32 16x16x4 32, bf16 32x32x16 (8 passes x 4 clk x 2 = measured below; sized from a first timing)
+    const Op ops[] = {{"v_mfma_f32_32x32x2_f32", 0, m_total_iters}, {"v_mfma_f32_16x16x4_f32", 1, 2 * m_total_iters},
+                      {"v_mfma_f32_32x32x16_bf16", 2, 2 * m_total_iters}};
+    printf("# opcode sweep: one MFMA wave per SIMD (4 independent accumulators, registers only) beside the L2 gather\n");
+    printf("# %-26s %3s | %8s %8s | %8s %8s | %s\n", "opcode", "gw", "M alone", "G alone", "M both", "G both", "speed M + speed G");
+    for (const Op& op : ops) {
+      auto run_mt = [&](hipStream_t st) {
+        if (op.mt == 0) hipLaunchKernelGGL(mfma_kernel<0>, dim3(cus), dim3(256), 0, st, out, op.iters);
+        else if (op.mt == 1) hipLaunchKernelGGL(mfma_kernel_t<1>, dim3(cus), dim3(256), 0, st, out, op.iters);
+        else hipLaunchKernelGGL(mfma_kernel_t<2>, dim3(cus), dim3(256), 0, st, out, op.iters);
+      };
+      for (int gw : {2, 6}) {
+        const float ma = time_alone(run_mt, sm);
+        const float ga = time_alone([&](hipStream_t st) { run_g(gw, st); }, sg);
+        float mb = 1e9f, gb = 1e9f;
+        for (int r = 0; r < 3; ++r) {
+          CHECK(hipDeviceSynchronize());
+          CHECK(hipEventRecord(e0, sm)); run_mt(sm); CHECK(hipEventRecord(e1, sm));
+          CHECK(hipEventRecord(f0, sg)); run_g(gw, sg); CHECK(hipEventRecord(f1, sg));
+          CHECK(hipDeviceSynchronize());
+          float a, b;
+          CHECK(hipEventElapsedTime(&a, e0, e1));
+          CHECK(hipEventElapsedTime(&b, f0, f1));
+          if (a + b < mb + gb) { mb = a; gb = b; }
+        }
+        const float t = mb < gb ? mb : gb;
+        const float m_done = mb <= gb ? 1.f : (1.f - (mb - t) / ma);
+        const float g_done = gb <= mb ? 1.f : (1.f - (gb - t) / ga);
+        printf("  %-26s %3d | %8.3f %8.3f | %8.3f %8.3f | %.2f + %.2f = %.2f   (%.1f cycles per MFMA alone at 2.4 GHz)\n", op.name, gw, ma,
+               ga, mb, gb, m_done * ma / t, g_done * ga / t, (m_done * ma + g_done * ga) / t, ma * 2.4e6 / ((double)op.iters * 4));
+        fflush(stdout);
+      }
+    }
+  }
   const int mws[] = {1, 2};
   const int ldss[] = {0};
   const int gws[] = {2, 6};

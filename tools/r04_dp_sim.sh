@@ -7,6 +7,6 @@ for spec in "c2:--config c2" "c3:--config c3" "inbatch512:--config c2 --loss inb
   tag=${spec%%:*}; args=${spec#*:}
   python tools/ab_tune.py --rounds 2 --out $O/r04_dp_sim_$tag.txt \
     -v "single:" -v "x0:--simulate-allreduce-us 0" -v "x30:--simulate-allreduce-us 30" -v "x60:--simulate-allreduce-us 60" -v "x100:--simulate-allreduce-us 100" \
-    -v "x30_split:--simulate-allreduce-us 30 --dp-split" -v "x60_split:--simulate-allreduce-us 60 --dp-split" -v "x100_split:--simulate-allreduce-us 100 --dp-split" \
+    -v "x30_split:--simulate-allreduce-us 30 --dp-split 1" -v "x60_split:--simulate-allreduce-us 60 --dp-split 1" -v "x100_split:--simulate-allreduce-us 100 --dp-split 1" \
     -- $args --steps 200 --warmup 20 2>&1 | tail -9
 done

@@ -22,7 +22,7 @@ TT_K1_SHARE_AUTO = -1  # tt_engine_config.k1_blocks_per_cu: pair the K1 form wit
 TT_K1_AUTO, TT_K1_PER_TEXT, TT_K1_ROW_SLICES, TT_K1_COLUMN_SLICES, TT_K1_STREAM, TT_K1_BINNED = 0, 1, 2, 3, 4, 5
 K1_FORMS = {"auto": TT_K1_AUTO, "per_text": TT_K1_PER_TEXT, "rows": TT_K1_ROW_SLICES, "columns": TT_K1_COLUMN_SLICES,
             "stream": TT_K1_STREAM, "binned": TT_K1_BINNED}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 _lock = threading.Lock()
@@ -46,6 +46,7 @@ class TTEngineConfig(C.Structure):
         ("device", C.c_int32),
         ("k1_blocks_per_cu", C.c_int32),
         ("grad_slabs", C.c_int32),
+        ("k1_form", C.c_int32),
     ]
 
 
@@ -160,6 +161,7 @@ SIGNATURES = {
     "tt_engine_reduce_grads_range": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "tt_engine_set_dw2_event": (_i, [_vp, _vp]),
     "tt_engine_set_loss_event": (_i, [_vp, _vp]),
+    "tt_engine_arm_loss_event": (_i, [_vp, _i32]),
     "tt_engine_set_join_wait": (_i, [_vp, _vp, C.POINTER(C.c_int32)]),
     "tt_event_create": (_i, [_i, C.POINTER(_vp)]),
     "tt_event_destroy": (_i, [_vp]),

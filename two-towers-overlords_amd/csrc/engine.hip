@@ -90,6 +90,7 @@ struct tt_engine {
   int bwd_mode;             // tt_engine_set_backward: TT_BWD_AUTO / TT_BWD_FORK / TT_BWD_FUSED
   hipEvent_t ev_dw2;        // tt_engine_set_dw2_event: recorded once the dW2 / db2 slabs are complete (may be null)
   hipEvent_t ev_loss;       // tt_engine_set_loss_event: recorded on the caller's stream right after the loss kernel (may be null)
+  bool loss_event_armed;    // tt_engine_arm_loss_event: the fused backward records ev_loss too (the fork backward always does: it IS its fork point)
   hipEvent_t join_wait;     // tt_engine_set_join_wait: one-shot, the second stream waits for it before the next join (may be null)
 };
 
@@ -113,16 +114,17 @@ void carve(tt_engine* e, char* base, size_t* total) {
   Carver c{base};
   const size_t rows = 3 * (size_t)e->cfg.max_B;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->pooled[i] = c.take<float>(rows * e->cfg.D);
-  // partial sums of the XCD-sliced K1: for tables the sliced form can win on (any N, S), or — so that a tuning can
-  // force that form on any table — whenever they are small (<= 64 MB per slot)
-  const size_t sliced_bytes = tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D);
-  e->k1_partial_bytes = (tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, (int64_t)1 << 40, 128) || sliced_bytes <= (64u << 20))
-                            ? sliced_bytes : tt_k1_colsliced_workspace_bytes((int64_t)rows, e->cfg.D);  // (the column form's is tiny)
-  // the binned form's partials + sorted ids, where the engine may pick it (a big table named many times per batch)
-  // (or whenever it is small, <= 64 MB per slot, so that a tuning can force that form on any table)
+  // per-slot partial sums of the sliced / binned K1 forms: sized for what the shape rule can pick for this table by
+  // itself (any N, S up to the handle's maxima) and for the form the caller says a tuning will force (cfg.k1_form)
+  const int want = e->cfg.k1_form;
+  const bool auto_sliced = tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, (int64_t)1 << 40, 128);
+  const bool rows_form = want == TT_K1_ROW_SLICES ||
+                         (auto_sliced && tt_k1_sliced_form(e->cfg.V, e->cfg.D, 128) == TT_K1_ROW_SLICES);
+  e->k1_partial_bytes = rows_form ? tt_gather_pool_sliced_workspace_bytes((int64_t)rows, e->cfg.D)
+                                  : tt_k1_colsliced_workspace_bytes((int64_t)rows, e->cfg.D);  // (the column form's is tiny)
   const size_t binned_bytes = tt_gather_pool_binned_workspace_bytes((int64_t)rows, e->cfg.D, e->cfg.max_S);
   if (binned_bytes > e->k1_partial_bytes &&
-      (tt_k1_prefers_binned(e->cfg.V, e->cfg.D, (int64_t)rows, e->cfg.max_S) || binned_bytes <= (64u << 20)))
+      (want == TT_K1_BINNED || tt_k1_prefers_binned(e->cfg.V, e->cfg.D, (int64_t)rows, e->cfg.max_S)))
     e->k1_partial_bytes = binned_bytes;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i)
     e->k1_partial[i] = e->k1_partial_bytes ? c.take<float>(e->k1_partial_bytes / sizeof(float)) : nullptr;
@@ -151,7 +153,8 @@ void carve(tt_engine* e, char* base, size_t* total) {
 static int fill_dims(tt_engine* e, const tt_engine_config* cfg) {
   TT_REQUIRE(cfg->V >= 1 && cfg->V <= 0x7fffffffLL && cfg->D >= 1 && cfg->P >= 1 && cfg->P <= 1024 &&
                  cfg->max_B >= 1 && cfg->max_S >= 1 && (int64_t)cfg->max_B * 3 <= 0x7fffffffLL &&
-                 cfg->k1_blocks_per_cu >= TT_K1_SHARE_AUTO && cfg->grad_slabs >= 0 && cfg->grad_slabs <= 16,
+                 cfg->k1_blocks_per_cu >= TT_K1_SHARE_AUTO && cfg->grad_slabs >= 0 && cfg->grad_slabs <= 16 &&
+                 cfg->k1_form >= TT_K1_AUTO && cfg->k1_form <= TT_K1_BINNED,
              TT_ERR_BAD_SHAPE);
   e->cfg = *cfg;
   e->tower_n = (int64_t)cfg->P * cfg->D + cfg->P + (int64_t)cfg->P * cfg->P + cfg->P;
@@ -213,8 +216,10 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
   }
   e->gathers_share_chip = true;
   e->shared = cfg->k1_blocks_per_cu != 0;
-  e->tile_above = cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO && e->k1_partial_bytes >= tt_gather_pool_sliced_workspace_bytes(3 * (int64_t)cfg->max_B, cfg->D) &&
-                  tt_k1_prefers_sliced(cfg->V, cfg->D, 3 * (int64_t)cfg->max_B, cfg->max_S);
+  e->tile_above = cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO && tt_k1_prefers_sliced(cfg->V, cfg->D, 3 * (int64_t)cfg->max_B, cfg->max_S) &&
+                  e->k1_partial_bytes >= (tt_k1_sliced_form(cfg->V, cfg->D, cfg->max_S) == TT_K1_ROW_SLICES
+                                              ? tt_gather_pool_sliced_workspace_bytes(3 * (int64_t)cfg->max_B, cfg->D)
+                                              : tt_k1_colsliced_workspace_bytes(3 * (int64_t)cfg->max_B, cfg->D));
   e->cap = cfg->k1_blocks_per_cu > 0 ? cfg->k1_blocks_per_cu : (cfg->k1_blocks_per_cu == TT_K1_SHARE_AUTO ? 2 : 0);
   e->magic = kMagic;
   *out = e;
@@ -329,8 +334,9 @@ static int engine_k1(tt_engine* e, int slot, const void* ids, int ids_dtype, con
     else if (auto_share && tt_k1_prefers_stream(e->cfg.V, e->cfg.D, N, S) &&
         tt_k1_stream_supported(e->cfg.D, e->table, e->pooled[slot]))
       form = TT_K1_STREAM;  // beside the projection chain when the table really comes from HBM (gather_pool.hip)
-    else if (e->k1_partial_bytes >= rows_ws && tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, N, S) &&
-             tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]))
+    else if (tt_k1_prefers_sliced(e->cfg.V, e->cfg.D, N, S) && tt_k1_sliced_supported(S, e->cfg.D, e->table, e->pooled[slot]) &&
+             e->k1_partial_bytes >= (tt_k1_sliced_form(e->cfg.V, e->cfg.D, S) == TT_K1_ROW_SLICES ? rows_ws : cols_ws) &&
+             (tt_k1_sliced_form(e->cfg.V, e->cfg.D, S) == TT_K1_ROW_SLICES || cols_ws != 0))
       form = tt_k1_sliced_form(e->cfg.V, e->cfg.D, S);  // table several times an XCD's L2 (tt_k1_prefers_sliced)
     else
       form = TT_K1_PER_TEXT;
@@ -442,7 +448,7 @@ static int backward_chain(tt_engine* e, const ttp::Tower (&t)[2], int32_t loss_r
   int rc;
   if (!use_fork(e)) {
     e->join_wait = nullptr;
-    if (e->ev_loss) TT_HIP(hipEventRecord(e->ev_loss, st));
+    if (e->ev_loss && e->loss_event_armed) TT_HIP(hipEventRecord(e->ev_loss, st));  // (an extra packet on the critical chain)
     if (loss_rows > 0) {
       rc = tt_launch_loss_mean(e->hinge, loss_rows, loss_denominator, e->loss, e->loss_sum, e->loss_cnt, st);
       if (rc != TT_OK) return rc;
@@ -572,6 +578,12 @@ extern "C" int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event) {
 extern "C" int tt_engine_set_loss_event(tt_engine* e, tt_event_t event) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   e->ev_loss = static_cast<hipEvent_t>(event);
+  return TT_OK;
+}
+
+extern "C" int tt_engine_arm_loss_event(tt_engine* e, int32_t armed) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  e->loss_event_armed = armed != 0;
   return TT_OK;
 }
 

@@ -234,8 +234,18 @@ __global__ __launch_bounds__(kThreads) void loss_mean_kernel(const float* __rest
                                                              double* __restrict__ acc_sum,
                                                              long long* __restrict__ acc_count) {
   __shared__ float red[kWavesPerBlock];
+  // The order of triplet_kernel's in-launch mean, so that the two backward schedules (loss mean in the triplet launch /
+  // as this launch) report bitwise the same loss: first the sum of each run of kWavesPerBlock rows — one triplet
+  // workgroup's partial — then thread t adds partials t, t + 256, ...
+  static_assert(kWavesPerBlock == 4, "one triplet workgroup's partial is the sum of four rows");
   float s = 0.f;
-  for (long long i = threadIdx.x; i < B; i += kThreads) s += hinge_rows[i];
+  const long long nparts = (B + kWavesPerBlock - 1) / kWavesPerBlock;
+  for (long long i = threadIdx.x; i < nparts; i += kThreads) {
+    const long long r = i * kWavesPerBlock;
+    const float h0 = hinge_rows[r], h1 = r + 1 < B ? hinge_rows[r + 1] : 0.f, h2 = r + 2 < B ? hinge_rows[r + 2] : 0.f,
+                h3 = r + 3 < B ? hinge_rows[r + 3] : 0.f;
+    s += ((h0 + h1) + h2) + h3;
+  }
   s = tt_wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -561,10 +571,12 @@ extern "C" int tt_adam_multi_f32(const tt_adam_tensor* tensors, int count, doubl
   const double bc1 = 1.0 - pow(beta1, (double)step);   // in double on the host, as torch does for a python-float step
   const double bc2 = 1.0 - pow(beta2, (double)step);
   const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-  for (int base = 0; base < count; base += kAdamMaxTensors) {
+  // one launch per kAdamMaxTensors NON-EMPTY tensors; `i` carries on across launches (empty tensors are skipped without
+  // taking a place, so a chunk may consume more than kAdamMaxTensors input entries)
+  for (int i = 0; i < count;) {
     AdamMulti a{};
     long long blocks = 0;
-    for (int i = base; i < count && a.count < kAdamMaxTensors; ++i) {
+    for (; i < count && a.count < kAdamMaxTensors; ++i) {
       const tt_adam_tensor& t = tensors[i];
       if (t.n == 0) continue;
       const int k = a.count++;

@@ -41,8 +41,9 @@ class HotPathEngine:
         self.V, self.D = table.shape
         self.P = int(projection_dim)
         self.max_B, self.max_S = int(max_batch), int(max_seq_len)
+        forced = _lib.make_tuning(tuning or {}).k1_form  # the partial-sum workspace is sized for a form a tuning will force
         cfg = TTEngineConfig(self.V, self.D, self.P, self.max_B, self.max_S, self.device.index or 0, int(k1_blocks_per_cu),
-                             int(grad_slabs))
+                             int(grad_slabs), int(forced))
         lib = _lib.load()
         nbytes = lib.tt_engine_workspace_bytes(C.byref(cfg))
         if nbytes == 0:
@@ -224,6 +225,14 @@ class HotPathEngine:
         took = C.c_int32(0)
         call("tt_engine_set_join_wait", self._h, event._h, C.byref(took))
         return bool(took.value)
+
+    def arm_loss_event(self, armed: bool) -> None:
+        """The fused backward records the loss event only while armed (tt_engine_arm_loss_event)."""
+        call("tt_engine_arm_loss_event", self._h, 1 if armed else 0)
+
+    def clear_join_wait(self) -> None:
+        """Drop a pending one-shot join wait (a pipeline that is being abandoned)."""
+        call("tt_engine_set_join_wait", self._h, None, None)
 
     def adam(self, step: int, lr: float, grads: Optional[torch.Tensor] = None, beta1=0.9, beta2=0.999, eps=1e-8) -> None:
         g = None

@@ -286,21 +286,117 @@ class _EngineRoute:
                 queries, positives, negatives = ((t["input_ids"], t.get("attention_mask")) for t in (tq, tp, tn))
             yield self._stack(queries, positives, negatives)
 
+    def _rebind(self) -> None:
+        """The nn.Parameters and `optimizer.state[p]` must still BE views of the trainer's flat buffers.  After
+        `optimizer.load_state_dict()` (torch replaces the state tensors), a hand-assigned `p.data`, or a cleared state they
+        are not: copy what the caller put there into the flat buffers and alias again, so that the fused epoch trains with
+        the caller's weights and moments and not with stale ones (round-4 advisor finding)."""
+        tr = self.trainer
+        for p, (_, off, shape) in zip(self.model.trainable_parameters(), flat_param_slices(tr.D, tr.P)):
+            n = p.numel()
+            view = tr.flat[off: off + n].view(shape)
+            if p.data.data_ptr() != view.data_ptr():
+                view.copy_(p.data)
+                p.data = view
+            st = self.optimizer.state.get(p)
+            if not st:  # a cleared optimizer state: zero moments, no steps taken (what torch does lazily)
+                st = self.optimizer.state[p] = {"step": 0}
+            for key, buf in (("exp_avg", tr.exp_avg), ("exp_avg_sq", tr.exp_avg_sq)):
+                v = buf[off: off + n].view(shape)
+                t = st.get(key)
+                if t is None:
+                    v.zero_()
+                elif t.data_ptr() != v.data_ptr():
+                    v.copy_(t.reshape(shape))
+                st[key] = v
+            st.setdefault("step", 0)
+
     def run_epoch(self, dataloader, accumulation_steps: Optional[int] = None) -> float:
         """One epoch.  accumulation_steps None: train_epoch (training.py:36-53: zero_grad, backward, step per batch, a
         print every tenth batch).  An integer k: train_epoch_optimized (training.py:66-133: loss / k, step + zero_grad
         after every k-th batch of THIS epoch, whatever `.grad` held on entry is added to, whatever the last unfinished
-        window accumulated stays in `.grad`)."""
+        window accumulated stays in `.grad`).  A batch larger than the engine was built for drains the pipeline and
+        rebuilds the engine (the reference's loop takes batches of any size); whatever raises inside the epoch — the
+        dataloader, an over-long row — leaves no half-applied batches behind in the trainer."""
         it = self._batches(dataloader)
         first = next(it, None)
         if first is None:
             raise ZeroDivisionError("train_epoch: empty dataloader")  # what the reference's `total_loss / num_batches` raises
-        if first.ids.shape[2] > self.MAX_S:
-            raise ValueError(f"train_epoch(fused): rows of {first.ids.shape[2]} tokens exceed {self.MAX_S}")
+        self._check(first)
         if self.trainer is None or first.size > self.trainer.engine.max_B:
             self._build(first.size)
             if first.size * first.ids.shape[2] >= 65536:  # a batch worth timing: pick the backward schedule / fence placement
                 self.trainer.calibrate(first)             # for this device and shape (state-neutral, ~0.1 s once)
+        self._rebind()
+        accumulate = accumulation_steps is not None
+        self._enter(accumulate, accumulation_steps)
+        state = {"n": 0, "loss_sum": 0.0, "loss_n": 0}
+
+        def step(nxt) -> None:
+            self.trainer.advance(nxt)
+            state["n"] += 1
+            if not accumulate and state["n"] % 10 == 0:  # the reference prints here (training.py:59-61): the one host
+                _, _, last = self.trainer.engine.read_stats(reset=False)  # read per ten batches
+                print(f"Batch {state['n']}, Loss: {last:.4f}")
+
+        def grow(b) -> None:
+            """`b` does not fit the engine: finish what is in flight, rebuild for b's size (weights, moments, step count,
+            the un-applied gradient window and the epoch's loss statistics carry over) and go on."""
+            old = self.trainer
+            while old._pending:
+                step(None)
+            ls, n, _ = old.engine.read_stats(reset=True)
+            state["loss_sum"] += ls
+            state["loss_n"] += n
+            carried = (old._micro, old._carry)
+            self._sync_steps(old)
+            self._build(b.size)
+            self._rebind()
+            self._enter(accumulate, accumulation_steps, carried=carried)
+
+        try:
+            depth = self.trainer.SLOTS - 1 if self.trainer.side is not None else 1
+            self.trainer.gather(first)
+            nxt = next(it, None)
+            while nxt is not None or self.trainer._pending:
+                if nxt is not None:
+                    self._check(nxt)
+                    if nxt.size > self.trainer.engine.max_B:
+                        grow(nxt)
+                if nxt is not None and len(self.trainer._pending) < depth:  # prime (or re-prime) the pipeline
+                    self.trainer.gather(nxt)
+                    nxt = next(it, None)
+                    continue
+                if not self.trainer._pending:
+                    self.trainer.gather(nxt)
+                    nxt = next(it, None)
+                    continue
+                step(nxt)
+                if nxt is not None:
+                    nxt = next(it, None)
+            tr = self.trainer
+            ls, n, _ = tr.engine.read_stats(reset=True)
+            state["loss_sum"] += ls
+            state["loss_n"] += n
+            self._sync_steps(tr)
+            if accumulate:
+                self._leave_grads(tr._carry)
+            else:  # `.grad` of the last batch, as the reference's loop leaves it (a later accumulation epoch adds to it)
+                self._grad_views()
+                tr.engine.reduce_grads(self._bucket, accumulate=False)
+                self._leave_grads(True)
+            return state["loss_sum"] / state["loss_n"]
+        finally:
+            tr = self.trainer
+            if tr._pending:  # an exception mid-epoch: gathered-but-unapplied batches must not leak into the next call
+                tr.abort_pipeline()
+                self._sync_steps(tr)
+                tr.engine.read_stats(reset=True)
+            tr.bucket, tr.accumulation_steps, tr._carry = None, 1, False
+
+    def _enter(self, accumulate: bool, accumulation_steps, carried=None) -> None:
+        """Hyper-parameters, step count and the accumulation window of this call -> the trainer.  `carried` = (micro, carry)
+        of the engine this one replaces mid-epoch; None at the start of an epoch."""
         tr = self.trainer
         group = self.optimizer.param_groups[0]
         tr.lr, tr.betas, tr.eps, tr.margin = float(group["lr"]), tuple(group["betas"]), float(group["eps"]), self.margin
@@ -308,49 +404,23 @@ class _EngineRoute:
         if len(steps) != 1:
             raise ValueError("train_epoch(fused): the optimizer's tensors have taken different numbers of steps")
         tr.step_count = steps.pop()  # module-path steps taken with this optimizer in between count too
-        accumulate = accumulation_steps is not None
         tr.accumulation_steps = int(accumulation_steps) if accumulate else 1
-        tr._micro = 0  # batch_idx restarts with the epoch (training.py:80)
-        tr._carry = self._take_left_over_grads() if accumulate else False  # train_epoch clears .grad before its first batch
+        if carried is None:
+            tr._micro = 0  # batch_idx restarts with the epoch (training.py:80)
+            tr._carry = self._take_left_over_grads() if accumulate else False  # train_epoch clears .grad before its first batch
+        else:
+            tr._micro, tr._carry = carried  # the un-applied window lives in self._bucket, which outlives the engine
         if tr._carry or tr.accumulation_steps > 1:
             self._grad_views()
             tr.bucket = self._bucket
         else:
             tr.bucket = None  # Adam reads the gradient slabs directly
         tr.engine.read_stats(reset=True)
-        depth = tr.SLOTS - 1 if tr.side is not None else 1
-        tr.gather(first)
-        while len(tr._pending) < depth:
-            b = next(it, None)
-            if b is None:
-                break
-            self._check(b)
-            tr.gather(b)
-        num_batches = 0
-        while tr._pending:
-            b = next(it, None)
-            if b is not None:
-                self._check(b)
-            tr.advance(b)
-            num_batches += 1
-            if not accumulate and num_batches % 10 == 0:  # the reference prints here (training.py:59-61): the one host
-                _, _, last = tr.engine.read_stats(reset=False)  # read per ten batches
-                print(f"Batch {num_batches}, Loss: {last:.4f}")
-        loss_sum, n, _ = tr.engine.read_stats(reset=True)
-        self._sync_steps(tr)
-        if accumulate:
-            self._leave_grads(tr._carry)
-        else:  # `.grad` of the last batch, as the reference's loop leaves it (a later accumulation epoch adds to it)
-            self._grad_views()
-            tr.engine.reduce_grads(self._bucket, accumulate=False)
-            self._leave_grads(True)
-        tr.bucket, tr.accumulation_steps, tr._carry = None, 1, False
-        return loss_sum / n
 
     def _check(self, b) -> None:
-        if b.size > self.trainer.engine.max_B or b.ids.shape[2] > self.MAX_S:
-            raise ValueError(f"train_epoch(fused): a batch of {b.size} x {b.ids.shape[2]} tokens after a first batch of "
-                             f"{self.trainer.engine.max_B}: put the largest batch first, or call train_epoch(fused=False)")
+        if b.ids.shape[2] > self.MAX_S:
+            raise ValueError(f"train_epoch(fused): rows of {b.ids.shape[2]} tokens exceed {self.MAX_S} (the tokenizer's "
+                             "max_length, backend/model.py:44)")
 
 
 def train_epoch_optimized(model: TwoTowersModel, dataloader, criterion: TripletLoss,
@@ -455,7 +525,7 @@ class TripletTrainer:
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
                  process_group=None, engine=None, overlap_streams: Optional[bool] = None,
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
-                 freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: bool = False,
+                 freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: Optional[bool] = False,
                  gather_under_exchange: bool = True, tuning: Optional[dict] = None, event_scope: Optional[int] = None,
                  fence_at_loss: Optional[bool] = None, grad_slabs: int = 0, join_carries_gather: bool = True):
         if model is not None:
@@ -515,12 +585,16 @@ class TripletTrainer:
         self._exchange = (self.world > 1) if exchange is None else bool(exchange)
         self._gather_under_exchange = bool(gather_under_exchange)  # False: the next gather goes ahead of the projection kernels (A/B)
         self.bucket = torch.empty_like(self.flat) if (self._exchange or self.accumulation_steps > 1) else None
+        # split_exchange=None: calibrate() times the data-parallel step with the exchange in one bucket and in two parts on
+        # the fabric at hand and keeps the faster (every replica takes the slowest rank's verdict).
         # split_exchange=True: the exchange in two parts — the second-layer gradients (dW2, db2 of both
         # towers: complete before the dH -> dW1 chain starts) are reduced and all-reduced on a second stream UNDER that
         # chain, only the first-layer gradients travel after it (see _split_step).  Same sums per element, so with two
         # replicas bitwise the one-bucket step; off by default until RCCL hardware says which is faster.
-        self._split = bool(split_exchange) and self._exchange and hasattr(self.engine, "reduce_grads_range")
-        if self._split:
+        can_split = self._exchange and hasattr(self.engine, "reduce_grads_range")
+        self._split = bool(split_exchange) and can_split
+        self._split_auto = split_exchange is None and can_split and self.device.type == "cuda"  # calibrate() times both forms
+        if self._split or self._split_auto:
             tn = self.engine.n_params // 2                      # floats per tower: W1 | b1 | W2 | b2
             n1 = self.P * self.D + self.P                       # W1 | b1
             self._late = [(0, n1), (tn, n1)]
@@ -589,6 +663,15 @@ class TripletTrainer:
         else:
             self._loss_event, self._use_loss_fence, self._fence_arg = None, False, fence_at_loss
             self._join_carries_gather = False
+        self._loss_armed = False              # tt_engine_arm_loss_event's current value
+        # With a gradient exchange the next gather sits UNDER the exchange and the chain runs alone on the chip: there the
+        # fused backward (one stream, no fork / join events) is the shorter one — the fork's events cost 11 + 7 us of gaps
+        # at configs[2]'s share (gpurun_out/r05_base/timeline_c3_x60.txt) and nothing shares the chip to fill them.  The
+        # engine's own AUTO rule decides for a chain that shares the chip with gathers; calibrate() re-measures both in
+        # the regime at hand and may override this.
+        if (self._exchange and self._gather_under_exchange and self.side is not None and hasattr(self.engine, "set_backward")
+                and not (tuning or {}).get("backward")):
+            self.engine.set_backward("fused")
         self._prewaited = None                # slot whose "ready" event the caller's stream already waits for
         self.k1_events = None                 # set to a list to collect (start, end) HIP events of K1 launches
         self.k1_event_every = 4               # ... of every 4th launch
@@ -597,7 +680,9 @@ class TripletTrainer:
         self.feature_cache = None             # [N_texts, D] pooled-normalised vectors (build_feature_cache)
         self.token_store = None               # (ids [N_texts, S], lens [N_texts] | None) behind TripletBatch.token_rows
         self.calibration = None               # what calibrate() measured and chose
-        self._dry = False                     # calibrate(): apply() stops after fwd + bwd (no exchange, no optimizer)
+        self.step_trace = None                # set to a list to collect per-step timing events (see _trace_mark)
+        self._dry = False                     # calibrate(): apply() stops after fwd + bwd (+ reduce + exchange under DP), no optimizer
+        self._dry_bucket = None               # scratch bucket of those dry data-parallel steps
         self.table = table
         # hipGraph replay of whole steps (single replica, no accumulation; opt-in).  Measured on
         # ROCm 7.2 / MI355X it does NOT pay: replaying the 3-stream, ~15-node step graph costs the
@@ -773,7 +858,13 @@ class TripletTrainer:
             raise ValueError("apply(): empty global batch")
         k = self.accumulation_steps
         self._steps_done += 1
+        mark = self._trace_mark if self.step_trace is not None else None
+        if mark:
+            mark(0)  # step start (caller's stream)
         loss_fence = self._loss_event if (self.side is not None and self._use_loss_fence) else None
+        if self._loss_event is not None and (loss_fence is not None) != self._loss_armed:
+            self._loss_armed = loss_fence is not None   # the fused backward records the event only when someone waits for it
+            self.engine.arm_loss_event(self._loss_armed)
         if self.side is not None:
             # Where the next gather goes.  Single replica: behind this batch's phase-B launches in HOST order, waiting
             # for the loss event (both streams stay busy back to back, and the caller's stream carries no fence packet).
@@ -816,6 +907,19 @@ class TripletTrainer:
             issue()
             issue = None
         if self._dry:
+            # calibrate(): no optimizer, no counters.  With a gradient exchange the timed step must be the data-parallel
+            # step as it will run — slab reduce -> (scratch) bucket, next gather issued, the exchange on this stream — or
+            # the schedules are ranked beside a gather that, in training, sits under the exchange instead (round 5)
+            if self._exchange and self._dry_bucket is not None and self._split:
+                self._split_step(local_B, True, True, issue, dry=True)
+                return
+            if self._exchange and self._dry_bucket is not None:
+                if local_B > 0:
+                    self.engine.reduce_grads(self._dry_bucket, accumulate=False)
+                if issue is not None:
+                    issue()
+                self._all_reduce(self._dry_bucket)
+                return
             if issue is not None:
                 issue()
             return
@@ -828,17 +932,22 @@ class TripletTrainer:
                 return
             self.step_count += 1
             self._prewait_next()
+            if mark:
+                mark(1)
+                mark(2)  # no exchange on this path
             if self._auto_step:  # step counter on the device: the same call sequence is graph-replayable
                 self.engine.adam_auto(self.lr, None, self.betas[0], self.betas[1], self.eps)
             else:
                 self.engine.adam(self.step_count, self.lr, None, self.betas[0], self.betas[1], self.eps)
+            if mark:
+                mark(3)
             if issue is not None:
                 issue()
             return
         first_micro = not self._carry  # nothing un-applied in the bucket: this batch's gradients overwrite it
         self._carry = not do_step
         if self._split:
-            self._split_step(local_B, first_micro, do_step, issue)
+            self._split_step(local_B, first_micro, do_step, issue, mark=mark)
             return
         if local_B > 0:
             self.engine.reduce_grads(self.bucket, accumulate=not first_micro)
@@ -846,12 +955,29 @@ class TripletTrainer:
             self.bucket.zero_()
         if issue is not None:
             issue()  # weight-independent; enqueued BEFORE the exchange so that its fence does not wait for it
+        if mark:
+            mark(1)  # forward + loss + backward + slab reduce done
         if do_step and self._exchange:
             self._all_reduce(self.bucket)
+        if mark:
+            mark(2)  # exchange done
         if do_step:
             self.step_count += 1
             self._prewait_next()
             self.engine.adam(self.step_count, self.lr, self.bucket, self.betas[0], self.betas[1], self.eps)
+        if mark:
+            mark(3)  # optimizer done
+
+    def _trace_mark(self, i: int) -> None:
+        """step_trace (a list, or None = off): every step appends [e0, e1, e2, e3] timing events recorded on the caller's
+        stream at step start / after forward+loss+backward(+slab reduce) / after the exchange / after Adam — what
+        bench.py's `dp_breakdown` is computed from.  Each record is an event packet on the critical chain (a few us): a
+        traced pass is its own short run, never the timed region."""
+        if i == 0:
+            self.step_trace.append([None, None, None, None])
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        self.step_trace[-1][i] = ev
 
     def _prewait_next(self) -> None:
         """The NEXT batch's gather must have finished before its forward starts.  If it has not yet (the host runs ahead
@@ -901,15 +1027,18 @@ class TripletTrainer:
 
     # -- calibration ----------------------------------------------------------------------
     def calibrate(self, batch: Batch, steps: int = 48, rounds: int = 2) -> dict:
-        """Time phase B's two backward schedules (include/tt_hotpath.h, tt_engine_set_backward) on THIS
-        device with THIS batch shape — gathers running beside them exactly as in training — and keep the
-        faster one.  The two tie at some shapes and differ by 5-10 % at others, and the
-        balance moves with what else shares the chip; both write bitwise the same gradients, so the choice
-        never changes a training run's parameters.  Parameters, Adam state, step counters and loss
-        statistics are untouched: the timed steps stop after the backward (no exchange, no optimizer).
-        A side effect worth knowing: the ~2*rounds*steps steps also bring the GPU from its idle power
-        state to sustained clocks, which otherwise takes the first ~70 training steps (the first steps
-        after any idle period run 10-20 % slower; measured)."""
+        """Time the step's equivalent schedules on THIS device with THIS batch shape, in the regime the trainer will run
+        in, and keep the fastest: phase B's two backward schedules (include/tt_hotpath.h, tt_engine_set_backward), where
+        the gather's slot fence comes from (single replica), and — with a gradient exchange whose form the caller left
+        open (`split_exchange=None`) — the exchange in one bucket or in two parts.  Single replica: dry steps with the
+        gathers running beside the chain exactly as in training.  Data parallel (round 5): the dry steps ARE the
+        data-parallel step — slab reduce into a scratch bucket, the next gather issued under the exchange, the real
+        collective on the caller's stream — because there the chain runs alone on the chip and the ranking differs
+        (configs[2]'s share under a 60 us stand-in: fork 187 us, fused 170; beside the gathers they tie).  All
+        candidates write bitwise the same gradients, so the choice never changes a training run's parameters.
+        Parameters, Adam state, step counters, the gradient bucket and loss statistics are untouched (no optimizer).
+        A side effect worth knowing: the dry steps also bring the GPU from its idle power state to sustained clocks,
+        which otherwise takes the first ~70 training steps."""
         if self._pending:
             raise RuntimeError("calibrate(): call it between epochs (batches are still in flight)")
         if self.device.type != "cuda" or not hasattr(self.engine, "set_backward") or self.loss_kind != "triplet":
@@ -919,12 +1048,17 @@ class TripletTrainer:
         # second dimension: where the gather's slot fence comes from (see __init__, fence_at_loss) — only where the
         # caller left it open and the engine's loss event exists
         fences = (False, True) if (self.side is not None and self._loss_event is not None and self._fence_arg is None) else (self._use_loss_fence,)
-        times = {(m, f): [] for m in ("fused", "fork") for f in fences}
+        # third: the exchange in one bucket or two parts — only where the caller left it open
+        forms = (False, True) if (self._exchange and self._split_auto) else (self._split,)
+        times = {(m, f, sp): [] for m in ("fused", "fork") for f in fences for sp in forms}
         self._dry = True
+        if self._exchange and self.bucket is not None:
+            self._dry_bucket = torch.zeros_like(self.bucket)  # the real bucket may hold an un-applied accumulation window
         try:
             for _ in range(rounds):
-                for mode, fence in times:
+                for mode, fence, sp in times:
                     self._use_loss_fence = fence
+                    self._split = sp
                     self.engine.set_backward(mode)
                     while len(self._pending) < depth:
                         self.gather(b)
@@ -936,9 +1070,10 @@ class TripletTrainer:
                     while self._pending:
                         self.apply(None)
                     e1.synchronize()
-                    times[(mode, fence)].append(e0.elapsed_time(e1) / steps)
+                    times[(mode, fence, sp)].append(e0.elapsed_time(e1) / steps)
         finally:
             self._dry = False
+            self._dry_bucket = None
         keys = list(times)
         best = {kf: min(v) for kf, v in times.items()}
         if self.world > 1:  # every replica must take the same decision: decide on the slowest rank's times
@@ -948,19 +1083,24 @@ class TripletTrainer:
         pick = min(best, key=best.get)
         self.engine.set_backward(pick[0])
         self._use_loss_fence = pick[1]
+        self._split = pick[2]
         self.engine.read_stats(reset=True)  # the dry steps' losses do not belong to any epoch
         self.calibration = {"backward": pick[0], "fence_at_loss": pick[1],
+                            "exchange_form": (None if not self._exchange else ("two-part" if pick[2] else "one-bucket")),
+                            "regime": ("data-parallel step: slab reduce + exchange inside the timed dry steps, the gather under "
+                                       "the exchange" if self._exchange else "single replica: gathers beside the chain"),
                             "ms_per_step": {m: min(best[kf] for kf in keys if kf[0] == m) for m in ("fused", "fork")},
-                            "ms_per_step_by_fence": {f"{m},{'loss' if f else 'own'}": best[(m, f)] for m, f in keys},
+                            "ms_per_step_by_fence": {f"{m},{'loss' if f else 'own'}" + (",two-part" if sp else ""): best[(m, f, sp)]
+                                                     for m, f, sp in keys},
                             "steps": steps, "rounds": rounds}
         return self.calibration
 
-    def _split_step(self, local_B: int, first_micro: bool, do_step: bool, issue_next) -> None:
+    def _split_step(self, local_B: int, first_micro: bool, do_step: bool, issue_next, mark=None, dry: bool = False) -> None:
         """Slab reduce + exchange + Adam with the bucket cut in two (split_exchange=True).  `early` = dW2 / db2 of both
         towers: their slabs are complete when the engine records `_ev_dw2` (inside fwd_bwd, before dH -> dW1), so a
         second stream reduces and all-reduces them while the caller's stream is still computing dW1 / db1; `late` =
         dW1 / db1, reduced and exchanged on the caller's stream after that chain, as the whole bucket is otherwise."""
-        eng, bucket = self.engine, self.bucket
+        eng, bucket = self.engine, (self._dry_bucket if dry else self.bucket)
         cuda = self.device.type == "cuda"
         main = torch.cuda.current_stream(self.device) if cuda else None
 
@@ -979,29 +1119,36 @@ class TripletTrainer:
             with torch.cuda.stream(self._comm):
                 reduce(self._early)
                 if do_step:
-                    self._all_reduce_parts(self._early)
+                    self._all_reduce_parts(self._early, bucket)
                 self._ev_early.record(self._comm)
         else:
             reduce(self._early)
             if do_step:
-                self._all_reduce_parts(self._early)
+                self._all_reduce_parts(self._early, bucket)
         reduce(self._late)
         if issue_next is not None:
             issue_next()
+        if mark:
+            mark(1)
         if do_step:
-            self._all_reduce_parts(self._late)
+            self._all_reduce_parts(self._late, bucket)
         if cuda:
             main.wait_event(self._ev_early)  # before Adam — or, on a micro-batch, before the next fwd_bwd rewrites the slabs
-        if do_step:
+        if mark:
+            mark(2)
+        if do_step and not dry:
             self.step_count += 1
             eng.adam(self.step_count, self.lr, bucket, self.betas[0], self.betas[1], self.eps)
+        if mark:
+            mark(3)
 
-    def _all_reduce_parts(self, parts) -> None:
+    def _all_reduce_parts(self, parts, bucket=None) -> None:
         """The views of one part of the flat bucket (W2 | b2 of each tower, or W1 | b1 of each), summed over the
         replicas: one public `dist.all_reduce` per view, issued back to back on the current stream (the early part's
         stream is off the critical chain; per-element sums do not depend on how the bucket is cut)."""
+        bucket = self.bucket if bucket is None else bucket
         for off, n in parts:
-            dist.all_reduce(self.bucket[off: off + n], op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
+            dist.all_reduce(bucket[off: off + n], op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
 
     def _all_reduce(self, bucket: torch.Tensor) -> None:
         """The step's one gradient exchange: sum of the flat bucket over the replicas (RCCL over xGMI on GPUs).
@@ -1189,6 +1336,7 @@ class TripletTrainer:
             self.apply(global_B, issue_next=(lambda fence=None: self.gather(nxt, fence=fence)) if nxt is not None else None)
             return
         slot_fb, ev, B, _, _ = self._pending.popleft()
+        self._prewaited = None  # a pre-wait belongs to the eager step that enqueued it (round-4 advisor finding)
         slot_k1 = None
         if nxt is not None:
             slot_k1 = self._next_slot
@@ -1203,6 +1351,15 @@ class TripletTrainer:
         self.step_count += 1
         if slot_k1 is not None:
             self._pending.append((slot_k1, None, B, None, None))
+
+    def abort_pipeline(self) -> None:
+        """Forget every gathered-but-unapplied batch (an epoch that ended in an exception).  Their gathers complete on the
+        side stream on their own; the slots are handed out again in stream order (gather() fences the side stream behind
+        the caller's stream), so nothing has to be waited for here."""
+        self._pending.clear()
+        self._prewaited = None
+        if hasattr(self.engine, "clear_join_wait"):
+            self.engine.clear_join_wait()
 
     # -- public ------------------------------------------------------------------
     def train_step(self, batch: Batch, global_batch: Optional[int] = None) -> None:

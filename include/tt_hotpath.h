@@ -410,6 +410,9 @@ typedef struct {
                          workspace is sized for the forms the shape rule can pick by itself plus this one (ABI 3; before,
                          every handle carried up to 64 MB per slot for forms nobody had asked for).  A tuning that forces a
                          form whose workspace was not sized falls back to the shape rule. */
+  int32_t pack_roles; /* != 0: the workspace also holds, per slot, int32 staging ids [3, max_B, max_S] + prefix lengths for
+                         tt_engine_pool_roles (the drop-in train_epoch route: 12 bytes per token slot; off for callers that
+                         hand over packed [roles, B, S] ids themselves) */
 } tt_engine_config;
 #define TT_K1_SHARE_AUTO (-1)
 
@@ -485,6 +488,28 @@ int tt_engine_pool(tt_engine* e, int slot, const void* ids, int ids_dtype, const
 int tt_engine_pool_rows(tt_engine* e, int slot, const void* store_ids, int ids_dtype,
                         const int32_t* store_lens, int64_t n_store, const int32_t* rows,
                         int32_t roles, int32_t B, int32_t S, tt_stream_t stream);
+
+/*
+ * K1 over roles handed over the way the reference's tokenizer call returns them (backend/model.py:43-48: one
+ * `input_ids` [B, S_r] and one `attention_mask` [B, S_r] per encode call, int64, every role padded to ITS longest
+ * text): one pass on `stream` squeezes every text's attended tokens (mask != 0), in order, into int32 ids
+ * [n_roles, B, S_max] + prefix lengths in the engine's workspace (tt_engine_config.pack_roles), then K1 runs in its
+ * prefix-length form — no [roles, B, S] int64 stacks on the caller's side and no mask re-reads in the gather
+ * (measured: 17 us of a 210 us step at BASELINE.json configs[1]).  For 0/1 masks this is the reference's masked mean
+ * (backend/model.py:63-72: a token with mask 0 adds nothing to either sum), bitwise the prefix-length form for right-padded
+ * rows; a mask value other than 0 / 1 (a weight) cannot be expressed: it raises the flag tt_engine_read_stats reports as
+ * TT_ERR_UNSUPPORTED — use tt_engine_pool with the mask for weighted pooling.  mask == NULL: every token attended.
+ */
+typedef struct {
+  const void* ids;     /* [B, S] row-major, device */
+  const void* mask;    /* [B, S] or NULL */
+  int32_t ids_dtype;   /* TT_I32 / TT_I64 */
+  int32_t mask_dtype;  /* TT_I32 / TT_I64 */
+  int32_t S;           /* this role's padded length, 1..max_S */
+  int32_t reserved;    /* must be 0 */
+} tt_role_tokens;
+int tt_engine_pool_roles(tt_engine* e, int slot, const tt_role_tokens* roles, int32_t n_roles, int32_t B,
+                         tt_stream_t stream);
 
 /*
  * Phase A from a frozen-feature cache.  The encoder is frozen (backend/model.py:29-30,51), so
@@ -619,6 +644,10 @@ int tt_engine_train_step(tt_engine* e, const void* ids, int ids_dtype, const voi
 const float* tt_engine_pooled(const tt_engine* e, int slot);   /* [roles*B, D] */
 const float* tt_engine_embeddings(const tt_engine* e);         /* [roles*B, P] projected */
 const float* tt_engine_grad_slab0(const tt_engine* e);         /* [slabs, param_count] */
+/* The device scalar every loss kernel leaves the batch loss in (what tt_engine_read_stats returns as last_loss): a caller
+ * that wants a batch's loss without stopping the stream copies it out stream-ordered (backend/training.py:59-61 prints
+ * every tenth batch's loss; a synchronous read there drains the pipeline). */
+const float* tt_engine_last_loss(const tt_engine* e);
 
 /* Host-side read of {sum of batch losses, number of batches, last loss}; synchronises
  * `stream`.  reset != 0 zeroes the accumulator afterwards. */

@@ -1285,6 +1285,68 @@ def test_engine_pool_rows_is_bitwise_pool_of_the_gathered_rows(tt, V, D, S, B, i
     eng.close()
 
 
+@pytest.mark.parametrize("V,D,idt,form", [(30522, 384, torch.int64, None), (800, 100, torch.int32, None),
+                                          (30522, 384, torch.int64, "per_text"), (250000, 64, torch.int64, "stream")])
+def test_engine_pool_roles_packs_the_tokenizers_blocks(tt, V, D, idt, form):
+    """tt_engine_pool_roles: roles handed over as the tokenizer returns them (one [B, S_r] int64 ids + attention mask per
+    encode call, every role padded to its own longest text, backend/model.py:43-48).  Right-padded masks: bitwise the
+    prefix-length gather of the same tokens.  Left-padded rows and holes (any 0/1 mask): the attended tokens squeezed
+    together in order — the oracle's masked mean (backend/model.py:63-72) within fp32 rounding.  A weight mask (a value
+    other than 0 / 1) cannot be packed: reported at the next read_stats(); an id outside the table likewise."""
+    ops, engine = tt
+    from two_towers_overlords_amd import _lib
+
+    B, S = 70, (33, 128, 97)
+    gen = torch.Generator().manual_seed(23)
+    table = (orc.synthetic_table(V, D, seed=1) * 30).cuda()
+    eng = engine.HotPathEngine(table, 16, B, max(S), pack_roles=True, tuning=({"k1_form": form} if form else None),
+                               k1_blocks_per_cu=(_lib.TT_K1_SHARE_AUTO if form == "stream" else 0))
+    flat = torch.zeros(eng.n_params, device="cuda")
+    eng.bind(flat, torch.zeros_like(flat), torch.zeros_like(flat))
+    ids = [torch.randint(0, V, (B, s), generator=gen).to(idt).cuda() for s in S]
+    lens = [torch.randint(0, s + 1, (B,), generator=gen) for s in S]          # includes empty texts (the 1e-9 clamp path)
+    lens[1][0] = S[1]
+    right = [(torch.arange(s).unsqueeze(0) < l.unsqueeze(1)).to(torch.int64).cuda() for s, l in zip(S, lens)]
+    for roles in (3, 2):
+        eng.pool_roles(0, [(ids[r], right[r]) for r in range(roles)])
+        a = eng.pooled(0, B, roles).clone()
+        padded = torch.zeros(roles, B, max(S), dtype=torch.int32, device="cuda")
+        for r in range(roles):
+            padded[r, :, : S[r]] = (ids[r] * right[r]).int()
+        eng.pool(1, padded, None, torch.stack(lens[:roles]).int().cuda())
+        assert torch.equal(a, eng.pooled(1, B, roles))                         # the prefix-length form, bit for bit
+        eng.pool_roles(2, [(ids[r], None) for r in range(roles)])              # no mask: every token attended
+        for r in range(roles):
+            ref = ops.gather_pool_norm(table, ids[r].contiguous(), sliced=False)
+            close(eng.pooled(2, B, roles)[r], ref, atol=2e-6)
+    # any 0/1 mask: left padding, holes
+    left = [torch.flip(m, dims=[1]).contiguous() for m in right]
+    holes = [(torch.rand(B, s, generator=gen) < 0.6).to(torch.int64).cuda() for s in S]
+    for masks in (left, holes):
+        eng.pool_roles(0, [(ids[r], masks[r].to(torch.int32) if r == 1 else masks[r]) for r in range(3)])
+        got = eng.pooled(0, B, 3).clone()
+        for r in range(3):
+            want = orc.gather_pool_normalize(table.cpu(), ids[r].cpu().long(), masks[r].cpu().long())
+            close(got[r], want, atol=2e-6)
+    torch.cuda.synchronize()
+    assert eng.read_stats()[1] == 0
+    weights = right[0].clone()
+    weights[3, 0] = 2
+    eng.pool_roles(0, [(ids[0], weights), (ids[1], right[1])])
+    with pytest.raises(ValueError, match="other than 0 / 1"):
+        eng.read_stats()
+    bad = ids[0].clone()
+    bad[1, 0] = V + 7
+    eng.pool_roles(0, [(bad, None), (ids[1], right[1])])
+    with pytest.raises(_lib.TTError):
+        eng.read_stats()
+    plain = engine.HotPathEngine(table, 16, B, max(S))                         # no staging area asked for
+    with pytest.raises(_lib.TTError):
+        plain.pool_roles(0, [(ids[0], None), (ids[1], None)])
+    plain.close()
+    eng.close()
+
+
 def test_trainer_token_store_epoch_equals_materialised_ids_and_calibrate_is_neutral(tt):
     """TokenTripletLoader(emit="rows3"/"rows2") + TripletTrainer.set_token_store: the same epoch, bit for
     bit, as the materialised [3,B,S] / [2,B,S] id batches describing the same triplets; and

@@ -47,7 +47,15 @@ class TTEngineConfig(C.Structure):
         ("k1_blocks_per_cu", C.c_int32),
         ("grad_slabs", C.c_int32),
         ("k1_form", C.c_int32),
+        ("pack_roles", C.c_int32),
     ]
+
+
+class TTRoleTokens(C.Structure):
+    """tt_role_tokens: one role's [B, S] ids (+ attention mask) as the tokenizer returned them (device pointers)."""
+
+    _fields_ = [("ids", C.c_void_p), ("mask", C.c_void_p), ("ids_dtype", C.c_int32), ("mask_dtype", C.c_int32),
+                ("S", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TTAdamTensor(C.Structure):
@@ -151,6 +159,7 @@ SIGNATURES = {
     "tt_engine_bind": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "tt_engine_pool": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i32, _i32, _i32, _vp]),
     "tt_engine_pool_cached": (_i, [_vp, _i, _vp, _i64, _vp, _i, _i32, _i32, _vp]),
+    "tt_engine_pool_roles": (_i, [_vp, _i, C.POINTER(TTRoleTokens), _i32, _i32, _vp]),
     "tt_engine_fwd_bwd": (_i, [_vp, _i, _i32, _vp, _f, _f, _f, _vp]),
     "tt_engine_forward": (_i, [_vp, _i, _i32, _i32, _vp]),
     "tt_engine_backward": (_i, [_vp, _i, _i32, _i32, _vp]),
@@ -175,6 +184,7 @@ SIGNATURES = {
     "tt_engine_pooled": (_vp, [_vp, _i]),
     "tt_engine_embeddings": (_vp, [_vp]),
     "tt_engine_grad_slab0": (_vp, [_vp]),
+    "tt_engine_last_loss": (_vp, [_vp]),
     "tt_engine_read_stats": (_i, [_vp, C.POINTER(_d), C.POINTER(_i64), C.POINTER(_f), _i, _vp]),
 }
 

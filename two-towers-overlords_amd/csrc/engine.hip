@@ -58,6 +58,8 @@ struct tt_engine {
   float* pooled[TT_ENGINE_SLOTS];
   float* k1_partial[TT_ENGINE_SLOTS];  // XCD-sliced K1: per-slice partial sums + mask sums of one batch
   size_t k1_partial_bytes;
+  int32_t* stage_ids[TT_ENGINE_SLOTS];   // tt_engine_pool_roles: packed int32 ids [3, max_B, max_S] of one batch (cfg.pack_roles)
+  int32_t* stage_lens[TT_ENGINE_SLOTS];  // ... and their prefix lengths [3, max_B]
   void* k1_stream_ctl[TT_ENGINE_SLOTS];  // streaming K1: queue head + per-CU registry of one launch (every engine has them: 16 KB each)
   bool k1_streamed[TT_ENGINE_SLOTS];     // the last tt_engine_pool* into this slot used the streaming form
   bool stream_beside;                    // the most recent tt_engine_pool* streamed: phase B pairs its tiles with that
@@ -129,6 +131,10 @@ void carve(tt_engine* e, char* base, size_t* total) {
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i)
     e->k1_partial[i] = e->k1_partial_bytes ? c.take<float>(e->k1_partial_bytes / sizeof(float)) : nullptr;
   for (int i = 0; i < TT_ENGINE_SLOTS; ++i) e->k1_stream_ctl[i] = c.take<char>(tt_gather_pool_stream_workspace_bytes());
+  for (int i = 0; i < TT_ENGINE_SLOTS; ++i) {
+    e->stage_ids[i] = e->cfg.pack_roles ? c.take<int32_t>(rows * (size_t)e->cfg.max_S) : nullptr;
+    e->stage_lens[i] = e->cfg.pack_roles ? c.take<int32_t>(rows) : nullptr;
+  }
   e->H = c.take<float>(rows * e->cfg.P);
   e->emb = c.take<float>(rows * e->cfg.P);
   e->dOut = c.take<float>(rows * e->cfg.P);
@@ -280,6 +286,7 @@ extern "C" const float* tt_engine_pooled(const tt_engine* e, int slot) {
 }
 extern "C" const float* tt_engine_embeddings(const tt_engine* e) { return ok(e) ? e->emb : nullptr; }
 extern "C" const float* tt_engine_grad_slab0(const tt_engine* e) { return ok(e) ? e->slabs : nullptr; }
+extern "C" const float* tt_engine_last_loss(const tt_engine* e) { return ok(e) ? e->loss : nullptr; }
 
 extern "C" int tt_engine_bind(tt_engine* e, const float* table, float* params, float* exp_avg,
                               float* exp_avg_sq) {
@@ -386,6 +393,77 @@ extern "C" int tt_engine_pool_rows(tt_engine* e, int slot, const void* store_ids
   TT_REQUIRE(store_ids && rows, TT_ERR_NULL_POINTER);
   TT_REQUIRE(n_store >= 1 && n_store <= 0x7fffffffLL, TT_ERR_BAD_SHAPE);
   return engine_k1(e, slot, store_ids, ids_dtype, nullptr, TT_I32, store_lens, roles, B, S, rows, n_store, stream);
+}
+
+// One wave per (role, text): the attended tokens (mask != 0) of a [B, S_r] block, in order, as int32 ids at the front of
+// row (role, text) of out_ids [roles, B, S_out]; the rest of the row zero; lens = their count.  flags[1] |= 1 where a
+// mask value is neither 0 nor 1 (weighted pooling cannot be packed), ids outside int32 become -1 (K1 reports them).
+struct PackRoles {
+  const void* ids[3];
+  const void* mask[3];
+  int ids_w[3], mask_w[3], S[3];
+  int n_roles;
+};
+__global__ __launch_bounds__(256) void pack_roles_kernel(const PackRoles a, int B, int S_out, int32_t* __restrict__ out_ids,
+                                                         int32_t* __restrict__ out_lens, int32_t* __restrict__ flags) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= (long long)a.n_roles * B) return;
+  const int role = (int)(t / B);
+  const long long text = t - (long long)role * B;
+  const int S = a.S[role];
+  const void* __restrict__ ip = a.ids[role];
+  const void* __restrict__ mp = a.mask[role];
+  const bool i64 = a.ids_w[role] == TT_I64, m64 = a.mask_w[role] == TT_I64;
+  int32_t* __restrict__ dst = out_ids + t * (long long)S_out;
+  const long long src = text * (long long)S;
+  int count = 0;
+  bool weird = false;
+  for (int base = 0; base < S; base += 64) {
+    const int tok = base + lane;
+    const bool in = tok < S;
+    long long m = 1, id = 0;
+    if (in) {
+      if (mp) m = m64 ? static_cast<const long long*>(mp)[src + tok] : (long long)static_cast<const int32_t*>(mp)[src + tok];
+      id = i64 ? static_cast<const long long*>(ip)[src + tok] : (long long)static_cast<const int32_t*>(ip)[src + tok];
+    }
+    const bool keep = in && m != 0;
+    weird = weird || (keep && m != 1);
+    const unsigned long long b = __ballot(keep);
+    const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
+    if (keep) dst[pos] = (id < 0 || id > 0x7fffffffLL) ? -1 : (int32_t)id;
+    count += __popcll(b);
+  }
+  for (int tok = count + lane; tok < S_out; tok += 64) dst[tok] = 0;
+  if (lane == 0) out_lens[t] = count;
+  if (__any(weird) && lane == 0) atomicOr(flags + 1, 1);
+}
+
+extern "C" int tt_engine_pool_roles(tt_engine* e, int slot, const tt_role_tokens* roles, int32_t n_roles, int32_t B,
+                                    tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(roles, TT_ERR_NULL_POINTER);
+  TT_REQUIRE(e->cfg.pack_roles, TT_ERR_WORKSPACE);  // the handle was created without the staging area
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS && (n_roles == 2 || n_roles == 3), TT_ERR_BAD_SHAPE);
+  TT_REQUIRE(B >= 1 && B <= e->cfg.max_B, TT_ERR_BAD_SHAPE);
+  PackRoles a{};
+  a.n_roles = n_roles;
+  int S_out = 0;
+  for (int r = 0; r < n_roles; ++r) {
+    TT_REQUIRE(roles[r].ids, TT_ERR_NULL_POINTER);
+    TT_REQUIRE(roles[r].reserved == 0 && roles[r].S >= 1 && roles[r].S <= e->cfg.max_S, TT_ERR_BAD_SHAPE);
+    TT_REQUIRE((roles[r].ids_dtype == TT_I32 || roles[r].ids_dtype == TT_I64) &&
+                   (!roles[r].mask || roles[r].mask_dtype == TT_I32 || roles[r].mask_dtype == TT_I64), TT_ERR_BAD_DTYPE);
+    a.ids[r] = roles[r].ids; a.mask[r] = roles[r].mask;
+    a.ids_w[r] = roles[r].ids_dtype; a.mask_w[r] = roles[r].mask ? roles[r].mask_dtype : TT_I32;
+    a.S[r] = roles[r].S;
+    S_out = roles[r].S > S_out ? roles[r].S : S_out;
+  }
+  const long long texts = (long long)n_roles * B;
+  hipLaunchKernelGGL(pack_roles_kernel, dim3((unsigned)((texts + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a, (int)B,
+                     S_out, e->stage_ids[slot], e->stage_lens[slot], e->oob);
+  TT_CHECK_LAUNCH();
+  return engine_k1(e, slot, e->stage_ids[slot], TT_I32, nullptr, TT_I32, e->stage_lens[slot], n_roles, B, S_out, nullptr, 0, stream);
 }
 
 extern "C" int tt_engine_pool_cached(tt_engine* e, int slot, const float* cache, int64_t cache_rows,
@@ -655,15 +733,15 @@ extern "C" int tt_engine_read_stats(tt_engine* e, double* loss_sum, int64_t* n_b
   double s = 0;
   long long c = 0;
   float l = 0;
-  int32_t oob = 0;
+  int32_t oob[2] = {0, 0};  // [0] a token id / store row outside its range was clamped, [1] tt_engine_pool_roles met a weight mask
   TT_HIP(hipMemcpyAsync(&s, e->loss_sum, sizeof(double), hipMemcpyDeviceToHost, st));
   TT_HIP(hipMemcpyAsync(&c, e->loss_cnt, sizeof(long long), hipMemcpyDeviceToHost, st));
   TT_HIP(hipMemcpyAsync(&l, e->loss, sizeof(float), hipMemcpyDeviceToHost, st));
-  TT_HIP(hipMemcpyAsync(&oob, e->oob, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  TT_HIP(hipMemcpyAsync(oob, e->oob, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   if (reset) {
     TT_HIP(hipMemsetAsync(e->loss_sum, 0, sizeof(double), st));
     TT_HIP(hipMemsetAsync(e->loss_cnt, 0, sizeof(long long), st));
-    TT_HIP(hipMemsetAsync(e->oob, 0, sizeof(int32_t), st));  // the out-of-range flag is reported once
+    TT_HIP(hipMemsetAsync(e->oob, 0, 2 * sizeof(int32_t), st));  // the flags are reported once
     // the in-launch loss mean's arrival ticket: zero between launches by construction (the last workgroup
     // re-zeroes it); cleared here as well so that a launch torn down mid-grid cannot leave it poisoned
     TT_HIP(hipMemsetAsync(e->mean_ticket, 0, sizeof(unsigned), st));
@@ -672,7 +750,8 @@ extern "C" int tt_engine_read_stats(tt_engine* e, double* loss_sum, int64_t* n_b
   if (loss_sum) *loss_sum = s;
   if (n_batches) *n_batches = c;
   if (last_loss) *last_loss = l;
-  return oob ? TT_ERR_BAD_SHAPE : TT_OK;  // an out-of-range token id was clamped
+  if (oob[1]) return TT_ERR_UNSUPPORTED;  // a mask value other than 0 / 1 reached tt_engine_pool_roles
+  return oob[0] ? TT_ERR_BAD_SHAPE : TT_OK;  // an out-of-range token id was clamped
 }
 
 // Events for ordering streams of ONE device against each other (the trainer's gather fence / slot-ready events).  A

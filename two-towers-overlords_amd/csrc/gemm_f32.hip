@@ -24,12 +24,35 @@
 // 145.9; profiles/r04_proj_depth_ab.txt.  Removed: the tiles are not short of requests in flight, and the registers
 // cost a resident wave per SIMD.)
 //
+// (Round 5 built K-step 64 for the 64x64 tiles — one barrier per 32 MFMAs instead of 16, 70 KB of LDS, 116-120 registers,
+// bitwise the same products — on in-kernel phase stamps (tools/gemm_stamps.hip) that show a workgroup's K loop taking 2.3 x
+// its MFMA time with the chip otherwise idle: K loop 11.96 -> 11.44 us at configs[2]'s share but the prologue 1.24 -> 1.84,
+// launches 19.8 -> 20.3 us; at configs[1] the 70 KB stop the third workgroup of a CU from being resident: 27.1 -> 29.6 us;
+// profiles/r05_gemm_stamps.txt.  Removed.  What the stamps do show: all workgroups of a launch start within 0.6 us, the
+// prologue is 1.2-1.6 us, the epilogue 0.6-1 us — the launches are bound by the CUs that hold the most tiles (2 of 64x64
+// at 1.5 tiles per CU, 3 at 2.25), each tile's K loop running at 0.7-0.86 of the MFMA rate while it shares its SIMDs.)
+//
 // Numerics: each C element is a k-ordered fmaf chain in fp32 (what the MFMA
 // computes, bitwise), K-steps in ascending order; split-K (kTN) partials go to
 // separate slabs that are summed in fixed order later => run-to-run bitwise
 // reproducible, no float atomics.
 #include <type_traits>
 #include "gemm_f32.h"
+
+#ifdef TT_GEMM_STAMPS
+// Diagnostic builds only (tools/gemm_stamps.hip): thread 0 of every workgroup leaves the 100 MHz wall clock at entry, after
+// the prologue (first operand tile in LDS), after the K loop and after the epilogue.
+__device__ unsigned long long tt_gemm_stamps[4 * 8192];
+#define TT_STAMP(i)                                                                                              \
+  do {                                                                                                           \
+    if (threadIdx.x == 0) {                                                                                      \
+      const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                       \
+      if (wg_ < 8192) tt_gemm_stamps[4 * wg_ + (i)] = wall_clock64();                                            \
+    }                                                                                                            \
+  } while (0)
+#else
+#define TT_STAMP(i)
+#endif
 
 namespace ttg {
 namespace {
@@ -186,6 +209,7 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
 
   const int m0 = by * BM, n0 = bx * BN;
   if (m0 >= M || n0 >= N) return;  // grouped launch: grid is sized for the largest problem
+  TT_STAMP(0);
 
   const bool ksplit = (LAYOUT == kTN) || b.nsplit > 1;  // split z covers k in [z * kps, (z + 1) * kps)
   const int kbeg = ksplit ? min(K, split * kps) : 0;
@@ -270,6 +294,7 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
       sstore(ra0, rb0, 0);
     }
     __syncthreads();
+    TT_STAMP(1);
     int kt = 0;
     // steady state, two K-steps per trip, no conditionals inside (so the compiler can keep
     // the newest request in flight behind a counted vmcnt): on entry LDS 0 holds tile kt
@@ -304,6 +329,7 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
   };
   if (VEC && full) kloop(std::true_type{});
   else kloop(std::false_type{});
+  TT_STAMP(2);
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*h.
   // The tile goes through LDS (free after the K loop's last barrier) so that global
@@ -450,6 +476,7 @@ __device__ __forceinline__ void gemm_body(const Batch& b, float* __restrict__ ld
     }
   }
   if (do_colsum && tid < BM && m0 + tid < M) gcolsum[slab + m0 + tid] = csum;
+  TT_STAMP(3);
 }
 
 // Tile coordinates of this workgroup.  Plain: the 3-D grid.  XCD-aware (Batch::xcd_order): a 1-D grid where

@@ -34,7 +34,7 @@ def flat_param_slices(D: int, P: int):
 
 class HotPathEngine:
     def __init__(self, table: torch.Tensor, projection_dim: int, max_batch: int, max_seq_len: int,
-                 k1_blocks_per_cu: int = 0, tuning=None, grad_slabs: int = 0):
+                 k1_blocks_per_cu: int = 0, tuning=None, grad_slabs: int = 0, pack_roles: bool = False):
         _req(table, "table", torch.float32, 2)
         self.device = table.device
         self.table = table
@@ -43,7 +43,8 @@ class HotPathEngine:
         self.max_B, self.max_S = int(max_batch), int(max_seq_len)
         forced = _lib.make_tuning(tuning or {}).k1_form  # the partial-sum workspace is sized for a form a tuning will force
         cfg = TTEngineConfig(self.V, self.D, self.P, self.max_B, self.max_S, self.device.index or 0, int(k1_blocks_per_cu),
-                             int(grad_slabs), int(forced))
+                             int(grad_slabs), int(forced), 1 if pack_roles else 0)
+        self.pack_roles = bool(pack_roles)
         lib = _lib.load()
         nbytes = lib.tt_engine_workspace_bytes(C.byref(cfg))
         if nbytes == 0:
@@ -118,6 +119,27 @@ class HotPathEngine:
         a = self._ids_args(ids, mask, lens)
         call("tt_engine_pool", self._h, slot, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7],
              self._stream() if stream is None else stream)
+
+    def pool_roles(self, slot: int, blocks, stream: Optional[int] = None) -> None:
+        """K1 over roles given as separate (input_ids [B, S_r], attention_mask [B, S_r] | None) blocks — what the
+        reference's tokenizer call returns per encode (backend/model.py:43-48) — packed to int32 ids + prefix lengths
+        on `stream` by the engine (tt_engine_pool_roles; needs HotPathEngine(pack_roles=True)).  0/1 masks only: a
+        weight mask raises at the next read_stats()."""
+        if len(blocks) not in (2, 3):
+            raise ValueError("pool_roles: 2 or 3 roles (q, pos[, neg])")
+        arr = (_lib.TTRoleTokens * len(blocks))()
+        B = blocks[0][0].shape[0]
+        for r, (ids, mask) in enumerate(blocks):
+            _req(ids, "ids", ndim=2)
+            if ids.dtype not in _INT_WIDTH or ids.device != self.device or ids.shape[0] != B:
+                raise ValueError("pool_roles: ids must be int32/int64 [B, S] tensors on the engine device, one B for all roles")
+            arr[r].ids, arr[r].ids_dtype, arr[r].S = ids.data_ptr(), _INT_WIDTH[ids.dtype], ids.shape[1]
+            if mask is not None:
+                _req(mask, "mask", ndim=2)
+                if mask.dtype not in _INT_WIDTH or tuple(mask.shape) != tuple(ids.shape) or mask.device != self.device:
+                    raise ValueError("pool_roles: mask must be an int32/int64 tensor of the ids' shape")
+                arr[r].mask, arr[r].mask_dtype = mask.data_ptr(), _INT_WIDTH[mask.dtype]
+        call("tt_engine_pool_roles", self._h, slot, arr, len(blocks), B, self._stream() if stream is None else stream)
 
     def pool_rows(self, slot: int, store_ids: torch.Tensor, store_lens: Optional[torch.Tensor], rows: torch.Tensor,
                   stream: Optional[int] = None) -> None:
@@ -261,7 +283,14 @@ class HotPathEngine:
     def read_stats(self, reset: bool = True) -> Tuple[float, int, float]:
         """(sum of batch losses, batches, last batch loss); synchronises the stream."""
         s, c, l = C.c_double(), C.c_int64(), C.c_float()
-        call("tt_engine_read_stats", self._h, C.byref(s), C.byref(c), C.byref(l), int(reset), self._stream())
+        try:
+            call("tt_engine_read_stats", self._h, C.byref(s), C.byref(c), C.byref(l), int(reset), self._stream())
+        except _lib.TTError as e:
+            if e.code == -7:  # TT_ERR_UNSUPPORTED
+                raise ValueError("an attention_mask with values other than 0 / 1 reached tt_engine_pool_roles (the packed "
+                                 "prefix-length form cannot weigh tokens): the batches since the last read were pooled with "
+                                 "every non-zero mask value as 1 — use pool() with the mask, or train_epoch(fused=False)") from e
+            raise
         return s.value, c.value, l.value
 
     # ------------------------------------------------------------------ views
@@ -275,6 +304,10 @@ class HotPathEngine:
 
     def embeddings(self, B: int, roles: int = 3) -> torch.Tensor:
         return self._view(_lib.load().tt_engine_embeddings(self._h), roles * B * self.P).view(roles, B, self.P)
+
+    def last_loss(self) -> torch.Tensor:
+        """The device scalar [1] the loss kernels leave each batch's loss in (a view: read it stream-ordered)."""
+        return self._view(_lib.load().tt_engine_last_loss(self._h), 1)
 
     def grad_slabs(self) -> torch.Tensor:
         stride = (self.n_params + 3) // 4 * 4

@@ -215,7 +215,7 @@ class _EngineRoute:
         group = self.optimizer.param_groups[0]
         old = self.trainer
         tr = TripletTrainer(self.model, max_batch=B, max_seq_len=self.MAX_S, margin=self.margin, lr=group["lr"],
-                            betas=tuple(group["betas"]), eps=group["eps"])
+                            betas=tuple(group["betas"]), eps=group["eps"], pack_roles=True)
         params = self.model.trainable_parameters()
         steps = set()
         for p, (_, off, shape) in zip(params, flat_param_slices(tr.D, tr.P)):
@@ -266,17 +266,17 @@ class _EngineRoute:
 
     @staticmethod
     def _stack(queries, positives, negatives) -> "TripletBatch":
-        """(ids, mask) x 3 -> ids [3, B, S], mask [3, B, S] padded to the longest role (masked-out zeros are never read).
-        On the caller's stream: built on the gather stream instead (round 4) the step is slower, 215.2 vs 210.5 us — with
-        int64 ids and masks the gather stream is the longer one (profiles/r04_module_path.txt)."""
-        blocks = [_ids_mask(x) for x in (queries, positives, negatives)]
-        S = max(i.shape[1] for i, _ in blocks)
-        pad = lambda t: t if t.shape[1] == S else torch.nn.functional.pad(t, (0, S - t.shape[1]))
-        ids = torch.stack([pad(i) for i, _ in blocks])
-        if all(m is None for _, m in blocks) and all(i.shape[1] == S for i, _ in blocks):
-            return TripletBatch(ids=ids.contiguous())
-        mask = torch.stack([pad(torch.ones_like(i) if m is None else m.to(i.dtype)) for i, m in blocks])
-        return TripletBatch(ids=ids.contiguous(), mask=mask.contiguous())
+        """(ids, mask) x 3 as the tokenizer returned them -> one batch of three role blocks.  Nothing is copied here: the
+        engine packs the blocks (int64 -> int32 ids, attention masks -> prefix lengths, roles padded to the longest) in
+        one pass on the gather stream (tt_engine_pool_roles).  Round 4 built [3, B, S] int64 id and mask stacks on the
+        caller's stream instead — two copy kernels of ~10 us each in the projection chain — and the gather re-read the
+        int64 mask on each of its column passes (17 us): 202-219 us per configs[1] step against 170-175 for packed ids."""
+        blocks = []
+        for ids, mask in (_ids_mask(x) for x in (queries, positives, negatives)):
+            if mask is not None and mask.dtype not in (torch.int32, torch.int64):
+                mask = mask.to(torch.int64)  # bool / uint8 masks
+            blocks.append((ids.contiguous(), None if mask is None else mask.contiguous()))
+        return TripletBatch(role_blocks=blocks)
 
     def _batches(self, dataloader):
         dt, qt = self.model.document_tower, self.model.query_tower
@@ -325,19 +325,36 @@ class _EngineRoute:
         self._check(first)
         if self.trainer is None or first.size > self.trainer.engine.max_B:
             self._build(first.size)
-            if first.size * first.ids.shape[2] >= 65536:  # a batch worth timing: pick the backward schedule / fence placement
+            if first.size * max(i.shape[1] for i, _ in first.role_blocks) >= 65536:  # a batch worth timing: pick the backward schedule / fence placement
                 self.trainer.calibrate(first)             # for this device and shape (state-neutral, ~0.1 s once)
         self._rebind()
         accumulate = accumulation_steps is not None
         self._enter(accumulate, accumulation_steps)
         state = {"n": 0, "loss_sum": 0.0, "loss_n": 0}
 
+        prints = collections.deque()  # (batch number, pinned host scalar, event): losses on their way to the host
+
+        def flush(wait: bool) -> None:
+            while prints and (wait or prints[0][2].query()):
+                n, host, ev = prints.popleft()
+                ev.synchronize()
+                print(f"Batch {n}, Loss: {float(host):.4f}")
+
         def step(nxt) -> None:
             self.trainer.advance(nxt)
             state["n"] += 1
-            if not accumulate and state["n"] % 10 == 0:  # the reference prints here (training.py:59-61): the one host
-                _, _, last = self.trainer.engine.read_stats(reset=False)  # read per ten batches
-                print(f"Batch {state['n']}, Loss: {last:.4f}")
+            if not accumulate and state["n"] % 10 == 0:
+                # the reference prints this batch's loss here (training.py:59-61).  A synchronous read would drain the
+                # two-deep pipeline every ten batches (measured ~10 us per step at configs[1]); the value is copied out
+                # stream-ordered instead and printed as soon as it has arrived — the same lines in the same order,
+                # a few batches later at most (all of them before the epoch returns)
+                host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+                host.copy_(self.trainer.engine.last_loss(), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                prints.append((state["n"], host, ev))
+            if prints:
+                flush(False)
 
         def grow(b) -> None:
             """`b` does not fit the engine: finish what is in flight, rebuild for b's size (weights, moments, step count,
@@ -345,6 +362,7 @@ class _EngineRoute:
             old = self.trainer
             while old._pending:
                 step(None)
+            flush(True)
             ls, n, _ = old.engine.read_stats(reset=True)
             state["loss_sum"] += ls
             state["loss_n"] += n
@@ -375,6 +393,7 @@ class _EngineRoute:
                 if nxt is not None:
                     nxt = next(it, None)
             tr = self.trainer
+            flush(True)
             ls, n, _ = tr.engine.read_stats(reset=True)
             state["loss_sum"] += ls
             state["loss_n"] += n
@@ -418,9 +437,12 @@ class _EngineRoute:
         tr.engine.read_stats(reset=True)
 
     def _check(self, b) -> None:
-        if b.ids.shape[2] > self.MAX_S:
-            raise ValueError(f"train_epoch(fused): rows of {b.ids.shape[2]} tokens exceed {self.MAX_S} (the tokenizer's "
+        S = max(i.shape[1] for i, _ in b.role_blocks)
+        if S > self.MAX_S:
+            raise ValueError(f"train_epoch(fused): rows of {S} tokens exceed {self.MAX_S} (the tokenizer's "
                              "max_length, backend/model.py:44)")
+        if any(i.dim() != 2 or i.shape[0] != b.size for i, _ in b.role_blocks):
+            raise ValueError("train_epoch(fused): queries, positives and negatives of a batch must have one length")
 
 
 def train_epoch_optimized(model: TwoTowersModel, dataloader, criterion: TripletLoss,
@@ -481,18 +503,26 @@ class TripletBatch:
     # host->device copies on a copy stream); the gather then waits for it.  Not needed for tensors produced on the
     # stream that calls gather(): that stream is fenced anyway.
     ready_event: Optional["torch.cuda.Event"] = None
+    # roles as SEPARATE (input_ids [B, S_r], attention_mask [B, S_r] | None) blocks, the tokenizer's own output per encode
+    # call (backend/model.py:43-48): the engine packs them on the gather stream (tt_engine_pool_roles; single replica,
+    # an engine built with pack_roles=True)
+    role_blocks: Optional[list] = None
 
     @property
     def size(self) -> int:
         for t in (self.ids, self.token_rows, self.cache_rows):
             if t is not None:
                 return t.shape[1]
+        if self.role_blocks is not None:
+            return self.role_blocks[0][0].shape[0]
         raise ValueError("empty TripletBatch")
 
     def expand_negatives(self) -> "TripletBatch":
         """roles 2 + neg_index -> roles 3 (negatives materialised by a row gather)."""
         if self.neg_index is None:
             return self
+        if self.role_blocks is not None:
+            raise ValueError("role_blocks batches carry their negatives as a third block")
         ni = self.neg_index.long()
         cat = lambda t: None if t is None else torch.cat([t, t[1:2].index_select(1, ni)], dim=0).contiguous()
         return TripletBatch(cat(self.ids), cat(self.mask), cat(self.lens), None, cat(self.cache_rows), self.query_ids,
@@ -527,7 +557,8 @@ class TripletTrainer:
                  k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
                  freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: Optional[bool] = False,
                  gather_under_exchange: bool = True, tuning: Optional[dict] = None, event_scope: Optional[int] = None,
-                 fence_at_loss: Optional[bool] = None, grad_slabs: int = 0, join_carries_gather: bool = True):
+                 fence_at_loss: Optional[bool] = None, grad_slabs: int = 0, join_carries_gather: bool = True,
+                 pack_roles: bool = False):
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -563,7 +594,7 @@ class TripletTrainer:
         # nothing process-wide — two trainers in one process may differ
         self.engine = engine if engine is not None else HotPathEngine(table.contiguous(), self.P, max_batch, max_seq_len,
                                                                       k1_blocks_per_cu=k1_blocks_per_cu, tuning=tuning,
-                                                                      grad_slabs=grad_slabs)
+                                                                      grad_slabs=grad_slabs, pack_roles=pack_roles)
         self.engine_k1_cap = int(k1_blocks_per_cu or 0)
         n = self.engine.n_params
         self.flat = torch.cat([t.reshape(-1).float() for t in tensors]).to(self.device).contiguous()
@@ -747,7 +778,8 @@ class TripletTrainer:
             self.side.wait_event(batch.ready_event)
         # K1 reads these tensors on the side stream: tell the caching allocator, so that memory the producer
         # drops right after this call is not handed out again before K1 has finished with it
-        for t in (batch.ids, batch.mask, batch.lens, batch.cache_rows, batch.token_rows):
+        for t in (batch.ids, batch.mask, batch.lens, batch.cache_rows, batch.token_rows,
+                  *(x for blk in (batch.role_blocks or ()) for x in blk)):
             if t is not None:
                 t.record_stream(self.side)
         # launch on the side stream by handle (no stream context switch on the host)
@@ -775,6 +807,10 @@ class TripletTrainer:
             if self.feature_cache is None:
                 raise RuntimeError("batch carries cache_rows but build_feature_cache() has not been called")
             self.engine.pool_cached(slot, self.feature_cache, batch.cache_rows, stream=raw)
+        elif batch.role_blocks is not None:
+            if self.world > 1:
+                raise RuntimeError("role_blocks batches are not sharded: hand a data-parallel trainer packed ids")
+            self.engine.pool_roles(slot, batch.role_blocks, stream=raw)
         elif batch.token_rows is not None:
             if self.token_store is None:
                 raise RuntimeError("batch carries token_rows but set_token_store() has not been called")

@@ -258,6 +258,13 @@ def main():
                          "bucket) with the all-reduce replaced by a kernel of this duration on the caller's stream (where a "
                          "synchronous-op RCCL collective runs) — how much of an N-GPU all-reduce's latency the step would "
                          "expose (RCCL's own CU use is not modelled)")
+    ap.add_argument("--calibrate-k1", action="store_true",
+                    help="calibrate() also times the gather's form on this run's ids where the shape rule picks the binned form "
+                         "(TripletTrainer.calibrate(k1_forms=True)); the pick is in calibration.k1_form")
+    ap.add_argument("--ids-form", default="packed", choices=["packed", "lens", "roles"],
+                    help="diagnostic: how the engine path's batches carry their ids — packed int32 [3,B,S] (headline), the same "
+                         "with full prefix lengths, or the tokenizer's form: three (int64 input_ids, int64 attention_mask) "
+                         "blocks packed by the engine (what the drop-in route hands over)")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="skip TripletTrainer.calibrate() in set-up (it times the two backward schedules on this device "
                          "and keeps the faster; its ~190 dry steps also bring the GPU out of its idle power state)")
@@ -350,7 +357,7 @@ def main():
         return
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
-                    and not args.vocab and not args.lib and not args.zipf and not args.ragged and not args.tuning and args.dp_split is None
+                    and not args.vocab and not args.lib and not args.zipf and not args.ragged and not args.tuning and args.dp_split is None and args.ids_form == "packed"
                     and args.fence_at_loss is None and not args.grad_slabs)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
     # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")
@@ -484,6 +491,8 @@ def run_module_path(args, device) -> dict:
                                          "one gather for the three roles, projection fwd x2 per tower, triplet fwd+bwd, projection "
                                          "bwd x3 + one slab reduction per tower, 1 multi-tensor Adam, ~5 torch ops")},
         "roofline": None, "avg_loss": avg,
+        "calibration": (getattr(getattr(opt, "_tt_route", None), "trainer", None).calibration
+                        if getattr(opt, "_tt_route", None) is not None else None),
     }
 
 
@@ -573,7 +582,8 @@ def run_config(args, world, rank, device) -> dict:
                              split_exchange=({"0": False, "1": True, "auto": None}[args.dp_split] if args.dp_split is not None
                                              else (None if world > 1 else False)),
                              fence_at_loss=(None if args.fence_at_loss is None else bool(args.fence_at_loss)),
-                             grad_slabs=args.grad_slabs, join_carries_gather=bool(args.join_carries_gather))
+                             grad_slabs=args.grad_slabs, join_carries_gather=bool(args.join_carries_gather),
+                             pack_roles=(args.ids_form == "roles"))
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1
@@ -586,6 +596,14 @@ def run_config(args, world, rank, device) -> dict:
                                   torch.randint(min(32, S), S + 1, (B,), generator=gl)]).int() for _ in range(n_distinct)]
         valid_tokens = sum(int(l.sum()) for l in lens_list) / n_distinct
         batches = [(ids, None, l.to(device)) for ids, l in zip(id_batches, lens_list)]
+    if args.ids_form == "lens" and not args.ragged:
+        full = torch.full((3, B), S, dtype=torch.int32, device=device)
+        batches = [(ids, None, full) for ids in id_batches]
+    if args.ids_form == "roles":
+        from two_towers_overlords_amd.training import TripletBatch as _TBr
+
+        ones = torch.ones(B, S, dtype=torch.int64, device=device)
+        batches = [_TBr(role_blocks=[(ids[r].long(), ones) for r in range(3)]) for ids in id_batches]
     if args.loss == "inbatch":
         from two_towers_overlords_amd.training import TripletBatch
 
@@ -689,7 +707,8 @@ def run_config(args, world, rank, device) -> dict:
         e1.record()
     if not args.no_calibrate and not args.k1_only and args.loss == "triplet":
         trainer.calibrate(batches[0], steps=getattr(args, "calibrate_steps", 48),
-                          rounds=getattr(args, "calibrate_rounds", 2))   # set-up: part of what run_training does before its first epoch
+                          rounds=getattr(args, "calibrate_rounds", 2),   # set-up: part of what run_training does before its first epoch
+                          k1_forms=bool(getattr(args, "calibrate_k1", False)))
     set_up_steps = 0  # steps of this workload executed before the timed region besides --warmup
     if trainer.calibration:
         combos = len(trainer.calibration.get("ms_per_step_by_fence") or (0, 0))  # backward schedules x fence placements timed
@@ -764,7 +783,7 @@ def run_config(args, world, rank, device) -> dict:
     tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_k1_traffic_{args.config}.json")))
     if tpaths and not args.zipf and not args.ragged and args.inputs == "ids3":  # the newest round's PMC passes
         tj = json.load(open(tpaths[-1]))
-        if int(tj.get("algorithmic_bytes_per_launch", -1)) == alg and tj.get("kernel", "").split(",")[0] == k1_kernel:
+        if int(tj.get("algorithmic_bytes_per_launch", -1)) == alg and tj.get("kernel", "").split(",")[0].split("*")[0] == k1_kernel:
             traffic = tj["traffic_bytes_per_launch"]
             traffic_source = (os.path.relpath(tpaths[-1], ROOT) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               "workload and kernel (`bench.py --k1-only`), committed; PMC counters are not collected in a timed run")

@@ -53,6 +53,8 @@ typedef enum {
 /* integer element widths accepted for ids / masks */
 #define TT_I32 4
 #define TT_I64 8
+/* a token id that means "padding" (see tt_gather_pool_norm_f32) */
+#define TT_PAD_ID (-2147483647 - 1)
 
 /*
  * Tuning: which of several equivalent kernels / tilings / schedules a call uses.  Every field 0 = "auto", the
@@ -109,7 +111,9 @@ const char* tt_status_string(int status);
  * without materialising the [N,S,D] tensor.
  *
  *   table [V,D] f32, 16-byte aligned, D % 4 == 0
- *   ids   [N,S] int32 or int64 (ids_dtype = TT_I32 / TT_I64)
+ *   ids   [N,S] int32 or int64 (ids_dtype = TT_I32 / TT_I64).  TT_PAD_ID (INT32_MIN; INT64_MIN in int64 ids too) marks
+ *         padding inside the ids themselves: such a token has weight 0 whatever mask / lens say, is never read and never
+ *         reported — every gather form honours it (what tt_engine_pool_roles writes behind the attended tokens)
  *   w:    mask  [N,S] int32/int64 (mask_dtype) attention mask, any 0/1 pattern
  *         (values are cast to float as the reference does, so weights other
  *         than 0/1 are honoured), or, if mask == NULL, lens [N] int32 prefix
@@ -493,8 +497,8 @@ int tt_engine_pool_rows(tt_engine* e, int slot, const void* store_ids, int ids_d
  * K1 over roles handed over the way the reference's tokenizer call returns them (backend/model.py:43-48: one
  * `input_ids` [B, S_r] and one `attention_mask` [B, S_r] per encode call, int64, every role padded to ITS longest
  * text): one pass on `stream` squeezes every text's attended tokens (mask != 0), in order, into int32 ids
- * [n_roles, B, S_max] + prefix lengths in the engine's workspace (tt_engine_config.pack_roles), then K1 runs in its
- * prefix-length form — no [roles, B, S] int64 stacks on the caller's side and no mask re-reads in the gather
+ * [n_roles, B, S_max] (TT_PAD_ID behind them) in the engine's workspace (tt_engine_config.pack_roles), then K1 runs
+ * without mask or lengths — no [roles, B, S] int64 stacks on the caller's side and no mask re-reads in the gather
  * (measured: 17 us of a 210 us step at BASELINE.json configs[1]).  For 0/1 masks this is the reference's masked mean
  * (backend/model.py:63-72: a token with mask 0 adds nothing to either sum), bitwise the prefix-length form for right-padded
  * rows; a mask value other than 0 / 1 (a weight) cannot be expressed: it raises the flag tt_engine_read_stats reports as
@@ -510,6 +514,12 @@ typedef struct {
 } tt_role_tokens;
 int tt_engine_pool_roles(tt_engine* e, int slot, const tt_role_tokens* roles, int32_t n_roles, int32_t B,
                          tt_stream_t stream);
+/* The two halves of tt_engine_pool_roles for a caller whose gather stream is the busier one: the packing pass on one
+ * stream (*S_out = the padded length of the packed rows, the longest role's), the gather over the packed rows of `slot` on
+ * another — ordered by the caller (an event between them).  Same results as the one-call form. */
+int tt_engine_pack_roles(tt_engine* e, int slot, const tt_role_tokens* roles, int32_t n_roles, int32_t B, int32_t* S_out,
+                         tt_stream_t stream);
+int tt_engine_pool_packed(tt_engine* e, int slot, int32_t n_roles, int32_t B, int32_t S, tt_stream_t stream);
 
 /*
  * Phase A from a frozen-feature cache.  The encoder is frozen (backend/model.py:29-30,51), so

@@ -1285,6 +1285,29 @@ def test_engine_pool_rows_is_bitwise_pool_of_the_gathered_rows(tt, V, D, S, B, i
     eng.close()
 
 
+@pytest.mark.parametrize("D,form", [(384, "per_text"), (384, "columns"), (388, "rows"), (64, "binned"), (384, "stream"), (101, "per_text")])
+def test_pad_id_inside_the_ids_is_a_masked_token_in_every_gather_form(tt, D, form):
+    """TT_PAD_ID (INT32_MIN / INT64_MIN): padding marked in the ids themselves — weight 0 with no mask and no lengths
+    given, never read, never reported as out of range; bitwise what the same tokens give with prefix lengths (and a text
+    that is ALL padding takes the reference's clamp path, backend/model.py:70-72)."""
+    ops, _ = tt
+    V, N, S = 3000, 90, 70
+    gen = torch.Generator().manual_seed(5 + D)
+    table = (orc.synthetic_table(V, D, seed=1) * 30).cuda()
+    lens = torch.randint(0, S + 1, (N,), generator=gen)
+    lens[0], lens[1] = 0, S
+    for idt, pad in ((torch.int32, -2 ** 31), (torch.int64, -2 ** 63)):
+        ids = torch.randint(0, V, (N, S), generator=gen).to(idt)
+        marked = torch.where(torch.arange(S).unsqueeze(0) < lens.unsqueeze(1), ids, torch.full_like(ids, pad))
+        kw = dict(stream_form=2) if form == "stream" else dict(form=form)
+        a = ops.gather_pool_norm(table, marked.cuda(), check_ids=True, **kw)
+        b = ops.gather_pool_norm(table, ids.cuda(), lens=lens.int().cuda(), **kw)
+        assert torch.equal(a, b)
+        c = ops.gather_pool_norm(table, marked.cuda(), lens=torch.full((N,), S, dtype=torch.int32).cuda(), **kw)
+        assert torch.equal(a, c)                                              # the marker wins over a length that covers it
+    assert float(a[0].abs().max()) == 0.0                                     # all padding: 0 / clamp(0, 1e-9), normalised 0
+
+
 @pytest.mark.parametrize("V,D,idt,form", [(30522, 384, torch.int64, None), (800, 100, torch.int32, None),
                                           (30522, 384, torch.int64, "per_text"), (250000, 64, torch.int64, "stream")])
 def test_engine_pool_roles_packs_the_tokenizers_blocks(tt, V, D, idt, form):

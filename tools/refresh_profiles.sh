@@ -2,7 +2,7 @@
 # Runs the bench modes reported in DESIGN.md section 5 on ONE box and writes the JSON lines, rocprofv3 kernel stats,
 # timelines, MFMA utilisation and K1 fabric-traffic (PMC) summaries to gpurun_out/refresh/ (copied into profiles/ afterwards).
 #   usage: tools/refresh_profiles.sh [rNN]         (every variant is a bench argument: nothing reads the environment)
-r=${1:-r04}
+r=${1:-r05}
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/refresh; mkdir -p $out
 cd $root
 B="python bench.py --no-cpu-baseline --no-secondary"
@@ -22,6 +22,10 @@ $B --loss inbatch --batch 512 > $out/${r}_bench_inbatch_b512_share.json
 $B --config c3 > $out/${r}_bench_c3_share.json
 $B --config c4 --steps 40 --warmup 8 > $out/${r}_bench_c4_full.json
 $B --config c4 --steps 40 --warmup 8 --tune k1_form=stream > $out/${r}_bench_c4_stream_form.json
+$B --config c4 --steps 40 --warmup 8 --zipf > $out/${r}_bench_c4_zipf.json      # real-text-like id skew: which K1 form the policy picks is in roofline.kernel
+$B --config c4 --steps 40 --warmup 8 --ragged > $out/${r}_bench_c4_ragged.json  # ragged prefix lengths (queries U{8..S}, documents U{32..S})
+$B --config c4 --steps 40 --warmup 8 --zipf --tune k1_form=stream > $out/${r}_bench_c4_zipf_stream_form.json
+$B --config c4 --steps 40 --warmup 8 --ragged --tune k1_form=stream > $out/${r}_bench_c4_ragged_stream_form.json
 $B --config c4 --steps 20 --warmup 4 --no-overlap > $out/${r}_bench_c4_no_overlap.json
 $B --config c4 --steps 12 --warmup 4 --inputs index > $out/${r}_bench_c4_inputs_index.json
 echo "benches done"

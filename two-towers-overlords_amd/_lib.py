@@ -160,6 +160,8 @@ SIGNATURES = {
     "tt_engine_pool": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i32, _i32, _i32, _vp]),
     "tt_engine_pool_cached": (_i, [_vp, _i, _vp, _i64, _vp, _i, _i32, _i32, _vp]),
     "tt_engine_pool_roles": (_i, [_vp, _i, C.POINTER(TTRoleTokens), _i32, _i32, _vp]),
+    "tt_engine_pack_roles": (_i, [_vp, _i, C.POINTER(TTRoleTokens), _i32, _i32, C.POINTER(_i32), _vp]),
+    "tt_engine_pool_packed": (_i, [_vp, _i, _i32, _i32, _i32, _vp]),
     "tt_engine_fwd_bwd": (_i, [_vp, _i, _i32, _vp, _f, _f, _f, _vp]),
     "tt_engine_forward": (_i, [_vp, _i, _i32, _i32, _vp]),
     "tt_engine_backward": (_i, [_vp, _i, _i32, _i32, _vp]),

@@ -434,13 +434,13 @@ __global__ __launch_bounds__(256) void pack_roles_kernel(const PackRoles a, int 
     if (keep) dst[pos] = (id < 0 || id > 0x7fffffffLL) ? -1 : (int32_t)id;
     count += __popcll(b);
   }
-  for (int tok = count + lane; tok < S_out; tok += 64) dst[tok] = 0;
+  for (int tok = count + lane; tok < S_out; tok += 64) dst[tok] = (int32_t)TT_PAD_ID32;  // padding marked in the ids themselves
   if (lane == 0) out_lens[t] = count;
   if (__any(weird) && lane == 0) atomicOr(flags + 1, 1);
 }
 
-extern "C" int tt_engine_pool_roles(tt_engine* e, int slot, const tt_role_tokens* roles, int32_t n_roles, int32_t B,
-                                    tt_stream_t stream) {
+static int pack_roles(tt_engine* e, int slot, const tt_role_tokens* roles, int32_t n_roles, int32_t B, int* S_out_p,
+                      hipStream_t st) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(roles, TT_ERR_NULL_POINTER);
   TT_REQUIRE(e->cfg.pack_roles, TT_ERR_WORKSPACE);  // the handle was created without the staging area
@@ -460,10 +460,36 @@ extern "C" int tt_engine_pool_roles(tt_engine* e, int slot, const tt_role_tokens
     S_out = roles[r].S > S_out ? roles[r].S : S_out;
   }
   const long long texts = (long long)n_roles * B;
-  hipLaunchKernelGGL(pack_roles_kernel, dim3((unsigned)((texts + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a, (int)B,
-                     S_out, e->stage_ids[slot], e->stage_lens[slot], e->oob);
+  hipLaunchKernelGGL(pack_roles_kernel, dim3((unsigned)((texts + 3) / 4)), dim3(256), 0, st, a, (int)B, S_out,
+                     e->stage_ids[slot], e->stage_lens[slot], e->oob);
   TT_CHECK_LAUNCH();
-  return engine_k1(e, slot, e->stage_ids[slot], TT_I32, nullptr, TT_I32, e->stage_lens[slot], n_roles, B, S_out, nullptr, 0, stream);
+  *S_out_p = S_out;
+  return TT_OK;
+}
+
+extern "C" int tt_engine_pack_roles(tt_engine* e, int slot, const tt_role_tokens* roles, int32_t n_roles, int32_t B,
+                                    int32_t* S_out, tt_stream_t stream) {
+  TT_REQUIRE(S_out, TT_ERR_NULL_POINTER);
+  int s = 0;
+  const int rc = pack_roles(e, slot, roles, n_roles, B, &s, static_cast<hipStream_t>(stream));
+  *S_out = s;
+  return rc;
+}
+
+extern "C" int tt_engine_pool_packed(tt_engine* e, int slot, int32_t n_roles, int32_t B, int32_t S, tt_stream_t stream) {
+  TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
+  TT_REQUIRE(e->cfg.pack_roles, TT_ERR_WORKSPACE);
+  TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
+  // no mask and no lengths: the packed rows mark their own padding (TT_PAD_ID32)
+  return engine_k1(e, slot, e->stage_ids[slot], TT_I32, nullptr, TT_I32, nullptr, n_roles, B, S, nullptr, 0, stream);
+}
+
+extern "C" int tt_engine_pool_roles(tt_engine* e, int slot, const tt_role_tokens* roles, int32_t n_roles, int32_t B,
+                                    tt_stream_t stream) {
+  int S_out = 0;
+  const int rc = pack_roles(e, slot, roles, n_roles, B, &S_out, static_cast<hipStream_t>(stream));
+  if (rc != TT_OK) return rc;
+  return engine_k1(e, slot, e->stage_ids[slot], TT_I32, nullptr, TT_I32, nullptr, n_roles, B, S_out, nullptr, 0, stream);
 }
 
 extern "C" int tt_engine_pool_cached(tt_engine* e, int slot, const float* cache, int64_t cache_rows,

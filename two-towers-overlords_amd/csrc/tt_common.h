@@ -37,6 +37,11 @@ static inline unsigned tt_event_flags(int scope) {
   return hipEventDisableTiming | (scope == 1 ? hipEventDisableSystemFence : scope == 2 ? hipEventReleaseToDevice : 0u);
 }
 
+// the id that marks padding inside an ids array (gather_pool.hip, tt_is_pad)
+#ifndef TT_PAD_ID32
+#define TT_PAD_ID32 (-2147483647LL - 1LL)
+#endif
+
 static inline bool tt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #ifdef __HIPCC__

@@ -44,7 +44,7 @@ class HotPathEngine:
         forced = _lib.make_tuning(tuning or {}).k1_form  # the partial-sum workspace is sized for a form a tuning will force
         cfg = TTEngineConfig(self.V, self.D, self.P, self.max_B, self.max_S, self.device.index or 0, int(k1_blocks_per_cu),
                              int(grad_slabs), int(forced), 1 if pack_roles else 0)
-        self.pack_roles = bool(pack_roles)
+        self.has_pack_roles = bool(pack_roles)
         lib = _lib.load()
         nbytes = lib.tt_engine_workspace_bytes(C.byref(cfg))
         if nbytes == 0:
@@ -120,11 +120,7 @@ class HotPathEngine:
         call("tt_engine_pool", self._h, slot, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7],
              self._stream() if stream is None else stream)
 
-    def pool_roles(self, slot: int, blocks, stream: Optional[int] = None) -> None:
-        """K1 over roles given as separate (input_ids [B, S_r], attention_mask [B, S_r] | None) blocks — what the
-        reference's tokenizer call returns per encode (backend/model.py:43-48) — packed to int32 ids + prefix lengths
-        on `stream` by the engine (tt_engine_pool_roles; needs HotPathEngine(pack_roles=True)).  0/1 masks only: a
-        weight mask raises at the next read_stats()."""
+    def _role_array(self, blocks):
         if len(blocks) not in (2, 3):
             raise ValueError("pool_roles: 2 or 3 roles (q, pos[, neg])")
         arr = (_lib.TTRoleTokens * len(blocks))()
@@ -139,7 +135,26 @@ class HotPathEngine:
                 if mask.dtype not in _INT_WIDTH or tuple(mask.shape) != tuple(ids.shape) or mask.device != self.device:
                     raise ValueError("pool_roles: mask must be an int32/int64 tensor of the ids' shape")
                 arr[r].mask, arr[r].mask_dtype = mask.data_ptr(), _INT_WIDTH[mask.dtype]
+        return arr, B
+
+    def pool_roles(self, slot: int, blocks, stream: Optional[int] = None) -> None:
+        """K1 over roles given as separate (input_ids [B, S_r], attention_mask [B, S_r] | None) blocks — what the
+        reference's tokenizer call returns per encode (backend/model.py:43-48) — packed to int32 ids + prefix lengths
+        on `stream` by the engine (tt_engine_pool_roles; needs HotPathEngine(pack_roles=True)).  0/1 masks only: a
+        weight mask raises at the next read_stats()."""
+        arr, B = self._role_array(blocks)
         call("tt_engine_pool_roles", self._h, slot, arr, len(blocks), B, self._stream() if stream is None else stream)
+
+    def pack_roles(self, slot: int, blocks, stream: Optional[int] = None) -> int:
+        """The packing half of pool_roles on `stream`; returns the packed rows' padded length for pool_packed()."""
+        arr, B = self._role_array(blocks)
+        S = C.c_int32(0)
+        call("tt_engine_pack_roles", self._h, slot, arr, len(blocks), B, C.byref(S), self._stream() if stream is None else stream)
+        return int(S.value)
+
+    def pool_packed(self, slot: int, roles: int, B: int, S: int, stream: Optional[int] = None) -> None:
+        """The gather half of pool_roles over the rows pack_roles() left in `slot` (order the two streams yourself)."""
+        call("tt_engine_pool_packed", self._h, slot, roles, B, S, self._stream() if stream is None else stream)
 
     def pool_rows(self, slot: int, store_ids: torch.Tensor, store_lens: Optional[torch.Tensor], rows: torch.Tensor,
                   stream: Optional[int] = None) -> None:

@@ -695,6 +695,11 @@ class TripletTrainer:
             self._loss_event, self._use_loss_fence, self._fence_arg = None, False, fence_at_loss
             self._join_carries_gather = False
         self._loss_armed = False              # tt_engine_arm_loss_event's current value
+        self._prep = self._prep_fence = None  # third stream for the role-packing pass of role_blocks batches (see _timed_pool)
+        if pack_roles and self.side is not None and self.event_scope != 3:
+            self._prep = torch.cuda.Stream(self.device)
+            self._pack_done = [_lib.StreamEvent(self.event_scope) for _ in range(self.SLOTS)]
+            self._prep.wait_stream(torch.cuda.current_stream(self.device))  # behind tt_engine_create's workspace memset
         # With a gradient exchange the next gather sits UNDER the exchange and the chain runs alone on the chip: there the
         # fused backward (one stream, no fork / join events) is the shorter one — the fork's events cost 11 + 7 us of gaps
         # at configs[2]'s share (gpurun_out/r05_base/timeline_c3_x60.txt) and nothing shares the chip to fill them.  The
@@ -774,6 +779,10 @@ class TripletTrainer:
                 fence2 = self._slot_fence2[slot]
                 fence2.record(self._apply_stream)
                 fence2.wait(self.side)
+        # the packing pass of a role_blocks batch may run on the third stream behind this ONE fence — not when the order
+        # also hangs on a second fence or on the producer's own event
+        self._prep_fence = fence if (batch.ready_event is None and
+                                     (self._apply_stream is None or cur == self._apply_stream)) else None
         if batch.ready_event is not None:  # produced on a stream of its own (a copy stream)
             self.side.wait_event(batch.ready_event)
         # K1 reads these tensors on the side stream: tell the caching allocator, so that memory the producer
@@ -782,6 +791,8 @@ class TripletTrainer:
                   *(x for blk in (batch.role_blocks or ()) for x in blk)):
             if t is not None:
                 t.record_stream(self.side)
+                if self._prep is not None and batch.role_blocks is not None:
+                    t.record_stream(self._prep)
         # launch on the side stream by handle (no stream context switch on the host)
         self._timed_pool(slot, batch, self.side)
         ev = self._slot_ready[slot]
@@ -810,7 +821,18 @@ class TripletTrainer:
         elif batch.role_blocks is not None:
             if self.world > 1:
                 raise RuntimeError("role_blocks batches are not sharded: hand a data-parallel trainer packed ids")
-            self.engine.pool_roles(slot, batch.role_blocks, stream=raw)
+            if self._prep is not None and stream is not None and self._prep_fence is not None:
+                # The gather stream is the busier one (it runs K1 back to back): the packing pass goes on a third stream,
+                # ordered behind the same fence as the gather, and the gather waits for it — by then it has long finished
+                # (the gather of the batch before is still running when this one is enqueued)
+                self._prep_fence.wait(self._prep)
+                S = self.engine.pack_roles(slot, batch.role_blocks, stream=self._prep.cuda_stream)
+                ev = self._pack_done[slot]
+                ev.record(self._prep)
+                ev.wait(stream)
+                self.engine.pool_packed(slot, len(batch.role_blocks), batch.size, S, stream=raw)
+            else:
+                self.engine.pool_roles(slot, batch.role_blocks, stream=raw)
         elif batch.token_rows is not None:
             if self.token_store is None:
                 raise RuntimeError("batch carries token_rows but set_token_store() has not been called")
@@ -1062,7 +1084,7 @@ class TripletTrainer:
             self.engine.set_step(self.step_count)
 
     # -- calibration ----------------------------------------------------------------------
-    def calibrate(self, batch: Batch, steps: int = 48, rounds: int = 2) -> dict:
+    def calibrate(self, batch: Batch, steps: int = 48, rounds: int = 2, k1_forms: bool = False) -> dict:
         """Time the step's equivalent schedules on THIS device with THIS batch shape, in the regime the trainer will run
         in, and keep the fastest: phase B's two backward schedules (include/tt_hotpath.h, tt_engine_set_backward), where
         the gather's slot fence comes from (single replica), and — with a gradient exchange whose form the caller left
@@ -1074,7 +1096,12 @@ class TripletTrainer:
         candidates write bitwise the same gradients, so the choice never changes a training run's parameters.
         Parameters, Adam state, step counters, the gradient bucket and loss statistics are untouched (no optimizer).
         A side effect worth knowing: the dry steps also bring the GPU from its idle power state to sustained clocks,
-        which otherwise takes the first ~70 training steps."""
+        which otherwise takes the first ~70 training steps.
+        `k1_forms=True` (opt-in) adds the gather's form as a candidate where the shape rule picks the binned form: that
+        rule assumes every table row is named about equally often, and on THIS batch's ids the streaming form may be
+        the faster one (log-uniform ids at configs[3]: 4.4 vs 5.6+ ms per step, profiles/r05_c4_skew.txt).  Unlike the
+        other candidates the two forms differ in fp32 summation order, so this choice moves results by rounding — which
+        is why it is not on by default: a run that must be bitwise repeatable fixes the form in `tuning`."""
         if self._pending:
             raise RuntimeError("calibrate(): call it between epochs (batches are still in flight)")
         if self.device.type != "cuda" or not hasattr(self.engine, "set_backward") or self.loss_kind != "triplet":
@@ -1086,15 +1113,22 @@ class TripletTrainer:
         fences = (False, True) if (self.side is not None and self._loss_event is not None and self._fence_arg is None) else (self._use_loss_fence,)
         # third: the exchange in one bucket or two parts — only where the caller left it open
         forms = (False, True) if (self._exchange and self._split_auto) else (self._split,)
-        times = {(m, f, sp): [] for m in ("fused", "fork") for f in fences for sp in forms}
+        base_tuning = dict(self.engine.tuning or {}) if hasattr(self.engine, "tuning") else {}
+        gathers = (None,)
+        if (k1_forms and hasattr(self.engine, "set_tuning") and not base_tuning.get("k1_form") and b.ids is not None
+                and _lib.load().tt_k1_prefers_binned(self.engine.V, self.D, b.ids.shape[0] * b.size, b.ids.shape[2])):
+            gathers = (None, "stream")
+        times = {(m, f, sp, kf): [] for m in ("fused", "fork") for f in fences for sp in forms for kf in gathers}
         self._dry = True
         if self._exchange and self.bucket is not None:
             self._dry_bucket = torch.zeros_like(self.bucket)  # the real bucket may hold an un-applied accumulation window
         try:
             for _ in range(rounds):
-                for mode, fence, sp in times:
+                for mode, fence, sp, kf in times:
                     self._use_loss_fence = fence
                     self._split = sp
+                    if len(gathers) > 1:
+                        self.engine.set_tuning({**base_tuning, **({"k1_form": kf} if kf else {})})
                     self.engine.set_backward(mode)
                     while len(self._pending) < depth:
                         self.gather(b)
@@ -1106,7 +1140,7 @@ class TripletTrainer:
                     while self._pending:
                         self.apply(None)
                     e1.synchronize()
-                    times[(mode, fence, sp)].append(e0.elapsed_time(e1) / steps)
+                    times[(mode, fence, sp, kf)].append(e0.elapsed_time(e1) / steps)
         finally:
             self._dry = False
             self._dry_bucket = None
@@ -1117,6 +1151,8 @@ class TripletTrainer:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
             best = {kf: float(t[i]) for i, kf in enumerate(keys)}
         pick = min(best, key=best.get)
+        if len(gathers) > 1:
+            self.engine.set_tuning({**base_tuning, **({"k1_form": pick[3]} if pick[3] else {})})
         self.engine.set_backward(pick[0])
         self._use_loss_fence = pick[1]
         self._split = pick[2]
@@ -1126,8 +1162,9 @@ class TripletTrainer:
                             "regime": ("data-parallel step: slab reduce + exchange inside the timed dry steps, the gather under "
                                        "the exchange" if self._exchange else "single replica: gathers beside the chain"),
                             "ms_per_step": {m: min(best[kf] for kf in keys if kf[0] == m) for m in ("fused", "fork")},
-                            "ms_per_step_by_fence": {f"{m},{'loss' if f else 'own'}" + (",two-part" if sp else ""): best[(m, f, sp)]
-                                                     for m, f, sp in keys},
+                            "k1_form": (pick[3] or "shape rule") if len(gathers) > 1 else None,
+                            "ms_per_step_by_fence": {f"{m},{'loss' if f else 'own'}" + (",two-part" if sp else "") + (f",k1={kf}" if kf else ""):
+                                                     best[(m, f, sp, kf)] for m, f, sp, kf in keys},
                             "steps": steps, "rounds": rounds}
         return self.calibration
 

@@ -851,7 +851,15 @@ class TripletTrainer:
             raise ValueError("set_token_store: ids must be [N, S] on the trainer's device")
         if ids.shape[1] > self.engine.max_S:
             raise ValueError(f"set_token_store: rows of {ids.shape[1]} tokens exceed the engine's max_seq_len")
-        self.token_store = (ids.contiguous(), None if lens is None else lens.to(torch.int32).contiguous())
+        if lens is not None:
+            # The lengths go INTO the rows: tokens behind a text's length become TT_PAD_ID (weight 0 in every gather form,
+            # include/tt_hotpath.h), and the gather runs without a per-text length load — beside the projection chain that
+            # dependent load cost the column-sliced gather 12 us per configs[1] launch (profiles/r05_module_path.txt); a whole
+            # epoch through the loader: 10.65 -> 11.04 M triplets/s (192.3 -> 185.5 us per step, same box, interleaved).
+            pad = -(2 ** 31) if ids.dtype == torch.int32 else -(2 ** 63)
+            keep = torch.arange(ids.shape[1], device=ids.device).unsqueeze(0) < lens.to(ids.device).unsqueeze(1)
+            ids = torch.where(keep, ids, torch.full((), pad, dtype=ids.dtype, device=ids.device))
+        self.token_store = (ids.contiguous(), None)
 
     @torch.no_grad()
     def build_feature_cache(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None,

@@ -284,6 +284,10 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
                     help="a tt_tuning field for this run's engine (include/tt_hotpath.h), e.g. --tune k1_form=stream "
                          "--tune proj_tile=22; repeatable.  Speed only; recorded in config.tuning")
+    ap.add_argument("--trainer", action="append", default=[], metavar="FIELD=VALUE",
+                    help="a TrainerConfig field for this run's TripletTrainer (two-towers-overlords_amd/training.py), e.g. "
+                         "--trainer join_carries_gather=false --trainer accumulation_steps=2; repeatable; recorded in "
+                         "config.trainer.  (the older single-purpose flags below set the same fields)")
     ap.add_argument("--event-scope", type=int, default=None, choices=[1, 2, 3],
                     help="release scope of the events that order the gather stream and the caller's stream, and the engine's "
                          "two streams (1 no system-scope fence [default], 2 device-scope release, 3 HIP's default events)")
@@ -317,6 +321,20 @@ def main():
         k, _, v = kv.partition("=")
         args.tuning[k] = v if not v.lstrip("-").isdigit() else int(v)
 
+    def _val(v):
+        lv = v.lower()
+        if lv in ("none", "null"):
+            return None
+        if lv in ("true", "false"):
+            return lv == "true"
+        for cast in (int, float):
+            try:
+                return cast(v)
+            except ValueError:
+                pass
+        return v
+
+    args.trainer_cfg = {kv.partition("=")[0]: _val(kv.partition("=")[2]) for kv in args.trainer}
     if args.lib:
         from two_towers_overlords_amd import _lib as _ttl
         _ttl.LIB_PATH = os.path.abspath(args.lib)
@@ -357,7 +375,7 @@ def main():
         return
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
-                    and not args.vocab and not args.lib and not args.zipf and not args.ragged and not args.tuning and args.dp_split is None and args.ids_form == "packed"
+                    and not args.vocab and not args.lib and not args.zipf and not args.ragged and not args.tuning and args.dp_split is None and args.ids_form == "packed" and not args.trainer
                     and args.fence_at_loss is None and not args.grad_slabs)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
     # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")
@@ -575,7 +593,7 @@ def run_config(args, world, rank, device) -> dict:
                 if self._cycles > 0:
                     torch.cuda._sleep(self._cycles)
 
-    trainer = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3,
+    tkw = dict(margin=0.3, lr=1e-3,
                              overlap_streams=(False if (args.no_overlap or args.k1_only) else None),
                              k1_blocks_per_cu=args.k1_blocks_per_cu, use_graphs=bool(args.graphs), loss=args.loss,
                              tuning=(args.tuning or None),
@@ -584,6 +602,8 @@ def run_config(args, world, rank, device) -> dict:
                              fence_at_loss=(None if args.fence_at_loss is None else bool(args.fence_at_loss)),
                              grad_slabs=args.grad_slabs, join_carries_gather=bool(args.join_carries_gather),
                              pack_roles=(args.ids_form == "roles"))
+    tkw.update(getattr(args, "trainer_cfg", {}))  # --trainer FIELD=VALUE wins over the single-purpose flags
+    trainer = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, **tkw)
     if trainer.use_graphs:
         trainer.eager_every = 8   # every 8th step is launched kernel by kernel, with HIP events around its K1
         trainer.k1_event_every = 1
@@ -862,6 +882,7 @@ def run_config(args, world, rank, device) -> dict:
                    + ("zipf" if args.zipf else "uniform") + (", ragged lengths" if args.ragged else ", full length"), "parallelism": f"dp{world}", "inputs": args.inputs,
                    "k1_only": bool(args.k1_only), "tuning": (trainer.engine.tuning or None),
                    "event_scope": getattr(trainer, "event_scope", None), "grad_slabs": trainer.engine.n_slabs,
+                   "trainer": (getattr(args, "trainer_cfg", None) or None),
                    "gather_overlap": ("side stream, " + ("K1's LDS reservation paired with the projection tile (auto)"
                                                        if trainer.engine_k1_cap < 0 else
                                                        "K1 capped at %d workgroups/CU" % trainer.engine_k1_cap))

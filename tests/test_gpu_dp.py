@@ -245,6 +245,50 @@ def test_data_parallel_step_over_rccl_single_rank_is_the_single_replica_step():
     assert np.array_equal(f0, f2)  # the two-part exchange (split_exchange=True): its early part on a second stream
 
 
+def _dp_calibrate_worker(rank, world, port, q):
+    try:
+        from two_towers_overlords_amd.training import TrainerConfig, TripletTrainer
+
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        table, params, _, gb = _setup()
+        dev_batches = [tuple(None if t is None else t.cuda() for t in b) for b in gb]
+        out = {}
+        for name, split in (("fixed", False), ("auto", None)):
+            tr = TripletTrainer(table=table.cuda(), params={k: v.cuda() for k, v in params.items()}, max_batch=B, max_seq_len=S,
+                                config=TrainerConfig(margin=0.3, lr=1e-3, exchange=True, split_exchange=split, accumulation_steps=2))
+            tr.train_epoch(dev_batches)                      # leaves an un-applied gradient in the bucket (3 batches, k = 2)
+            before = [t.clone() for t in (tr.flat, tr.exp_avg, tr.exp_avg_sq, tr.bucket)]
+            state = (tr.step_count, tr._micro, tr._carry)
+            cal = tr.calibrate(dev_batches[0], steps=6, rounds=1)
+            same = all(torch.equal(a, b) for a, b in zip(before, (tr.flat, tr.exp_avg, tr.exp_avg_sq, tr.bucket)))
+            out[name] = (cal, same, state == (tr.step_count, tr._micro, tr._carry), tr._split,
+                         [tr.train_epoch(dev_batches) for _ in range(2)], tr.flat.cpu().numpy().copy())
+        q.put(("ok", out, None))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put(("error", f"{e}\n{traceback.format_exc()}", None))
+        raise
+
+
+def test_calibrate_times_the_data_parallel_step_and_leaves_the_run_untouched():
+    """Round 5: with a gradient exchange calibrate()'s dry steps are the data-parallel step itself (slab reduce into a
+    scratch bucket, the gather under the real RCCL collective) and, where the caller left the exchange form open
+    (split_exchange=None), both forms are candidates.  Nothing of the run moves: parameters, Adam moments, step counters
+    and an un-applied accumulation window in the bucket; the epochs that follow are the same whatever was picked."""
+    out = _ranks(_dp_calibrate_worker, 1, salt=91)[1]
+    cal, same, counters, split, losses_f, flat_f = out["fixed"]
+    assert cal["regime"].startswith("data-parallel") and cal["exchange_form"] == "one-bucket" and not split
+    assert same and counters and not any("two-part" in k for k in cal["ms_per_step_by_fence"])
+    cal_a, same_a, counters_a, split_a, losses_a, flat_a = out["auto"]
+    assert same_a and counters_a and any("two-part" in k for k in cal_a["ms_per_step_by_fence"])
+    assert cal_a["exchange_form"] == ("two-part" if split_a else "one-bucket")
+    assert losses_f == losses_a and np.array_equal(flat_f, flat_a)   # both exchange forms sum the same elements
+
+
 # --------------------------------------------------------------------------- two-part exchange, two ranks
 def _split_worker(rank, world, port, backend, q):
     try:

@@ -533,6 +533,36 @@ def as_batch(b) -> TripletBatch:
     return b if isinstance(b, TripletBatch) else TripletBatch(*b)
 
 
+@dataclasses.dataclass
+class TrainerConfig:
+    """Every knob of TripletTrainer in one place (bench.py mirrors it: `--trainer FIELD=VALUE`).  The first block is the
+    reference's hyper-parameters (backend/training.py:383-397, :436); the rest steer HOW the same arithmetic is run —
+    none of them changes a result beyond fp32 summation order, and only `tuning["k1_form"]` does even that."""
+
+    # -- what is computed (backend/training.py:433-436: TripletLoss(margin), Adam(lr), defaults of torch.optim.Adam)
+    margin: float = 0.3
+    lr: float = 1e-3
+    betas: tuple = (0.9, 0.999)
+    eps: float = 1e-8
+    accumulation_steps: int = 1          # backend/training.py:66-133: loss / k, optimizer step every k-th batch of an epoch
+    loss: str = "triplet"                # "triplet" (the reference's sampled negative) | "inbatch" (BASELINE.json configs[4])
+    # -- how the two streams share the chip
+    overlap_streams: Optional[bool] = None   # gathers of the next batches on a side stream (None: on a GPU with the HIP engine)
+    k1_blocks_per_cu: Optional[int] = None   # tt_engine_config.k1_blocks_per_cu (None: TT_K1_SHARE_AUTO with a side stream)
+    tuning: Optional[dict] = None            # tt_tuning fields for this trainer's engine (include/tt_hotpath.h)
+    grad_slabs: int = 0                      # split-K slabs of the weight-gradient GEMMs (0: the engine's rule)
+    event_scope: Optional[int] = None        # release scope of the cross-stream events: 1 no system fence (default), 2, 3
+    fence_at_loss: Optional[bool] = None     # the gather's slot fence = the engine's loss event (None: calibrate() decides)
+    join_carries_gather: bool = True         # the fork backward's join also carries the wait for the next gather
+    use_graphs: Optional[bool] = None        # hipGraph replay of whole steps (opt-in; slower on ROCm 7.2)
+    pack_roles: bool = False                 # engine staging for role_blocks batches (the drop-in train_epoch route)
+    freeze_gc: bool = True                   # gc.freeze() once before the first epoch
+    # -- data parallel
+    exchange: Optional[bool] = None          # gradients are exchanged (None: iff more than one replica; True on one rank: tests)
+    split_exchange: Optional[bool] = False   # the exchange in two parts (None: calibrate() times both forms on the fabric)
+    gather_under_exchange: bool = True       # the next gather is issued right before the exchange
+
+
 class TripletTrainer:
     """The batch body of backend/training.py:36-53 on the fused engine.
 
@@ -551,14 +581,18 @@ class TripletTrainer:
     SLOTS = 3  # == TT_ENGINE_SLOTS (include/tt_hotpath.h)
 
     def __init__(self, model: Optional[TwoTowersModel] = None, *, table: Optional[torch.Tensor] = None,
-                 params: Optional[dict] = None, max_batch: int, max_seq_len: int, margin: float = 0.3,
-                 lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, accumulation_steps: int = 1,
-                 process_group=None, engine=None, overlap_streams: Optional[bool] = None,
-                 k1_blocks_per_cu: Optional[int] = None, use_graphs: Optional[bool] = None, loss: str = "triplet",
-                 freeze_gc: bool = True, exchange: Optional[bool] = None, split_exchange: Optional[bool] = False,
-                 gather_under_exchange: bool = True, tuning: Optional[dict] = None, event_scope: Optional[int] = None,
-                 fence_at_loss: Optional[bool] = None, grad_slabs: int = 0, join_carries_gather: bool = True,
-                 pack_roles: bool = False):
+                 params: Optional[dict] = None, max_batch: int, max_seq_len: int, config: Optional["TrainerConfig"] = None,
+                 process_group=None, engine=None, **overrides):
+        """`config`: a TrainerConfig (every knob with its default and its meaning in one place); any of its fields may
+        also be given by keyword (`TripletTrainer(model, max_batch=..., max_seq_len=..., lr=1e-4, loss="inbatch")`),
+        which overrides the config's value.  `engine`: an injected engine (tests); `process_group`: the replicas."""
+        cfg = dataclasses.replace(config or TrainerConfig(), **overrides)  # an unknown keyword raises TypeError, like a signature
+        self.config = cfg
+        (margin, lr, betas, eps, accumulation_steps, loss, overlap_streams, k1_blocks_per_cu, use_graphs, freeze_gc, exchange,
+         split_exchange, gather_under_exchange, tuning, event_scope, fence_at_loss, grad_slabs, join_carries_gather, pack_roles) = (
+            cfg.margin, cfg.lr, cfg.betas, cfg.eps, cfg.accumulation_steps, cfg.loss, cfg.overlap_streams, cfg.k1_blocks_per_cu,
+            cfg.use_graphs, cfg.freeze_gc, cfg.exchange, cfg.split_exchange, cfg.gather_under_exchange, cfg.tuning,
+            cfg.event_scope, cfg.fence_at_loss, cfg.grad_slabs, cfg.join_carries_gather, cfg.pack_roles)
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed

@@ -378,7 +378,7 @@ def main():
                     and not args.vocab and not args.lib and not args.zipf and not args.ragged and not args.tuning and args.dp_split is None and args.ids_form == "packed" and not args.trainer
                     and args.fence_at_loss is None and not args.grad_slabs)
     # on the default line the GPU legs run back to back (headline, then `secondary`) and the ~30 s of CPU baselines come
-    # last: a GPU that has idled through them starts the next GPU leg in its power ramp (DESIGN.md §5 "Cold start")
+    # last: a GPU that has idled through them starts the next GPU leg in its power ramp (docs/LOG_r04.md §5 "Cold start")
     args.cpu_baseline_later = bool(rank == 0 and world == 1 and default_line and not args.no_secondary)
     result = run_config(args, world, rank, device)
     if rank == 0 and world == 1 and default_line:
@@ -719,7 +719,7 @@ def run_config(args, world, rank, device) -> dict:
             torch.cuda.synchronize(device)
         del a
     # (every piece of host-side set-up goes BEFORE calibrate(): its dry steps bring the GPU to its sustained power state, and
-    #  a millisecond of idleness afterwards already costs the next ~30 steps a few percent — DESIGN.md section 5, "Cold start")
+    #  a millisecond of idleness afterwards already costs the next ~30 steps a few percent — docs/LOG_r04.md section 5, "Cold start")
     trainer.k1_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                              for _ in range(args.steps // max(trainer.k1_event_every, 1) + 8)]
     for e0, e1 in trainer.k1_event_pool:  # torch creates the HIP event at its first record(): do that now

@@ -58,7 +58,7 @@ typedef enum {
 
 /*
  * Tuning: which of several equivalent kernels / tilings / schedules a call uses.  Every field 0 = "auto", the
- * measured-best choice for the shape (DESIGN.md sections 3, 5, 8).  Speed only: no field changes a result beyond fp32
+ * measured-best choice for the shape (the measurements behind each rule: docs/LOG_r04.md sections 3, 5, 8).  Speed only: no field changes a result beyond fp32
  * summation order, and the projection tiles do not even do that (every output element is a k-ordered fmaf chain
  * whatever the tile).  Passed per call (NULL = all auto) or bound to an engine handle (tt_engine_set_tuning); there
  * is no process-wide state behind it.  Fields a call has no use for are ignored; values a shape does not support
@@ -409,7 +409,7 @@ typedef struct {
                                  n >= 2            at most n gather workgroups per CU, 128x64 tiles (A/B) */
   int32_t grad_slabs; /* split-K slabs of the weight-gradient GEMMs (1..16; fixed for the handle's lifetime: the slab
                          workspace is sized by it); 0 = about 256 query rows per split, at least four where the batch
-                         allows them (measured) */
+                         allows them (measured, docs/LOG_r04.md section 8) */
   int32_t k1_form;    /* TT_K1_* form a later tt_engine_set_tuning will force on this handle, or 0: the per-slot partial-sum
                          workspace is sized for the forms the shape rule can pick by itself plus this one (ABI 3; before,
                          every handle carried up to 64 MB per slot for forms nobody had asked for).  A tuning that forces a

@@ -1,5 +1,5 @@
 // What do an MFMA-bound kernel and an L2-bound gather cost each other when they share the chip?  (diagnostic, not part of
-// the product; DESIGN.md section 8 "Round 4")
+// the product; docs/LOG_r04.md section 8 "Round 4"; round 5: docs/LOG_r05.md section 3)
 //
 //   kernel M: every wave runs a chain of v_mfma_f32_32x32x2_f32 on registers only (4 independent accumulators) — no
 //             memory traffic at all, `mw` waves per SIMD (one 4-wave workgroup per wave-per-SIMD), optionally holding

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""Regenerates the 'Round 4 table' of DESIGN.md section 5 from profiles/r04_bench_*.json (between the markers
-<!-- r04-table-begin --> and <!-- r04-table-end -->), so the table is exactly what the committed JSON lines say."""
+"""Regenerates the table of DESIGN.md section 5 from profiles/rNN_bench_*.json (between the markers
+<!-- bench-table-begin --> and <!-- bench-table-end -->), so the table is exactly what the committed JSON lines say.
+    usage: tools/design_table.py [rNN]   (default r05)"""
 import json
 import os
 import re
+import sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
@@ -19,7 +23,8 @@ def row(label, name, unit="M"):
     if r is None:
         return None
     rf = r.get("roofline") or {}
-    k1 = f"{rf['achieved'] / 1e3:.2f} TB/s = {rf['frac']:.3f}" if rf.get("achieved") else "—"
+    nom = (rf.get("nominal_hbm") or {}).get("frac")
+    k1 = (f"{rf['achieved'] / 1e3:.2f} TB/s = {rf['frac']:.2f} of {rf.get('bound', 'hbm')}" + (f" ({nom:.2f} of 8 TB/s)" if nom is not None and rf.get("bound") != "hbm" else "")) if rf.get("achieved") else "—"
     alone = f"{rf['alone']['achieved'] / 1e3:.2f} TB/s = {rf['alone']['avg_launch_ms'] * 1e3:.1f} µs" if rf.get("alone") and rf.get("achieved") else "—"
     step = r["ms_per_step"] * 1e3
     step_s = f"{step / 1e3:.2f} ms" if step >= 2000 else f"{step:.1f} µs"
@@ -27,36 +32,39 @@ def row(label, name, unit="M"):
 
 
 rows = [
-    ("**configs[1] default** (the driver's line: carries `secondary`, three CPU baselines, `roofline.binding`)", "r04_bench_c2_default.json"),
-    ("configs[1] at the driver's 20 steps / 5 warm-up", "r04_bench_c2_default_k20_w5.json"),
-    ("whole epoch through the loader, 1000 batches (`--e2e`)", "r04_bench_c2_e2e_epoch1000.json"),
-    ("`--no-overlap` (everything on one stream)", "r04_bench_c2_no_overlap.json"),
-    ("`--ragged` lengths", "r04_bench_c2_ragged.json"),
-    ("`--zipf` ids (SURVEY §8d's text-like id distribution)", "r04_bench_c2_zipf.json"),
-    ("`--inputs index` (negatives by in-batch index, 2 gathers)", "r04_bench_c2_inputs_index.json"),
-    ("`--inputs cache` (cache-fed step: no gather)", "r04_bench_c2_inputs_cache.json"),
-    ("**`--path module`**: the drop-in `train_epoch(model, batches, TripletLoss, FusedAdam)` — batch body routed to the engine; fill, drain, engine-side id stacking and the loss reads inside the timed epoch", "r04_bench_c2_module_path.json"),
-    ("`--path module-unfused`: the same call with `fused=False` (autograd Functions, module by module)", "r04_bench_c2_module_unfused.json"),
-    ("`--path module` at the driver's 20 steps / 5 warm-up (a 20-batch epoch)", "r04_bench_c2_module_path_k20.json"),
-    ("configs[2], one GPU's share (B = 1024 of 8192, P = 512)", "r04_bench_c3_share.json"),
-    ("**configs[3]** (V = 250k, D = P = 768, S = 256, B = 16384; binned K1)", "r04_bench_c4_full.json"),
-    ("configs[3] with the streaming K1 (`--tune k1_form=stream`: rounds 3's form, same box)", "r04_bench_c4_stream_form.json"),
-    ("configs[3] one stream `--no-overlap`", "r04_bench_c4_no_overlap.json"),
-    ("configs[3] negatives by index", "r04_bench_c4_inputs_index.json"),
-    ("in-batch negatives B = 4096 (queries/s)", "r04_bench_inbatch_b4096.json"),
-    ("in-batch negatives B = 2048", "r04_bench_c2_inbatch_b2048.json"),
-    ("in-batch negatives, one GPU's share of configs[4] (B = 512 of 4096)", "r04_bench_inbatch_b512_share.json"),
+    ("**configs[1] default** (the driver's line: carries `secondary`, three CPU baselines, `dp_breakdown`)", R + "_bench_c2_default.json"),
+    ("configs[1] at the driver's 20 steps / 5 warm-up", R + "_bench_c2_default_k20_w5.json"),
+    ("whole epoch through the loader, 1000 batches (`--e2e`)", R + "_bench_c2_e2e_epoch1000.json"),
+    ("`--no-overlap` (everything on one stream)", R + "_bench_c2_no_overlap.json"),
+    ("`--ragged` lengths", R + "_bench_c2_ragged.json"),
+    ("`--zipf` ids (SURVEY §8d's text-like id distribution)", R + "_bench_c2_zipf.json"),
+    ("`--inputs index` (negatives by in-batch index, 2 gathers)", R + "_bench_c2_inputs_index.json"),
+    ("`--inputs cache` (cache-fed step: no gather)", R + "_bench_c2_inputs_cache.json"),
+    ("**`--path module`**: the drop-in `train_epoch(model, batches, TripletLoss, FusedAdam)` — batch body routed to the engine; fill, drain, engine-side role packing and the loss reads inside the timed epoch", R + "_bench_c2_module_path.json"),
+    ("`--path module-unfused`: the same call with `fused=False` (autograd Functions, module by module)", R + "_bench_c2_module_unfused.json"),
+    ("configs[2], one GPU's share (B = 1024 of 8192, P = 512)", R + "_bench_c3_share.json"),
+    ("**configs[3]** (V = 250k, D = P = 768, S = 256, B = 16384; binned K1)", R + "_bench_c4_full.json"),
+    ("configs[3] with the streaming K1 (`--tune k1_form=stream`: round 3's form, same box)", R + "_bench_c4_stream_form.json"),
+    ("configs[3] `--zipf` ids, the shape rule's binned K1", R + "_bench_c4_zipf.json"),
+    ("configs[3] `--zipf` ids, streaming K1 (what `calibrate(k1_forms=True)` picks)", R + "_bench_c4_zipf_stream_form.json"),
+    ("configs[3] `--ragged` lengths, binned K1", R + "_bench_c4_ragged.json"),
+    ("configs[3] `--ragged` lengths, streaming K1", R + "_bench_c4_ragged_stream_form.json"),
+    ("configs[3] one stream `--no-overlap`", R + "_bench_c4_no_overlap.json"),
+    ("configs[3] negatives by index", R + "_bench_c4_inputs_index.json"),
+    ("in-batch negatives B = 4096 (queries/s)", R + "_bench_inbatch_b4096.json"),
+    ("in-batch negatives B = 2048", R + "_bench_c2_inbatch_b2048.json"),
+    ("in-batch negatives, one GPU's share of configs[4] (B = 512 of 4096)", R + "_bench_inbatch_b512_share.json"),
 ]
-out = ["| run (`profiles/…`) | triplets/s | per step | K1 in the loop (algorithmic bytes ÷ launch time; fraction of 8 TB/s) | K1 alone |", "|---|---|---|---|---|"]
+out = ["| run (`profiles/…`) | triplets/s | per step | K1 in the loop (algorithmic bytes ÷ launch time; fraction of the binding bound) | K1 alone |", "|---|---|---|---|---|"]
 for label, name in rows:
     r = row(label, name)
     if r:
         out.append(r)
-d = j("r04_bench_c2_default.json")
+d = j(R + "_bench_c2_default.json")
 if d:
     s = d["secondary"]
     out.append(f"| configs[3] as `secondary` of the default line | {s['value'] / 1e6:.2f} M | {s['ms_per_step']:.2f} ms | "
-               f"{s['roofline']['achieved'] / 1e3:.2f} TB/s = {s['roofline']['frac']:.3f} | {s['roofline']['alone']['achieved'] / 1e3:.2f} TB/s |")
+               f"{s['roofline']['achieved'] / 1e3:.2f} TB/s = {s['roofline']['frac']:.2f} of {s['roofline'].get('bound', 'hbm')} | {s['roofline']['alone']['achieved'] / 1e3:.2f} TB/s |")
     for k, lab in (("cpu_baseline", "CPU oracle `embed` mode at configs[1]'s shape"), ("cpu_baseline_configs0", "CPU oracle at configs[0]'s shape (B = 256, P = 64)"),
                    ("cpu_baseline_bert", "CPU oracle `bert` mode — what the reference's CPU path executes")):
         if d.get(k) and d[k].get("value"):
@@ -64,7 +72,7 @@ if d:
 table = "\n".join(out)
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-s2 = re.sub(r"<!-- r04-table-begin -->.*?<!-- r04-table-end -->", "<!-- r04-table-begin -->\n" + table + "\n<!-- r04-table-end -->", s, flags=re.S)
+s2 = re.sub(r"<!-- bench-table-begin -->.*?<!-- bench-table-end -->", "<!-- bench-table-begin -->\n" + table + "\n<!-- bench-table-end -->", s, flags=re.S)
 assert s2 != s or table in s, "markers not found"
 open(p, "w").write(s2)
 print(table)

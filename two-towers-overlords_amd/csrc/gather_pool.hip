@@ -890,7 +890,7 @@ __global__ __launch_bounds__(kThreads) void embed_gather_kernel(const float* __r
 
 // Sharing the chip with the projection kernels of another stream.  K1 is launched with enough *dynamic*
 // LDS that a workgroup occupies `lds_total` bytes of the CU's 160 KB; what the CU then holds is decided
-// by which workgroup fits the hole a finished one leaves (measured):
+// by which workgroup fits the hole a finished one leaves (measured, docs/LOG_r04.md §5):
 //  * tt_k1_lds_for_cap(n): 160 KB / n minus one granule — at most n gather workgroups per CU.  The
 //    per-text form runs best at n = 2 beside 128x64 projection tiles.
 //  * projection tile's LDS + 3 KB (engine.hip, sliced form beside 64x64 tiles: 37 KB): a hole left by a

@@ -618,7 +618,7 @@ class TripletTrainer:
         self.accumulation_steps = int(accumulation_steps)
         # Default on a GPU: the gathers of the next batches run on a side stream under this batch's
         # projection kernels; how the two share a CU is steered through the LDS a gather workgroup occupies
-        # (TT_K1_SHARE_AUTO: the engine pairs the K1 form with the projection tile): +20 %
+        # (TT_K1_SHARE_AUTO: the engine pairs the K1 form with the projection tile, docs/LOG_r04.md §5): +20 %
         # triplets/s over running them back to back.
         if overlap_streams is None:
             overlap_streams = self.device.type == "cuda" and engine is None
@@ -1138,7 +1138,7 @@ class TripletTrainer:
         candidates write bitwise the same gradients, so the choice never changes a training run's parameters.
         Parameters, Adam state, step counters, the gradient bucket and loss statistics are untouched (no optimizer).
         A side effect worth knowing: the dry steps also bring the GPU from its idle power state to sustained clocks,
-        which otherwise takes the first ~70 training steps.
+        which otherwise takes the first ~70 training steps (docs/LOG_r04.md §5 "Cold start").
         `k1_forms=True` (opt-in) adds the gather's form as a candidate where the shape rule picks the binned form: that
         rule assumes every table row is named about equally often, and on THIS batch's ids the streaming form may be
         the faster one (log-uniform ids at configs[3]: 4.4 vs 5.6+ ms per step, profiles/r05_c4_skew.txt).  Unlike the

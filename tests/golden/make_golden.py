@@ -289,6 +289,41 @@ def g_bert_mode():
     print("bert_mode.npz: out[0,:3] =", out[0, :3].tolist())
 
 
+def g_bert_minilm():
+    """`bert` encoder mode at the shape the reference actually loads (sentence-transformers/all-MiniLM-L6-v2: vocab 30522,
+    hidden 384, 6 layers, 12 heads, intermediate 1536, max positions 512 — SURVEY.md Appendix A; 22,713,216 parameters),
+    with seeded random weights (the pretrained ones are not in the image): the reference's AveragePoolingTower.forward,
+    unchanged, with that encoder between gather and pool, ragged texts.  The weights are NOT stored (91 MB): the test
+    rebuilds the same module from the seed and checks its hidden states against the stored ones first."""
+    from transformers import BertConfig, BertModel
+
+    torch.manual_seed(9)
+    cfg = BertConfig(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12, intermediate_size=1536,
+                     max_position_embeddings=512)
+    bert = BertModel(cfg).eval()
+    assert sum(p.numel() for p in bert.parameters()) == 22_713_216
+    D, P, B, S = 384, 64, 6, 48
+    params = orc.init_params(D, P, seed=41)
+    g = torch.Generator().manual_seed(10)
+    ids = torch.randint(0, 30522, (B, S), generator=g)
+    lens = torch.tensor([48, 31, 1, 17, 40, 9])
+    mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+    ids = ids * mask
+    tok = _StubTokenizer()
+    tok.registry["x"] = (ids, mask)
+    k = "document_tower.projection."
+    t = build_ref_tower(bert, tok, D, P, params[k + "0.weight"], params[k + "0.bias"], params[k + "2.weight"], params[k + "2.bias"])
+    out = t(["x"] * B)
+    with torch.no_grad():
+        hidden = bert(input_ids=ids, attention_mask=mask)[0]
+    np.savez_compressed(
+        os.path.join(HERE, "bert_minilm.npz"),
+        ids=np_(ids), mask=np_(mask), hidden=np_(hidden), out=np_(out),
+        w1=np_(params[k + "0.weight"]), b1=np_(params[k + "0.bias"]), w2=np_(params[k + "2.weight"]), b2=np_(params[k + "2.bias"]),
+    )
+    print("bert_minilm.npz: out[0,:3] =", out[0, :3].tolist())
+
+
 def g_triplets():
     """`TripletDataLoader.create_triplets` (data.py:113-137) on fake items with
     seeded `random`: expected negative index per item for several seeds.  Cases 4-5
@@ -465,12 +500,16 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["accum"]:  # regenerate only the accumulation fixture
         g_accum()
         sys.exit(0)
+    if sys.argv[1:] == ["bert_minilm"]:  # only the MiniLM-L6-shaped bert-mode fixture (round 5)
+        g_bert_minilm()
+        sys.exit(0)
     r = g_kat0()
     g_step_mid()
     g_step_minilm_shape()
     g_pool_edges()
     g_loss_edges()
     g_bert_mode()
+    g_bert_minilm()
     g_triplets()
     g_eval()
     g_accum()

@@ -95,8 +95,9 @@ def test_loss_edges():
         np.testing.assert_allclose(a.numpy() / scale, g[k] / scale, atol=TOL, rtol=1e-5)
 
 
-def test_bert_mode_dense_pool():
-    g = load_golden("bert_mode.npz")
+@pytest.mark.parametrize("name", ["bert_mode.npz", "bert_minilm.npz"])  # 2 layers / hidden 32; MiniLM-L6 shape (round 5)
+def test_bert_mode_dense_pool(name):
+    g = load_golden(name)
     pooled = orc.pool_normalize(T(g["hidden"]), T(g["mask"]))
     out = orc.projection(pooled, T(g["w1"]), T(g["b1"]), T(g["w2"]), T(g["b2"]))
     np.testing.assert_allclose(out.numpy(), g["out"], atol=TOL, rtol=0)

@@ -83,6 +83,20 @@ int main() {
     ttg::Batch b2 = b1;
     for (int i = 0; i < 2; ++i) { ttg::Problem& p = b2.p[i]; p.A = H + (i ? (size_t)Mq * P : 0); p.B = W2 + (size_t)i * P * P; p.C = O + (i ? (size_t)Mq * P : 0); p.K = P; p.lda = P; p.ldb = P; }
     timed("NT layer 2 (K = P)", nt_wgs, P / 32, [&] { ttg::launch(ttg::kNT, ttg::kBias, b2, 1, 1, st, bk); });
+    {  // Probe (round 5): what a launch of the same total work would cost if a third of its tile-units were HALF units —
+       // as many full tiles as CUs would hold one each, the rest as tiles with half the K loop (a stand-in for K-split half
+       // tiles: same MFMA time, same workgroup shape), full tiles first in the grid.  Wrong results by construction.
+      const int units = (P / 64) * (rows / 64);             // 64x64 tile-units of the real launch
+      const int full_tiles = units >= 512 ? 384 : 256, half_tiles = 2 * (units - full_tiles);
+      ttg::Batch pb{}; pb.count = 2; pb.nsplit = 1;
+      for (int i = 0; i < 2; ++i) {
+        ttg::Problem& p = pb.p[i];
+        p.A = X; p.B = W1; p.C = H; p.bias = b;
+        p.M = (i == 0 ? full_tiles : half_tiles) / (P / 64) * 64; p.N = P; p.K = i == 0 ? D : D / 2; p.lda = D; p.ldb = D; p.ldc = P;
+      }
+      if (pb.p[0].M <= rows && pb.p[1].M <= rows && pb.p[1].M > 0)
+        timed("  probe: NT1 as full + half-K tiles", full_tiles + half_tiles, D / 32, [&] { ttg::launch(ttg::kNT, ttg::kBiasRelu, pb, 1, 1, st, bk); });
+    }
     ttg::Batch gh = b2;
     for (int i = 0; i < 2; ++i) { ttg::Problem& p = gh.p[i]; p.A = O + (i ? (size_t)Mq * P : 0); p.C = dH + (i ? (size_t)Mq * P : 0); p.aux = H + (i ? (size_t)Mq * P : 0); p.ldaux = P; p.bias = nullptr; }
     timed("NN dH (K = P)", nt_wgs, P / 32, [&] { ttg::launch(ttg::kNN, ttg::kReluMask, gh, 1, 1, st, bk); });

@@ -32,6 +32,11 @@
 // prologue is 1.2-1.6 us, the epilogue 0.6-1 us — the launches are bound by the CUs that hold the most tiles (2 of 64x64
 // at 1.5 tiles per CU, 3 at 2.25), each tile's K loop running at 0.7-0.86 of the MFMA rate while it shares its SIMDs.)
 //
+// (Round 5 also built BALANCED launches for the tile quantisation the stamps show — the left-over tile-units of a launch as
+// two 32x64 half tiles each, K split between wave pairs inside the workgroup — after a probe (half-K full tiles) had run the
+// same work 15-22 % faster: the real half tile, overhead-bound at 8 MFMAs per barrier and LDS-heavy at 16, gained 3 % alone
+// at best and lost 10-18 % beside the gather; docs/LOG_r05.md section 1, profiles/r05_gemm_stamps.txt.  Removed.)
+//
 // Numerics: each C element is a k-ordered fmaf chain in fp32 (what the MFMA
 // computes, bitwise), K-steps in ascending order; split-K (kTN) partials go to
 // separate slabs that are summed in fixed order later => run-to-run bitwise

@@ -373,11 +373,12 @@ class _EngineRoute:
             return state["loss_sum"] / state["loss_n"]
         finally:
             tr = self.trainer
-            if tr._pending:  # an exception mid-epoch: gathered-but-unapplied batches must not leak into the next call
-                tr.abort_pipeline()
-                self._sync_steps(tr)
-                tr.engine.read_stats(reset=True)
-            tr.bucket, tr.accumulation_steps, tr._carry = None, 1, False
+            if tr is not None:
+                if tr._pending:  # an exception mid-epoch: gathered-but-unapplied batches must not leak into the next call
+                    tr.abort_pipeline()
+                    self._sync_steps(tr)
+                    tr.engine.read_stats(reset=True)
+                tr.bucket, tr.accumulation_steps, tr._carry = None, 1, False
 
     def _enter(self, accumulate: bool, accumulation_steps, carried=None) -> None:
         """Hyper-parameters, step count and the accumulation window of this call -> the trainer.  `carried` = (micro, carry)

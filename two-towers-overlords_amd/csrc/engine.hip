@@ -395,9 +395,10 @@ extern "C" int tt_engine_pool_rows(tt_engine* e, int slot, const void* store_ids
   return engine_k1(e, slot, store_ids, ids_dtype, nullptr, TT_I32, store_lens, roles, B, S, rows, n_store, stream);
 }
 
-// One wave per (role, text): the attended tokens (mask != 0) of a [B, S_r] block, in order, as int32 ids at the front of
-// row (role, text) of out_ids [roles, B, S_out]; the rest of the row zero; lens = their count.  flags[1] |= 1 where a
-// mask value is neither 0 nor 1 (weighted pooling cannot be packed), ids outside int32 become -1 (K1 reports them).
+// One wave per (role, text): the attended tokens (mask != 0, id not already TT_PAD_ID) of a [B, S_r] block, in order, as int32
+// ids at the front of row (role, text) of out_ids [roles, B, S_out]; TT_PAD_ID behind them; lens = their count.  flags[1] |= 1
+// where a mask value is neither 0 nor 1 (weighted pooling cannot be packed), ids outside int32 become -1 (K1 reports them).
+__device__ __forceinline__ bool tt_is_pad_host(long long raw) { return raw == TT_PAD_ID32 || raw == (-9223372036854775807LL - 1LL); }
 struct PackRoles {
   const void* ids[3];
   const void* mask[3];
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void pack_roles_kernel(const PackRoles a, int 
       if (mp) m = m64 ? static_cast<const long long*>(mp)[src + tok] : (long long)static_cast<const int32_t*>(mp)[src + tok];
       id = i64 ? static_cast<const long long*>(ip)[src + tok] : (long long)static_cast<const int32_t*>(ip)[src + tok];
     }
-    const bool keep = in && m != 0;
+    const bool keep = in && m != 0 && !tt_is_pad_host(id);
     weird = weird || (keep && m != 1);
     const unsigned long long b = __ballot(keep);
     const int pos = count + __popcll(b & ((1ull << lane) - 1ull));

@@ -261,7 +261,7 @@ def main():
     ap.add_argument("--calibrate-k1", action="store_true",
                     help="calibrate() also times the gather's form on this run's ids where the shape rule picks the binned form "
                          "(TripletTrainer.calibrate(k1_forms=True)); the pick is in calibration.k1_form")
-    ap.add_argument("--ids-form", default="packed", choices=["packed", "lens", "roles"],
+    ap.add_argument("--ids-form", default="packed", choices=["packed", "lens", "roles", "padids"],
                     help="diagnostic: how the engine path's batches carry their ids — packed int32 [3,B,S] (headline), the same "
                          "with full prefix lengths, or the tokenizer's form: three (int64 input_ids, int64 attention_mask) "
                          "blocks packed by the engine (what the drop-in route hands over)")
@@ -616,6 +616,10 @@ def run_config(args, world, rank, device) -> dict:
                                   torch.randint(min(32, S), S + 1, (B,), generator=gl)]).int() for _ in range(n_distinct)]
         valid_tokens = sum(int(l.sum()) for l in lens_list) / n_distinct
         batches = [(ids, None, l.to(device)) for ids, l in zip(id_batches, lens_list)]
+    if args.ids_form == "padids" and args.ragged:  # the ragged lengths marked inside the ids (TT_PAD_ID) instead of a lens tensor
+        pos = torch.arange(S, device=device).view(1, 1, S)
+        batches = [(torch.where(pos < l.unsqueeze(2), ids, torch.full((), -(2 ** 31), dtype=ids.dtype, device=device)), None, None)
+                   for ids, _, l in batches]
     if args.ids_form == "lens" and not args.ragged:
         full = torch.full((3, B), S, dtype=torch.int32, device=device)
         batches = [(ids, None, full) for ids in id_batches]

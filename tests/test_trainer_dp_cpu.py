@@ -203,6 +203,31 @@ def test_neg_index_and_feature_cache_equal_three_encodes():
             np.testing.assert_allclose(runs[mode][1][k].numpy(), runs["ids3"][1][k].numpy(), atol=2e-6, rtol=0)
 
 
+def test_trainer_config_object_and_keyword_overrides():
+    """TrainerConfig (round 5): every knob of TripletTrainer in one dataclass; keywords given beside it override its
+    fields (so every older call site keeps working), an unknown keyword is a TypeError like a bad argument, and the two
+    spellings train identically."""
+    from oracle_engine import OracleEngine
+    from two_towers_overlords_amd.training import TrainerConfig, TripletTrainer
+
+    torch.set_num_threads(1)
+    table, params, batches = _setup()
+    gb = [(torch.stack([r[0] for r in b]), torch.stack([r[1] for r in b]), None) for b in batches]
+    mk = lambda **kw: TripletTrainer(table=table, params={k: v.clone() for k, v in params.items()}, max_batch=B,
+                                     max_seq_len=S, engine=OracleEngine(table, P, B, S), **kw)
+    a = mk(margin=0.25, lr=2e-3, accumulation_steps=2)
+    b = mk(config=TrainerConfig(margin=0.9, lr=2e-3, accumulation_steps=2), margin=0.25)   # the keyword wins
+    assert (b.config.margin, b.config.lr, b.config.accumulation_steps, b.margin) == (0.25, 2e-3, 2, 0.25)
+    assert a.config == b.config and TrainerConfig().loss == "triplet" and TrainerConfig().split_exchange is False
+    assert a.train_epoch(gb) == b.train_epoch(gb)
+    for k in orc.PARAM_KEYS:
+        assert torch.equal(a.named_parameters()[k], b.named_parameters()[k])
+    with pytest.raises(TypeError):
+        mk(learning_rate=1e-3)
+    with pytest.raises(ValueError):
+        mk(loss="softmax")
+
+
 @pytest.mark.parametrize("accum", [1, 3])
 def test_trainer_state_dict_resumes_exactly(accum):
     """Two epochs straight == one epoch, state_dict() -> a NEW trainer -> load_state_dict(), one more epoch: parameters,

@@ -47,7 +47,9 @@ typedef enum {
   TT_ERR_ALIGNMENT = -4,
   TT_ERR_WORKSPACE = -5,
   TT_ERR_BAD_HANDLE = -6,
-  TT_ERR_UNSUPPORTED = -7
+  TT_ERR_UNSUPPORTED = -7,
+  TT_ERR_WRONG_DEVICE = -8 /* tt_engine_create: the calling thread's current HIP device is not cfg->device, or the
+                              workspace lives on another device (one engine handle per device/rank: hipSetDevice first) */
 } tt_status;
 
 /* integer element widths accepted for ids / masks */
@@ -398,7 +400,9 @@ typedef struct {
   int32_t P;        /* projection dim */
   int32_t max_B;    /* max triplets per step on this replica */
   int32_t max_S;    /* max padded sequence length */
-  int32_t device;   /* HIP device ordinal */
+  int32_t device;   /* HIP device ordinal: must be the calling thread's current device at tt_engine_create (the handle's
+                       second stream and events are created there) and the device of `workspace`, else
+                       TT_ERR_WRONG_DEVICE — a rank that forgot hipSetDevice(local_rank) fails here, not later */
   int32_t k1_blocks_per_cu; /* How tt_engine_pool shares the chip with the MFMA kernels of
                                tt_engine_fwd_bwd running on another stream (both sides are steered
                                through the LDS a gather workgroup occupies):

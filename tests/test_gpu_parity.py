@@ -1465,3 +1465,31 @@ def test_trainer_token_store_epoch_equals_materialised_ids_and_calibrate_is_neut
     # calibrate() first: same parameters, bit for bit (the two backward schedules write the same gradients)
     trc, _, lossc, _, _ = epoch("rows3", True)
     assert torch.equal(trc.flat, tr3.flat) and abs(lossc - loss3) <= 1e-6
+
+
+def test_engine_create_refuses_a_device_that_is_not_the_callers_current_one(tt):
+    """One engine handle per device/rank (include/tt_hotpath.h, tt_engine_config.device): a handle's second stream and
+    events are created on the calling thread's CURRENT device, so a config naming another ordinal — a rank that forgot
+    hipSetDevice(local_rank) — is refused at create with TT_ERR_WRONG_DEVICE (-8), not left to fail at the first join."""
+    import ctypes as C
+
+    from two_towers_overlords_amd import _lib
+
+    lib = _lib.load()
+    cur = torch.cuda.current_device()
+    cfg = _lib.TTEngineConfig(1000, 64, 64, 32, 16, cur + 1, 0, 0, 0, 0)
+    nbytes = lib.tt_engine_workspace_bytes(C.byref(cfg))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    h = C.c_void_p()
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.tt_engine_create(C.byref(cfg), ws.data_ptr(), nbytes, stream, C.byref(h)) == -8 and not h.value
+    assert b"device" in lib.tt_status_string(-8)
+    cfg.device = cur
+    assert lib.tt_engine_create(C.byref(cfg), ws.data_ptr(), nbytes, stream, C.byref(h)) == 0 and h.value
+    torch.cuda.synchronize()
+    assert lib.tt_engine_destroy(h) == 0
+    # the Python handle resolves an index-less device to the current one
+    _, engine = tt
+    e = engine.HotPathEngine(torch.zeros(1000, 64, device="cuda"), 64, 32, 16)
+    assert e.device.index == cur
+    e.close()

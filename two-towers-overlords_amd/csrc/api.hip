@@ -13,6 +13,7 @@ extern "C" const char* tt_status_string(int status) {
     case TT_ERR_WORKSPACE: return "workspace too small / allocation failed";
     case TT_ERR_BAD_HANDLE: return "invalid engine handle";
     case TT_ERR_UNSUPPORTED: return "unsupported configuration";
+    case TT_ERR_WRONG_DEVICE: return "current HIP device / workspace device is not the engine config's device";
     default: break;
   }
   if (status > 0) return hipGetErrorString(static_cast<hipError_t>(status));

@@ -183,6 +183,16 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
                                 tt_stream_t stream, tt_engine** out) {
   TT_REQUIRE(cfg && out && workspace, TT_ERR_NULL_POINTER);
   TT_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, TT_ERR_ALIGNMENT);
+  {  // one handle per device/rank: the second stream and the events below are created on the CURRENT device
+    int cur = -1;
+    TT_REQUIRE(hipGetDevice(&cur) == hipSuccess && cur == cfg->device, TT_ERR_WRONG_DEVICE);
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, workspace) == hipSuccess) {
+      TT_REQUIRE(attr.device == cfg->device, TT_ERR_WRONG_DEVICE);
+    } else {
+      (void)hipGetLastError();  // a pointer the runtime cannot describe: left to the first launch to reject
+    }
+  }
   tt_engine* e = new (std::nothrow) tt_engine();
   TT_REQUIRE(e, TT_ERR_WORKSPACE);
   int rc = fill_dims(e, cfg);

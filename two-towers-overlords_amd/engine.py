@@ -36,13 +36,13 @@ class HotPathEngine:
     def __init__(self, table: torch.Tensor, projection_dim: int, max_batch: int, max_seq_len: int,
                  k1_blocks_per_cu: int = 0, tuning=None, grad_slabs: int = 0, pack_roles: bool = False):
         _req(table, "table", torch.float32, 2)
-        self.device = table.device
+        self.device = table.device if table.device.index is not None else torch.device("cuda", torch.cuda.current_device())
         self.table = table
         self.V, self.D = table.shape
         self.P = int(projection_dim)
         self.max_B, self.max_S = int(max_batch), int(max_seq_len)
         forced = _lib.make_tuning(tuning or {}).k1_form  # the partial-sum workspace is sized for a form a tuning will force
-        cfg = TTEngineConfig(self.V, self.D, self.P, self.max_B, self.max_S, self.device.index or 0, int(k1_blocks_per_cu),
+        cfg = TTEngineConfig(self.V, self.D, self.P, self.max_B, self.max_S, self.device.index, int(k1_blocks_per_cu),
                              int(grad_slabs), int(forced), 1 if pack_roles else 0)
         self.has_pack_roles = bool(pack_roles)
         lib = _lib.load()

@@ -80,9 +80,13 @@ int main() {
     }
     const int nt_wgs = (P / 64) * (Md / 64) * 2;
     timed("NT layer 1 (K = D)", nt_wgs, D / 32, [&] { ttg::launch(ttg::kNT, ttg::kBiasRelu, b1, 1, 1, st, bk); });
+    const int rn = P % 96 == 0 ? 3 : 2;  // K-split 96-row tiles (round 5): one tile per CU at these shapes
+    const int ks_wgs = (rows / 96) * (P / (32 * rn));
+    timed("NT layer 1, K-split 96-row tiles", ks_wgs, D / 32 * 3 * rn / 4, [&] { ttg::launch(ttg::kNT, ttg::kBiasRelu, b1, 3, rn, st, bk); });
     ttg::Batch b2 = b1;
     for (int i = 0; i < 2; ++i) { ttg::Problem& p = b2.p[i]; p.A = H + (i ? (size_t)Mq * P : 0); p.B = W2 + (size_t)i * P * P; p.C = O + (i ? (size_t)Mq * P : 0); p.K = P; p.lda = P; p.ldb = P; }
     timed("NT layer 2 (K = P)", nt_wgs, P / 32, [&] { ttg::launch(ttg::kNT, ttg::kBias, b2, 1, 1, st, bk); });
+    timed("NT layer 2, K-split 96-row tiles", ks_wgs, P / 32 * 3 * rn / 4, [&] { ttg::launch(ttg::kNT, ttg::kBias, b2, 3, rn, st, bk); });
     {  // Probe (round 5): what a launch of the same total work would cost if a third of its tile-units were HALF units —
        // as many full tiles as CUs would hold one each, the rest as tiles with half the K loop (a stand-in for K-split half
        // tiles: same MFMA time, same workgroup shape), full tiles first in the grid.  Wrong results by construction.
@@ -100,6 +104,7 @@ int main() {
     ttg::Batch gh = b2;
     for (int i = 0; i < 2; ++i) { ttg::Problem& p = gh.p[i]; p.A = O + (i ? (size_t)Mq * P : 0); p.C = dH + (i ? (size_t)Mq * P : 0); p.aux = H + (i ? (size_t)Mq * P : 0); p.ldaux = P; p.bias = nullptr; }
     timed("NN dH (K = P)", nt_wgs, P / 32, [&] { ttg::launch(ttg::kNN, ttg::kReluMask, gh, 1, 1, st, bk); });
+    timed("NN dH, K-split 96-row tiles", ks_wgs, P / 32 * 3 * rn / 4, [&] { ttg::launch(ttg::kNN, ttg::kReluMask, gh, 3, rn, st, bk); });
     ttg::Batch g1{}; g1.count = 2; g1.nsplit = nsplit; g1.slab_stride = stride;
     for (int i = 0; i < 2; ++i) {  // document tower (longer K) first, as proj.hip orders them
       const int t = 1 - i; ttg::Problem& p = g1.p[i];

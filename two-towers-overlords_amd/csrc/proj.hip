@@ -66,9 +66,19 @@ static void pick_tn_tile(int M, int N, const Plan& pl, int& wm, int& wn, int& bk
 // [6144 x 384] matrix where 64x64 gives 576 = 2.25 per CU — were built in round 3, parity-green, and measured slower at
 // BASELINE.json configs[1]: the two towers' 2048 + 4096 rows make 260 such tiles, cache-fed 132 vs 129 us, one stream
 // 253 vs 235 us, beside the gathers 233 vs 194 us; profiles/r03_gemm16_ab.txt.  Removed in round 4.)
+// (Round 5: K-split 96-row tiles, proj_tile = 33 / 32 — ONE tile per CU at BASELINE.json configs[1] and configs[2]'s share
+// (gemm_f32.hip).  Opt-in only: alone on the chip a launch is 19.2 / 23.4 / 24.6 us against 19.8 / 24.1 / 25.3 at configs[2]'s
+// share and 27.5 / 27.1 / 28.6 against 27.4 / 27.2 / 27.9 at configs[1] (profiles/r05_gemm_stamps_ksplit.txt), and no step
+// got faster: docs/LOG_r05.md section 1 says what is missing — the panel that straddles the towers runs two K loops, one
+// wave per SIMD leaves a bubble at every K-step's barrier (K loop at 0.70 of its MFMA time), and the fused backward loses
+// its TN + NN pairing.)
 static void pick_tile(long long total_rows, int N, int& wm, int& wn, int& bk, const Plan& pl) {
   const bool low_traffic = pl.policy == kTileLowTraffic;
   bk = 32;
+  if (pl.t.proj_tile == 33 || pl.t.proj_tile == 32) {  // K-split 96-row tiles, 96 or 64 columns (gemm_f32.hip)
+    wm = 3; wn = pl.t.proj_tile % 10;
+    return;
+  }
   if (pl.t.proj_tile == 11 || pl.t.proj_tile == 21 || pl.t.proj_tile == 22) {
     wm = pl.t.proj_tile / 10; wn = pl.t.proj_tile % 10;
     if (wm == 2 && wn == 2 && pl.t.proj_bk == 16) bk = 16;
@@ -89,6 +99,7 @@ static void pick_tile(long long total_rows, int N, int& wm, int& wn, int& bk, co
 size_t chain_lds_bytes(long long rows, int P, const Plan& pl) {
   int wm, wn, bk;
   pick_tile(rows, P, wm, wn, bk, pl);
+  if (wm == 3) wm = wn = 1;  // a K-split 96-row tile has its CU to itself (registers): the gather keeps the 64x64 pairing
   size_t m = ttg::tile_lds_bytes(ttg::kNT, wm, wn, bk);
   const size_t nn = ttg::tile_lds_bytes(ttg::kNN, wm, wn, bk);
   const size_t tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1);
@@ -182,7 +193,7 @@ int backward_dw2_dh(const Tower* t, int count, int D, int P, int nsplit, long lo
   pick_tile(rows, P, wm, wn, bk, pl);
   int tm, tn, tbk;
   pick_tn_tile(P, P, pl, tm, tn, tbk);
-  if ((wm == 2 && wn == 2) || tm != 1) {  // the fused kernel carries 64x64 TN tiles beside 64x64 / 128x64 NN tiles only
+  if ((wm == 2 && wn == 2) || wm == 3 || tm != 1) {  // the fused kernel carries 64x64 TN tiles beside 64x64 / 128x64 NN tiles only
     int rc = ttg::launch(ttg::kTN, ttg::kStore, g2, tm, tn, st, tbk);
     if (rc != TT_OK) return rc;
     return ttg::launch(ttg::kNN, ttg::kReluMask, gh, wm, wn, st, bk);

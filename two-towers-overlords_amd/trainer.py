@@ -670,8 +670,9 @@ class TripletTrainer:
         open (`split_exchange=None`) — the exchange in one bucket or in two parts.  Single replica: dry steps with the
         gathers running beside the chain exactly as in training.  Data parallel (round 5): the dry steps ARE the
         data-parallel step — slab reduce into a scratch bucket, the next gather issued under the exchange, the real
-        collective on the caller's stream — because there the chain runs alone on the chip and the ranking differs
-        (configs[2]'s share under a 60 us stand-in: fork 187 us, fused 170; beside the gathers they tie).  All
+        collective on the caller's stream — because there the chain runs alone on the chip and the ranking may differ
+        from the one beside the gathers (configs[2]'s share under a 60 us stand-in: the two tie at 186 us without a
+        profiler, fused is 4.6 us ahead under rocprofv3; docs/LOG_r05.md section 1).  All
         candidates write bitwise the same gradients, so the choice never changes a training run's parameters.
         Parameters, Adam state, step counters, the gradient bucket and loss statistics are untouched (no optimizer).
         A side effect worth knowing: the dry steps also bring the GPU from its idle power state to sustained clocks,

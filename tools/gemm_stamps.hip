@@ -24,7 +24,9 @@ static float* dev_rand(size_t n, unsigned seed) {
 static void report(const char* name, int wgs, int ksteps_long) {
   std::vector<unsigned long long> st(4 * 8192);
   CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(tt_gemm_stamps), st.size() * sizeof(unsigned long long)));
-  std::vector<double> start, pro, kl, epi, tot;
+  std::vector<unsigned long long> cy(4 * 8192);
+  CK(hipMemcpyFromSymbol(cy.data(), HIP_SYMBOL(tt_gemm_cycles), cy.size() * sizeof(unsigned long long)));
+  std::vector<double> start, pro, kl, epi, tot, ghz;
   unsigned long long t0 = ~0ull, t1 = 0;
   for (int w = 0; w < wgs && w < 8192; ++w) {
     const unsigned long long* p = &st[4 * w];
@@ -36,14 +38,15 @@ static void report(const char* name, int wgs, int ksteps_long) {
     if (p[0] == 0 || p[3] < p[0]) continue;
     start.push_back((p[0] - t0) * 0.01); pro.push_back((p[1] - p[0]) * 0.01); kl.push_back((p[2] - p[1]) * 0.01);
     epi.push_back((p[3] - p[2]) * 0.01); tot.push_back((p[3] - p[0]) * 0.01);
+    if (p[2] > p[1]) ghz.push_back((double)(cy[4 * w + 2] - cy[4 * w + 1]) / ((p[2] - p[1]) * 10.0));  // shader cycles per ns over the K loop
   }
   auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
   auto mx = [](const std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
   auto p90 = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() * 9 / 10]; };
   printf("%-34s wgs %4zu  span %6.2f us | start med %5.2f p90 %5.2f max %5.2f | prologue med %5.2f max %5.2f | K loop med %5.2f p90 %5.2f max %5.2f"
-         " (MFMA of %2d K-steps: %5.2f) | epilogue med %5.2f max %5.2f | workgroup med %5.2f max %5.2f\n",
+         " (MFMA of %2d K-steps: %5.2f) | epilogue med %5.2f max %5.2f | workgroup med %5.2f max %5.2f | clock64/wall over the K loop: %.3f GHz\n",
          name, tot.size(), (t1 - t0) * 0.01, med(start), p90(start), mx(start), med(pro), mx(pro), med(kl), p90(kl), mx(kl), ksteps_long,
-         ksteps_long * 1024 / 2400.0, med(epi), mx(epi), med(tot), mx(tot));
+         ksteps_long * 1024 / 2400.0, med(epi), mx(epi), med(tot), mx(tot), med(ghz));
 }
 
 int main() {
@@ -83,6 +86,15 @@ int main() {
     const int rn = P % 96 == 0 ? 3 : 2;  // K-split 96-row tiles (round 5): one tile per CU at these shapes
     const int ks_wgs = (rows / 96) * (P / (32 * rn));
     timed("NT layer 1, K-split 96-row tiles", ks_wgs, D / 32 * 3 * rn / 4, [&] { ttg::launch(ttg::kNT, ttg::kBiasRelu, b1, 3, rn, st, bk); });
+    {  // the same two launches over all-zero operands: if the K loop is shorter, what limits it is power (operand toggling), not issue
+      float* Xz; float* Wz; CK(hipMalloc(&Xz, (size_t)rows * D * sizeof(float))); CK(hipMalloc(&Wz, (size_t)2 * P * D * sizeof(float)));
+      CK(hipMemset(Xz, 0, (size_t)rows * D * sizeof(float))); CK(hipMemset(Wz, 0, (size_t)2 * P * D * sizeof(float)));
+      ttg::Batch bz = b1;
+      for (int i = 0; i < 2; ++i) { bz.p[i].A = Xz + (i ? (size_t)Mq * D : 0); bz.p[i].B = Wz + (size_t)i * P * D; }
+      timed("  zeros: NT layer 1 (K = D)", nt_wgs, D / 32, [&] { ttg::launch(ttg::kNT, ttg::kBiasRelu, bz, 1, 1, st, bk); });
+      timed("  zeros: NT layer 1, K-split tiles", ks_wgs, D / 32 * 3 * rn / 4, [&] { ttg::launch(ttg::kNT, ttg::kBiasRelu, bz, 3, rn, st, bk); });
+      CK(hipFree(Xz)); CK(hipFree(Wz));
+    }
     ttg::Batch b2 = b1;
     for (int i = 0; i < 2; ++i) { ttg::Problem& p = b2.p[i]; p.A = H + (i ? (size_t)Mq * P : 0); p.B = W2 + (size_t)i * P * P; p.C = O + (i ? (size_t)Mq * P : 0); p.K = P; p.lda = P; p.ldb = P; }
     timed("NT layer 2 (K = P)", nt_wgs, P / 32, [&] { ttg::launch(ttg::kNT, ttg::kBias, b2, 1, 1, st, bk); });

@@ -48,11 +48,15 @@
 // Diagnostic builds only (tools/gemm_stamps.hip): thread 0 of every workgroup leaves the 100 MHz wall clock at entry, after
 // the prologue (first operand tile in LDS), after the K loop and after the epilogue.
 __device__ unsigned long long tt_gemm_stamps[4 * 8192];
+__device__ unsigned long long tt_gemm_cycles[4 * 8192];  // the shader clock at the same points (clock64: follows DVFS)
 #define TT_STAMP(i)                                                                                              \
   do {                                                                                                           \
     if (threadIdx.x == 0) {                                                                                      \
       const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                       \
-      if (wg_ < 8192) tt_gemm_stamps[4 * wg_ + (i)] = wall_clock64();                                            \
+      if (wg_ < 8192) {                                                                                          \
+        tt_gemm_stamps[4 * wg_ + (i)] = wall_clock64();                                                          \
+        tt_gemm_cycles[4 * wg_ + (i)] = clock64();                                                               \
+      }                                                                                                          \
     }                                                                                                            \
   } while (0)
 #else

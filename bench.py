@@ -281,6 +281,20 @@ def main():
                          "routes its batch body to the fused engine.  module-unfused: the same call with fused=False — "
                          "TwoTowersModel.encode_* as autograd Functions over the same kernels, one multi-tensor Adam launch.  "
                          "Both reported under their own metric names")
+    ap.add_argument("--optimizer", default="torch", choices=["torch", "fused"],
+                    help="--path module*: torch = the reference's own `torch.optim.Adam(model.parameters(), lr)` "
+                         "(backend/training.py:436) [default]; fused = this package's FusedAdam")
+    ap.add_argument("--strings", default=None, choices=["lists", "columns", "loader"],
+                    help="--path module: batches of STRINGS through a real BertTokenizerFast (the reference's batch form, "
+                         "backend/training.py:36-42).  lists = plain list[str] batches; columns = the row-tagged lists this "
+                         "package's TripletDataLoader yields, pre-built; loader = the TripletDataLoader itself "
+                         "(shuffle + the reference's in-batch negative draws per batch).  Reports epoch 1 (tokenises) and "
+                         "epochs >= 2 (the text store) separately")
+    ap.add_argument("--epochs", type=int, default=3, help="--strings: epochs over the same --steps batches (1 cold + the rest warm)")
+    ap.add_argument("--text-cache", type=int, default=1, choices=[0, 1],
+                    help="--strings: 0 = train_epoch(text_cache=False): the three tokenizer calls on every batch, as the reference does")
+    ap.add_argument("--debug-hostprof", action="store_true",
+                    help="--strings: cProfile the last epoch's host side to stderr (the epoch is slower for it)")
     ap.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
                     help="a tt_tuning field for this run's engine (include/tt_hotpath.h), e.g. --tune k1_form=stream "
                          "--tune proj_tile=22; repeatable.  Speed only; recorded in config.tuning")
@@ -371,7 +385,9 @@ def main():
     if args.path != "engine":
         if world > 1:
             sys.exit("--path module is a single-process measurement")
-        print(json.dumps(run_module_path(args, device)))
+        from bench_module import run_module_path  # the drop-in surface's own measurements (bench_module.py)
+
+        print(json.dumps(run_module_path(args, device, CONFIGS, make_ids)))
         return
     default_line = (args.config == "c2" and args.inputs == "ids3" and args.loss == "triplet" and not args.k1_only
                     and not args.e2e and not args.h2d and args.simulate_allreduce_us is None and not args.batch
@@ -453,65 +469,6 @@ def self_launch(args) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool's host driver
     env.setdefault("OMP_NUM_THREADS", "4")
     return subprocess.run(cmd, env=env).returncode
-
-
-def run_module_path(args, device) -> dict:
-    """The reference-signature loop (two-towers-overlords_amd/training.py::train_epoch, backend/training.py:26-63) on the
-    mirrored nn.Modules: K batches after W warm-up batches, timed from the first batch's enqueue to the epoch's return
-    (every batch ends in loss.item(), so the host is in step with the GPU)."""
-    import contextlib
-
-    import two_towers_overlords_amd as pkg
-    from two_towers_overlords_amd.model import EmbeddingOnlyEncoder, TripletLoss, TwoTowersModel
-    from two_towers_overlords_amd.training import FusedAdam, train_epoch
-
-    pkg.load()
-    cfg = dict(CONFIGS[args.config])
-    if args.batch:
-        cfg["B"] = args.batch
-    V, D, P, B, S = cfg["V"], cfg["D"], cfg["P"], cfg["B"], cfg["S"]
-    gt = torch.Generator().manual_seed(1)
-    table = torch.randn(V, D, generator=gt) * 0.02
-    torch.manual_seed(2)
-    model = TwoTowersModel(projection_dim=P, tokenizer=lambda *a, **k: None, pretrained_model=EmbeddingOnlyEncoder(table),
-                           encoder_mode="embed").to(device)
-    crit = TripletLoss(margin=0.3)
-    opt = FusedAdam(model.parameters(), lr=1e-3)
-    ids = make_ids(V, B, S, 8, seed=1234, device=device, zipf=args.zipf)
-    ones = torch.ones(B, S, dtype=torch.int64, device=device)
-    # what the tokenizer hands over (backend/model.py:43-48): int64 input_ids and attention_mask per encode call
-    distinct = [tuple((b[r].long(), ones) for r in range(3)) for b in ids]
-    seq = lambda n: [distinct[i % len(distinct)] for i in range(n)]
-    fused = None if args.path == "module" else False
-    with contextlib.redirect_stdout(sys.stderr):  # train_epoch prints every 10th batch's loss, like the reference
-        train_epoch(model, seq(max(args.warmup, 1)), crit, opt, log_wandb=False, fused=fused)
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        avg = train_epoch(model, seq(args.steps), crit, opt, log_wandb=False, fused=fused)
-        torch.cuda.synchronize(device)
-        elapsed = time.perf_counter() - t0
-    return {
-        "metric": ("triplets/sec, drop-in train_epoch(model, batches, TripletLoss, FusedAdam) — batch body routed to the fused "
-                   "engine; pipeline fill, drain and the loss reads inside the timed epoch; NOT the BASELINE metric"
-                   if fused is None else
-                   "triplets/sec, drop-in MODULE path, fused=False: training.train_epoch over TwoTowersModel.encode_* + TripletLoss "
-                   "+ FusedAdam (autograd Functions over the same HIP kernels); NOT the BASELINE metric"),
-        "value": args.steps * B / elapsed, "unit": "triplets/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["label"], "path": args.path, "encoder_mode": "embed", "vocab": V, "embed_dim": D,
-                   "proj_dim": P, "seq_len": S, "batch_per_gpu": B, "global_batch": B,
-                   "ids": "int64 input_ids + int64 attention_mask [B,S] per encode call, " + ("zipf" if args.zipf else "uniform")
-                          + ", full length", "parallelism": "dp1",
-                   "launches_per_step": ("the fused engine's (one gather for the three roles two batches ahead on a side stream; "
-                                         "2 forward GEMM launches, loss, 2-3 backward launches, Adam) + stacking the three roles' "
-                                         "ids and masks" if fused is None else
-                                         "one gather for the three roles, projection fwd x2 per tower, triplet fwd+bwd, projection "
-                                         "bwd x3 + one slab reduction per tower, 1 multi-tensor Adam, ~5 torch ops")},
-        "roofline": None, "avg_loss": avg,
-        "calibration": (getattr(getattr(opt, "_tt_route", None), "trainer", None).calibration
-                        if getattr(opt, "_tt_route", None) is not None else None),
-    }
 
 
 def secondary_c4(args, world, rank, device) -> dict:

@@ -88,21 +88,27 @@ def test_module_forward_backward_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["kat0.npz", "step_mid.npz"])
-@pytest.mark.parametrize("opt", ["fused-engine", "fused-modules", "torch"])
+@pytest.mark.parametrize("opt", ["fused-engine", "fused-modules", "torch", "torch-modules"])
 def test_train_epoch_module_path_matches_reference(name, opt):
     """`train_epoch` with the reference's signature on the reference's kind of batches (string lists through the towers'
-    tokenizer): with FusedAdam the batch body runs on the fused engine (`fused=None` routes it), with `fused=False` or a
-    torch optimizer module by module — each against the epoch the reference's own train_epoch produced."""
+    tokenizer).  The reference's literal call — `torch.optim.Adam(model.parameters(), lr)` (backend/training.py:436) — and
+    FusedAdam both have their batch body run on the fused engine (`fused=None` routes it); `fused=False` runs module by
+    module — each against the epoch the reference's own train_epoch produced."""
     from two_towers_overlords_amd.model import TripletLoss
     from two_towers_overlords_amd.training import FusedAdam, train_epoch
 
     g = load_golden(name)
     m, texts = build_model(g)
     lr = float(g["lr"])
-    optim = torch.optim.Adam(m.parameters(), lr=lr) if opt == "torch" else FusedAdam(m.parameters(), lr=lr)
+    optim = torch.optim.Adam(m.parameters(), lr=lr) if opt.startswith("torch") else FusedAdam(m.parameters(), lr=lr)
     avg = train_epoch(m, texts, TripletLoss(margin=float(g["margin"])), optim, log_wandb=False,
-                      fused=(False if opt == "fused-modules" else None))
-    assert (getattr(optim, "_tt_route", None) is not None) == (opt == "fused-engine")
+                      fused=(False if opt.endswith("-modules") else None))
+    assert (getattr(optim, "_tt_route", None) is not None) == (opt in ("fused-engine", "torch"))
+    if opt == "torch":  # the state is in torch.optim.Adam's own form: a 0-d float step tensor on the host, moments on the device
+        for p_ in m.trainable_parameters():
+            st = optim.state[p_]
+            assert isinstance(st["step"], torch.Tensor) and st["step"].device.type == "cpu" and float(st["step"]) == len(texts)
+            assert st["exp_avg"].shape == p_.shape and st["exp_avg"].is_cuda
     assert abs(avg - float(g["epoch/avg_loss"])) <= TOL
     sd = m.state_dict()
     for k in orc.PARAM_KEYS:
@@ -157,7 +163,8 @@ def test_train_epoch_on_the_engine_hands_its_state_to_the_optimizer_and_back():
     engine, epoch 2 module by module with the SAME optimizer object, epoch 3 on the engine again must be the three epochs
     of the module loop — parameters and Adam moments travel through `optimizer.state` (views of the engine's flat
     buffers) in both directions; `state_dict()` of model and optimizer show the trained values; pre-tokenised batches whose
-    roles differ in width; a torch optimizer or a second param group is not routed."""
+    roles differ in width; a second param group, or an Adam with arithmetic the engine does not implement (weight decay,
+    amsgrad), is not routed."""
     from two_towers_overlords_amd.model import TripletLoss
     from two_towers_overlords_amd.training import FusedAdam, train_epoch
 
@@ -187,7 +194,12 @@ def test_train_epoch_on_the_engine_hands_its_state_to_the_optimizer_and_back():
     for x, y in zip(m0, m1):
         assert (x - y).abs().max().item() <= 1e-6 * max(1.0, x.abs().max().item())
     m, _ = build_model(g)
-    train_epoch(m, batches, crit, torch.optim.Adam(m.parameters(), lr=lr), log_wandb=False)  # torch optimizer: the module loop
+    for kw in ({"weight_decay": 1e-2}, {"amsgrad": True}):
+        other = torch.optim.Adam(m.parameters(), lr=lr, **kw)
+        train_epoch(m, batches, crit, other, log_wandb=False)  # the module loop runs whatever the optimizer is
+        assert getattr(other, "_tt_route", None) is None
+        with pytest.raises(ValueError):
+            train_epoch(m, batches, crit, other, log_wandb=False, fused=True)
     two = FusedAdam([{"params": m.query_tower.projection.parameters()}, {"params": m.document_tower.projection.parameters()}], lr=lr)
     train_epoch(m, batches, crit, two, log_wandb=False)
     assert getattr(two, "_tt_route", None) is None
@@ -339,13 +351,16 @@ def test_trainer_accumulation_matches_oracle():
 
 
 @pytest.mark.parametrize("opt,plan", [("fused", (False, False)), ("torch", (False, False)), ("fused", (None, None)),
-                                      ("fused", (None, False)), ("fused", (False, None))],
-                         ids=["module,FusedAdam", "module,torch.Adam", "engine", "engine-then-module", "module-then-engine"])
+                                      ("fused", (None, False)), ("fused", (False, None)), ("torch", (None, None)),
+                                      ("torch", (None, False)), ("torch", (False, None))],
+                         ids=["module,FusedAdam", "module,torch.Adam", "engine", "engine-then-module", "module-then-engine",
+                              "engine,torch.Adam", "engine-then-module,torch.Adam", "module-then-engine,torch.Adam"])
 def test_train_epoch_optimized_matches_reference(opt, plan):
     """a12 behind the reference's signature: `train_epoch_optimized` (backend/training.py:66-75) against
     tests/golden/step_accum.npz, made by the reference's own function in fp32 — two epochs of five batches, k = 2:
     four optimizer steps, epoch 1's fifth gradient applied with epoch 2's first two.  Module by module, routed to the
-    fused engine (FusedAdam), and one epoch each way: the un-applied gradient travels through `p.grad` in both directions."""
+    fused engine (FusedAdam, and the reference's own torch.optim.Adam), and one epoch each way: the un-applied gradient
+    travels through `p.grad` in both directions."""
     from two_towers_overlords_amd.model import TripletLoss
     from two_towers_overlords_amd.training import FusedAdam, train_epoch_optimized
 
@@ -835,3 +850,84 @@ def test_trainer_checkpoint_resumes_bitwise_on_the_device():
     lb.append(c.train_epoch(dev))
     assert la == lb and c.step_count == a.step_count == 10
     assert torch.equal(a.flat, c.flat) and torch.equal(a.exp_avg, c.exp_avg) and torch.equal(a.exp_avg_sq, c.exp_avg_sq)
+
+
+def test_stock_adam_state_written_by_the_engine_loads_into_a_fresh_adam_and_continues_on_the_module_path():
+    """the reference's literal call — `torch.optim.Adam(model.parameters(), lr)` (backend/training.py:436)
+    — runs on the engine, and what it leaves behind is a stock Adam's state: `optimizer.state_dict()` written after a
+    routed epoch loads into a FRESH torch.optim.Adam over a fresh model, whose next epoch on the module path (torch's own
+    Adam kernels) equals the second epoch of an all-module run; and the other way round (module epoch -> state_dict ->
+    fresh Adam -> engine epoch)."""
+    import copy
+
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import train_epoch
+
+    g = load_golden("step_mid.npz")
+    nb, lr = int(g["n_batches"]), float(g["lr"])
+    batches = [_pretok(g, i) for i in range(nb)]
+    crit = TripletLoss(margin=float(g["margin"]))
+
+    def two_epochs(first, second):
+        m, _ = build_model(g)
+        opt = torch.optim.Adam(m.parameters(), lr=lr)
+        a1 = train_epoch(m, batches, crit, opt, log_wandb=False, fused=first)
+        assert (getattr(opt, "_tt_route", None) is not None) == (first is None)
+        osd = copy.deepcopy(opt.state_dict())
+        assert all(isinstance(st["step"], torch.Tensor) and float(st["step"]) == nb for st in osd["state"].values())
+        assert len(osd["state"]) == 8  # the eight trainable tensors; the frozen encoder has no state, as under torch
+        msd = {k: v.clone() for k, v in m.state_dict().items()}
+        m2, _ = build_model(g)
+        m2.load_state_dict(msd)
+        opt2 = torch.optim.Adam(m2.parameters(), lr=lr)
+        opt2.load_state_dict(osd)
+        a2 = train_epoch(m2, batches, crit, opt2, log_wandb=False, fused=second)
+        return (a1, a2, {k: v.clone() for k, v in m2.state_dict().items() if ".projection." in k},
+                [opt2.state[p]["exp_avg_sq"].clone() for p in m2.trainable_parameters()],
+                {float(opt2.state[p]["step"]) for p in m2.trainable_parameters()})
+
+    ref = two_epochs(False, False)
+    assert abs(ref[0] - float(g["epoch/avg_loss"])) <= TOL
+    for plan in ((None, False), (False, None), (None, None)):
+        got = two_epochs(*plan)
+        assert got[4] == ref[4] == {2.0 * nb}
+        assert abs(got[0] - ref[0]) <= TOL and abs(got[1] - ref[1]) <= TOL
+        for k in ref[2]:
+            assert_params_close(got[2][k].cpu().numpy(), ref[2][k].cpu().numpy(), lr, 2 * nb, tight=2e-6)
+        for x, y in zip(ref[3], got[3]):
+            assert (x - y).abs().max().item() <= 1e-6 * max(1.0, x.abs().max().item())
+
+
+def test_float_attention_mask_is_refused_not_truncated():
+    """Round-5 advisor finding: a floating-point mask carries WEIGHTS for the reference's `_mean_pooling`
+    (backend/model.py:63-72: `mask.float()` multiplies the embeddings); the auto-selected route used to cast it to int64
+    (0.5 -> 0, 1.5 -> 1) and train on something else.  It is refused now, before any state is touched, on the engine
+    route as on the module path (whose kernels take int32 / int64 masks); bool masks are 0/1 masks and are routed."""
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import train_epoch
+
+    g = load_golden("step_mid.npz")
+    nb, lr = int(g["n_batches"]), float(g["lr"])
+    crit = TripletLoss(margin=float(g["margin"]))
+    weighted = []
+    for i in range(nb):
+        roles = []
+        for ids, mask in _pretok(g, i):
+            w = mask.float()
+            w[:, 0] *= 0.5
+            w[:, 1::2] *= 1.5
+            roles.append((ids, w))
+        weighted.append(tuple(roles))
+    for fused in (False, None, True):
+        m, _ = build_model(g)
+        opt = torch.optim.Adam(m.parameters(), lr=lr)
+        before = [p.detach().clone() for p in m.trainable_parameters()]
+        with pytest.raises(TypeError, match="attention_mask"):
+            train_epoch(m, iter(weighted), crit, opt, log_wandb=False, fused=fused)
+        assert all(torch.equal(x, y) for x, y in zip(before, m.trainable_parameters())) and not opt.state
+    m, _ = build_model(g)
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    boolean = (tuple((ids, mask.bool()) for ids, mask in _pretok(g, i)) for i in range(nb))  # a generator: admit() chains batch 0 back
+    avg = train_epoch(m, boolean, crit, opt, log_wandb=False)
+    assert opt._tt_route is not None and abs(avg - float(g["epoch/avg_loss"])) <= TOL
+    assert {int(opt.state[p]["step"]) for p in m.trainable_parameters()} == {nb}

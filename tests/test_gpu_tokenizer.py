@@ -116,3 +116,123 @@ def test_real_tokenizer_through_the_token_loader_packed_files_and_run_training(t
         flat[cache] = torch.cat([p.detach().reshape(-1).cpu() for p in m.trainable_parameters()])
         assert torch.isfinite(flat[cache]).all()
     assert (flat[True] - flat[False]).abs().max() <= 2e-5
+
+
+class _DS(torch.utils.data.Dataset):
+    def __init__(self, items):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _marco_like(n_queries, n, rng):
+    qtext = _texts(n_queries, rng, 1, 8)
+    return [{"query_id": i % n_queries, "query": qtext[i % n_queries], "positive": t} for i, t in enumerate(_texts(n, rng, 3, 40))]
+
+
+def test_string_batches_are_tokenised_once_and_train_like_the_reference_loop(tok, monkeypatch):
+    """`train_epoch(model, batches of strings, TripletLoss, torch.optim.Adam)` — the reference's literal
+    call (backend/training.py:26-63,436) — on the engine with the route's text store: every text goes through the
+    tokenizer ONCE (epoch 1), epochs 2 and 3 make no tokenizer call at all, and the three epochs are the module loop's
+    (which tokenises three lists per batch like backend/model.py:43-48) — losses, parameters, Adam moments."""
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import train_epoch
+
+    rng = random.Random(7)
+    items = _marco_like(40, 160, rng)
+    B = 32
+    batches = []
+    for s in range(0, len(items), B):
+        chunk = items[s: s + B]
+        neg = [(i * 7 + 3) % len(chunk) for i in range(len(chunk))]
+        batches.append(([c["query"] for c in chunk], [c["positive"] for c in chunk], [chunk[j]["positive"] for j in neg]))
+    crit = TripletLoss(margin=0.3)
+    calls = {"n": 0, "texts": 0}
+    real = type(tok).__call__
+
+    def counting(self, texts, *a, **kw):
+        calls["n"] += 1
+        calls["texts"] += len(texts)
+        return real(self, texts, *a, **kw)
+
+    monkeypatch.setattr(type(tok), "__call__", counting)
+    out = {}
+    for mode in ("modules", "engine-inline", "engine-cached"):
+        model, _ = _model(tok, 48, 3)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        calls.update(n=0, texts=0)
+        per_epoch, losses = [], []
+        for _ in range(3):
+            losses.append(train_epoch(model, batches, crit, opt, log_wandb=False, fused=(False if mode == "modules" else None),
+                                      text_cache=(None if mode == "engine-cached" else False)))
+            per_epoch.append(calls["texts"])
+        assert (getattr(opt, "_tt_route", None) is not None) == (mode != "modules")
+        out[mode] = (losses, [p.detach().clone() for p in model.trainable_parameters()],
+                     [opt.state[p]["exp_avg"].clone() for p in model.trainable_parameters()], per_epoch)
+        if mode == "engine-cached":
+            store = opt._tt_route.text_store
+            distinct = len({c["query"] for c in items}) + len({c["positive"] for c in items})
+            assert per_epoch == [distinct, distinct, distinct]  # nothing tokenised after the first epoch, nothing twice
+            st = store.stats()
+            assert st["rows"] == distinct == st["texts_tokenized"] and st["width"] % 64 == 0
+            # the rows hold the tokenizer's own ids, TT_PAD_ID behind them
+            enc = real(tok, [items[5]["positive"]], padding=True, truncation=True, return_tensors="pt", max_length=512)
+            row = store._by_text[id(tok)][items[5]["positive"]]
+            got = store.ids[row].cpu()
+            n = enc["input_ids"].shape[1]
+            assert torch.equal(got[:n].long(), enc["input_ids"][0]) and bool((got[n:] == -(2 ** 31)).all())
+        else:
+            assert per_epoch[2] == 3 * per_epoch[0] == 9 * len(items)  # the reference's three tokenizer calls per batch
+    ref = out["modules"]
+    for mode in ("engine-inline", "engine-cached"):
+        got = out[mode]
+        for a, b in zip(ref[0], got[0]):
+            assert abs(a - b) <= 1e-5
+        for x, y in zip(ref[1], got[1]):
+            assert (x - y).abs().max().item() <= 2e-5 * max(1.0, x.abs().max().item())
+        for x, y in zip(ref[2], got[2]):
+            assert (x - y).abs().max().item() <= 1e-5 * max(1.0, x.abs().max().item())
+
+
+def test_triplet_dataloader_batches_carry_their_dataset_rows_through_the_text_store(tok):
+    """This package's `TripletDataLoader` (backend/data.py:90-152: same shuffle, same draws) yields lists of strings that
+    also say which dataset item each string is; the route turns them into store rows with index arithmetic — no per-text
+    look-up — and the run is the module loop's under the same seeds.  The store grows in rows and in width while gathers
+    are in flight (it starts at 4096 x 64; positives here reach past 64 tokens)."""
+    from two_towers_overlords_amd.data import TextColumn, TripletDataLoader
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import train_epoch
+
+    rng = random.Random(11)
+    items = _marco_like(60, 300, rng)
+    long_doc = " ".join(rng.choice(WORDS) for _ in range(150))
+    items[17]["positive"] = long_doc
+    ds = _DS(items)
+    crit = TripletLoss(margin=0.3)
+    out = {}
+    for fused in (False, None):
+        model, _ = _model(tok, 32, 5)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        random.seed(21)
+        torch.manual_seed(21)
+        dl = TripletDataLoader(ds, batch_size=64, num_workers=0)
+        q, p, n = next(iter(dl))
+        assert isinstance(q, TextColumn) and isinstance(q, list) and q.field == "query" and n.field == "positive"
+        assert all(items[r]["query"] == t for r, t in zip(q.rows, q)) and all(items[r]["positive"] == t for r, t in zip(n.rows, n))
+        random.seed(22)
+        torch.manual_seed(22)
+        losses = [train_epoch(model, dl, crit, opt, log_wandb=False, fused=fused) for _ in range(3)]
+        out[fused] = (losses, [p_.detach().clone() for p_ in model.trainable_parameters()])
+        if fused is None:
+            store = opt._tt_route.text_store
+            st = store.stats()
+            assert st["rows"] == 2 * len(items) == st["texts_tokenized"]  # one row per dataset field, filled once
+            assert not store._by_text and st["width"] >= 128              # no dict look-ups; widened for the long passage
+    for a, b in zip(out[False][0], out[None][0]):
+        assert abs(a - b) <= 1e-5
+    for x, y in zip(out[False][1], out[None][1]):
+        assert (x - y).abs().max().item() <= 2e-5 * max(1.0, x.abs().max().item())

@@ -34,9 +34,18 @@ def sample_negative_indices(query_ids: Sequence[int], rng=random,
     other item qualifies and raises IndexError for a batch of one."""
     n = len(query_ids)
     out = []
+    # `rng.choice([k for k in range(n) if k != i])` is `seq[rng._randbelow(n - 1)]` (CPython's Random.choice) over a list
+    # whose r-th entry is r + (r >= i): the same draw from the same generator state without building the list — O(B) per
+    # batch where the reference's loop is O(B^2) (0.4 s of Python per 2048-item batch).  A generator without
+    # `_randbelow` (not a random.Random) takes the literal form.
+    below = getattr(getattr(rng, "_inst", rng), "_randbelow", None) if n > 1 else None  # the `random` module draws from `_inst`
     for i in range(n):
         while True:
-            j = rng.choice([k for k in range(n) if k != i])
+            if below is not None:
+                r = below(n - 1)
+                j = r + (r >= i)
+            else:
+                j = rng.choice([k for k in range(n) if k != i])
             if (positive_nonempty is None or positive_nonempty[j]) and query_ids[j] != query_ids[i]:
                 out.append(j)
                 break
@@ -143,14 +152,43 @@ class PackedTokens:
         return torch.from_numpy(out).to(device), torch.from_numpy(ln.astype(np.int32)).to(device)
 
 
+class TextColumn(list):
+    """A `list[str]` that also says where its strings come from: text i is field `field` ("query" | "positive") of item
+    `rows[i]` (an int64 numpy array) of the map-style dataset `source`.  To every consumer of backend/data.py:139-152's batches it IS the list
+    of strings; the drop-in `train_epoch` route reads the rows and skips both the tokenizer and a per-text look-up for
+    texts it has stored before (textstore.py)."""
+
+    __slots__ = ("source", "field", "rows")
+
+    def __init__(self, texts, source, field: str, rows):
+        super().__init__(texts)
+        self.source, self.field, self.rows = source, field, rows
+
+
+class _WithRow(torch.utils.data.Dataset):
+    """dataset[i] plus the index i itself (as "_row"): default collation turns it into a tensor beside query_id."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __len__(self) -> int:
+        return len(self.dataset)
+
+    def __getitem__(self, i):
+        item = dict(self.dataset[i])
+        item["_row"] = int(i)
+        return item
+
+
 class TripletDataLoader:
-    """Creates (queries, positives, negatives) string batches.  Mirrors backend/data.py:90-152."""
+    """Creates (queries, positives, negatives) string batches.  Mirrors backend/data.py:90-152.  The three lists are
+    `TextColumn`s: plain lists of strings that also carry the dataset index behind every string."""
 
     def __init__(self, dataset, batch_size: int = 1024, num_workers: int = 4, device: Optional[torch.device] = None):
         self.dataset = dataset
         self.batch_size = batch_size
         self.dataloader = DataLoader(
-            dataset,
+            _WithRow(dataset),
             batch_size=batch_size,
             shuffle=True,
             num_workers=num_workers,
@@ -164,12 +202,21 @@ class TripletDataLoader:
         neg_idx = sample_negative_indices([int(item["query_id"]) for item in batch],
                                           positive_nonempty=[bool(item["positive"]) for item in batch])
         negatives = [batch[j]["positive"] for j in neg_idx]
+        if all("_row" in item for item in batch):
+            import numpy as np
+
+            rows = np.fromiter((item["_row"] for item in batch), dtype=np.int64, count=len(batch))
+            return (TextColumn(queries, self.dataset, "query", rows), TextColumn(positives, self.dataset, "positive", rows),
+                    TextColumn(negatives, self.dataset, "positive", rows[np.asarray(neg_idx, dtype=np.int64)]))
         return queries, positives, negatives
 
     def __iter__(self) -> Iterator[Triplet]:
         for batch in self.dataloader:
+            rows = batch["_row"].tolist()
+            qid = batch["query_id"]
+            qid = qid.tolist() if isinstance(qid, torch.Tensor) and not qid.is_floating_point() else qid  # int(0-d tensor) per item is slow
             batch_list = [
-                {"query": batch["query"][i], "positive": batch["positive"][i], "query_id": batch["query_id"][i]}
+                {"query": batch["query"][i], "positive": batch["positive"][i], "query_id": qid[i], "_row": rows[i]}
                 for i in range(len(batch["query"]))
             ]
             yield self.create_triplets(batch_list)

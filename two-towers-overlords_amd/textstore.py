@@ -1,0 +1,139 @@
+"""TextRowStore — the token store behind STRING batches of the drop-in `train_epoch` route.
+
+backend/training.py:36-42 hands `model.encode_*` three lists of strings per batch and backend/model.py:43-48 runs the
+tokenizer on each of them, every batch of every epoch (9-15 epochs over the same texts, backend/main.py:18-85).  The ids
+of a text never change, so here a text is tokenised the FIRST time it is seen: its ids go into one row of a
+device-resident int32 store (`TT_PAD_ID` behind the text's own tokens: include/tt_hotpath.h), and from then on a batch is
+`token_rows [3, B]` through `tt_engine_pool_rows` — 12 bytes per triplet, no tokenizer, no [B, S] int64 traffic.
+
+Two ways a text finds its row:
+
+* `TextColumn` lists (data.py: what this package's `TripletDataLoader` yields — plain `list[str]` to every other
+  consumer) say which dataset item each string is; the row is arithmetic on that index, a batch costs a few numpy ops.
+* any other `list[str]`: a dict lookup per text (hash + compare of the whole string: ~0.1 us per text for strings that
+  are the same Python objects every epoch, ~1 us for strings re-created by DataLoader worker processes — host-bound at
+  BASELINE configs[1]'s batch, but two orders of magnitude below the tokenizer it replaces).
+
+Only a tokenizer that maps a text to the same ids whatever else is in the call may be cached: transformers'
+tokenizers (`PreTrainedTokenizerBase`), or a callable that declares `tt_per_text = True`.
+"""
+from __future__ import annotations
+
+import operator
+import time
+from typing import Callable, Sequence
+
+import numpy as np
+import torch
+
+PAD32 = -(2 ** 31)  # TT_PAD_ID32 (include/tt_hotpath.h): weight 0 in every gather form, never read as a table row
+
+
+def per_text_tokenizer(tok) -> bool:
+    """True where tokenising a text alone or inside any batch gives the same ids (padding aside)."""
+    flag = getattr(tok, "tt_per_text", None)
+    if flag is not None:
+        return bool(flag)
+    try:
+        from transformers import PreTrainedTokenizerBase
+    except Exception:  # pragma: no cover  (transformers is optional)
+        return False
+    return isinstance(tok, PreTrainedTokenizerBase)
+
+
+class TextRowStore:
+    """ids [capacity, width] int32 on `device`; rows are handed out once and filled once."""
+
+    def __init__(self, device, max_S: int = 512, rows: int = 4096, width: int = 64):
+        self.device, self.max_S = torch.device(device), int(max_S)
+        self.ids = torch.full((int(rows), int(width)), PAD32, dtype=torch.int32, device=self.device)
+        self.filled = np.zeros(int(rows), dtype=bool)
+        self.n = 0                 # rows handed out
+        self._by_text = {}         # tokenizer key -> {text: row}
+        self._by_source = {}       # id(dataset) -> (dataset, base row, len(dataset))
+        self.tokenize_s = 0.0      # host seconds inside tokenizer calls
+        self.texts_tokenized = 0
+        self.tokens_stored = 0
+
+    # -- rows ----------------------------------------------------------------------
+    def _reserve(self, k: int) -> int:
+        base = self.n
+        self.n += int(k)
+        if self.n > self.filled.shape[0]:
+            cap = max(self.n, 2 * self.filled.shape[0])
+            self.filled = np.concatenate([self.filled, np.zeros(cap - self.filled.shape[0], dtype=bool)])
+        return base
+
+    def _room(self, rows_needed: int, width_needed: int) -> None:
+        """The device tensor holds rows [0, rows_needed) at width >= width_needed.  A re-allocation leaves the old tensor
+        to the caching allocator; gathers still reading it hold it through `record_stream` (TripletTrainer.gather)."""
+        cap, W = self.ids.shape
+        if width_needed > self.max_S:
+            raise ValueError(f"a text of {width_needed} tokens exceeds {self.max_S} (the tokenizer's max_length, backend/model.py:44)")
+        new_W = W if width_needed <= W else min(self.max_S, -(-width_needed // 64) * 64)
+        new_cap = cap if rows_needed <= cap else max(rows_needed, 2 * cap)
+        if (new_cap, new_W) != (cap, W):
+            grown = torch.full((new_cap, new_W), PAD32, dtype=torch.int32, device=self.device)
+            grown[:cap, :W].copy_(self.ids)
+            self.ids = grown
+
+    def _fill(self, rows: np.ndarray, texts: Sequence[str], tokenize: Callable) -> None:
+        t0 = time.perf_counter()
+        enc = tokenize(list(texts))  # backend/model.py:43-45 on the texts not seen before (CPU tensors)
+        self.tokenize_s += time.perf_counter() - t0
+        ids = torch.as_tensor(enc["input_ids"])
+        mask = enc.get("attention_mask")
+        if ids.dim() != 2 or ids.shape[0] != len(texts):
+            raise ValueError("tokenizer returned input_ids that are not [len(texts), S]")
+        if int(ids.max()) > 2 ** 31 - 1 or int(ids.min()) < 0:
+            raise ValueError("token ids outside int32")
+        packed = ids.to(torch.int32)
+        if mask is not None:
+            mask = torch.as_tensor(mask)
+            if not bool(((mask == 0) | (mask == 1)).all()):
+                raise ValueError("a weight mask (values other than 0/1) cannot be stored as rows")
+            packed = torch.where(mask != 0, packed, torch.full((), PAD32, dtype=torch.int32))
+            self.tokens_stored += int(mask.sum())
+        else:
+            self.tokens_stored += ids.numel()
+        self._room(int(rows.max()) + 1, packed.shape[1])
+        self.ids[:, : packed.shape[1]].index_copy_(0, torch.from_numpy(rows.astype(np.int64)).to(self.device),
+                                                   packed.contiguous().to(self.device))
+        self.filled[rows] = True
+        self.texts_tokenized += len(texts)
+
+    # -- the two look-ups ------------------------------------------------------------
+    def rows_of_texts(self, key, texts: Sequence[str], tokenize: Callable) -> np.ndarray:
+        d = self._by_text.setdefault(key, {})
+        try:
+            got = operator.itemgetter(*texts)(d) if len(texts) > 1 else (d[texts[0]],)
+        except KeyError:
+            missing = [t for t in dict.fromkeys(texts) if t not in d]
+            base = self._reserve(len(missing))
+            self._fill(np.arange(base, base + len(missing)), missing, tokenize)
+            d.update(zip(missing, range(base, base + len(missing))))
+            got = operator.itemgetter(*texts)(d) if len(texts) > 1 else (d[texts[0]],)
+        return np.fromiter(got, dtype=np.int64, count=len(texts))
+
+    def rows_of_column(self, col, tokenize: Callable) -> np.ndarray:
+        """`col`: a data.TextColumn — text i is field `col.field` of item `col.rows[i]` of dataset `col.source`."""
+        ent = self._by_source.get(id(col.source))
+        if ent is None or ent[2] != len(col.source):
+            n = len(col.source)
+            ent = self._by_source[id(col.source)] = (col.source, self._reserve(2 * n), n)  # queries, then positives
+        _, base, n = ent
+        rows = np.asarray(col.rows, dtype=np.int64)
+        if rows.shape[0] != len(col) or (rows.size and (rows.min() < 0 or rows.max() >= n)):
+            raise ValueError("TextColumn.rows does not index its source dataset")
+        rows = rows + (base if col.field == "query" else base + n)
+        new = ~self.filled[rows]
+        if new.any():
+            idx = np.flatnonzero(new)
+            uniq, first = np.unique(rows[idx], return_index=True)
+            self._fill(uniq, [col[int(i)] for i in idx[first]], tokenize)
+        return rows
+
+    def stats(self) -> dict:
+        return {"rows": int(self.filled.sum()), "width": int(self.ids.shape[1]), "texts_tokenized": self.texts_tokenized,
+                "tokens_stored": self.tokens_stored, "tokenize_s": self.tokenize_s,
+                "device_bytes": int(self.ids.numel() * 4)}

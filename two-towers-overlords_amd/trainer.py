@@ -44,6 +44,10 @@ class TripletBatch:
     # call (backend/model.py:43-48): the engine packs them on the gather stream (tt_engine_pool_roles; single replica,
     # an engine built with pack_roles=True)
     role_blocks: Optional[list] = None
+    # the store `token_rows` index, when it is not the trainer's own (set_token_store): ids [N, S] int32/int64 with
+    # TT_PAD_ID behind each text's tokens — the drop-in route's growing text store hands every batch the tensor that was
+    # current when the batch was made
+    token_store: Optional[torch.Tensor] = None
 
     @property
     def size(self) -> int:
@@ -63,7 +67,7 @@ class TripletBatch:
         ni = self.neg_index.long()
         cat = lambda t: None if t is None else torch.cat([t, t[1:2].index_select(1, ni)], dim=0).contiguous()
         return TripletBatch(cat(self.ids), cat(self.mask), cat(self.lens), None, cat(self.cache_rows), self.query_ids,
-                            cat(self.token_rows), self.ready_event)
+                            cat(self.token_rows), self.ready_event, token_store=self.token_store)
 
 
 def as_batch(b) -> TripletBatch:
@@ -98,6 +102,8 @@ class TrainerConfig:
     exchange: Optional[bool] = None          # gradients are exchanged (None: iff more than one replica; True on one rank: tests)
     split_exchange: Optional[bool] = False   # the exchange in two parts (None: calibrate() times both forms on the fabric)
     gather_under_exchange: bool = True       # the next gather is issued right before the exchange
+    local_only: bool = False                 # ignore an initialised process group: this process trains on its own (what the
+    #                                          reference's train_epoch does under any launcher; the drop-in route sets it)
 
 
 class TripletTrainer:
@@ -130,6 +136,7 @@ class TripletTrainer:
             cfg.margin, cfg.lr, cfg.betas, cfg.eps, cfg.accumulation_steps, cfg.loss, cfg.overlap_streams, cfg.k1_blocks_per_cu,
             cfg.use_graphs, cfg.freeze_gc, cfg.exchange, cfg.split_exchange, cfg.gather_under_exchange, cfg.tuning,
             cfg.event_scope, cfg.fence_at_loss, cfg.grad_slabs, cfg.join_carries_gather, cfg.pack_roles)
+        local_only = bool(cfg.local_only)
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
             # between gather and pool): the encoder is not part of the fused step — its pooled outputs are computed
@@ -178,7 +185,8 @@ class TripletTrainer:
                 p.data = self.flat[off: off + p.numel()].view(shape)
         self.model = model
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = (dist.get_world_size(process_group)
+                      if dist.is_available() and dist.is_initialized() and not local_only else 1)
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         # gradients are exchanged between replicas (see _all_reduce); `exchange=True` forces the data-parallel step's
         # code path on a single-rank group too (tests: the exchange is then an identity)
@@ -358,7 +366,7 @@ class TripletTrainer:
             self.side.wait_event(batch.ready_event)
         # K1 reads these tensors on the side stream: tell the caching allocator, so that memory the producer
         # drops right after this call is not handed out again before K1 has finished with it
-        for t in (batch.ids, batch.mask, batch.lens, batch.cache_rows, batch.token_rows,
+        for t in (batch.ids, batch.mask, batch.lens, batch.cache_rows, batch.token_rows, batch.token_store,
                   *(x for blk in (batch.role_blocks or ()) for x in blk)):
             if t is not None:
                 t.record_stream(self.side)
@@ -405,9 +413,12 @@ class TripletTrainer:
             else:
                 self.engine.pool_roles(slot, batch.role_blocks, stream=raw)
         elif batch.token_rows is not None:
-            if self.token_store is None:
+            if batch.token_store is not None:
+                self.engine.pool_rows(slot, batch.token_store, None, batch.token_rows, stream=raw)
+            elif self.token_store is None:
                 raise RuntimeError("batch carries token_rows but set_token_store() has not been called")
-            self.engine.pool_rows(slot, self.token_store[0], self.token_store[1], batch.token_rows, stream=raw)
+            else:
+                self.engine.pool_rows(slot, self.token_store[0], self.token_store[1], batch.token_rows, stream=raw)
         else:
             self.engine.pool(slot, batch.ids, batch.mask, batch.lens, stream=raw)
         if timed:
@@ -418,8 +429,10 @@ class TripletTrainer:
         """The collection's texts, tokenised once: ids [N, S] int32/int64 zero-padded rows,
         lens [N] int32 prefix lengths (None: full length), resident on the device.  Batches then name their
         texts by row (`TripletBatch.token_rows`) and K1 reads the ids through that indirection."""
-        if ids.dim() != 2 or ids.device != self.device:
-            raise ValueError("set_token_store: ids must be [N, S] on the trainer's device")
+        if ids.dim() != 2 or ids.device != self.device or ids.dtype not in (torch.int32, torch.int64):
+            raise ValueError("set_token_store: ids must be an int32 / int64 [N, S] tensor on the trainer's device")
+        if lens is not None and (lens.dim() != 1 or lens.shape[0] != ids.shape[0] or lens.dtype.is_floating_point):
+            raise ValueError("set_token_store: lens must be an integer [N] tensor, one prefix length per row of ids")
         if ids.shape[1] > self.engine.max_S:
             raise ValueError(f"set_token_store: rows of {ids.shape[1]} tokens exceed the engine's max_seq_len")
         if lens is not None:
@@ -643,6 +656,8 @@ class TripletTrainer:
         return {"flat": cpu(self.flat), "exp_avg": cpu(self.exp_avg), "exp_avg_sq": cpu(self.exp_avg_sq),
                 "bucket": cpu(self.bucket) if self.accumulation_steps > 1 else None,
                 "step_count": self.step_count, "micro": self._micro, "carry": self._carry, "D": self.D, "P": self.P,
+                # the gather form calibrate() chose where it had a choice (forms differ in fp32 summation order)
+                "k1_form": (self.calibration or {}).get("k1_form"),
                 "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "margin": self.margin,
                           "accumulation_steps": self.accumulation_steps}}
 
@@ -659,11 +674,21 @@ class TripletTrainer:
             self.bucket.copy_(sd["bucket"].to(self.device))
         self.step_count, self._micro = int(sd["step_count"]), int(sd["micro"])
         self._carry = bool(sd.get("carry", self._micro % self.accumulation_steps != 0))
+        form = sd.get("k1_form")
+        if form is not None and hasattr(self.engine, "set_tuning"):
+            # the run being resumed had calibrate() choose between the binned and the streaming gather: keep ITS choice (a
+            # later calibrate() on this trainer leaves the form alone)
+            base = {k: v for k, v in dict(self.engine.tuning or {}).items() if k != "k1_form"}
+            self.engine.set_tuning({**base, **({"k1_form": form} if form != "shape rule" else {})})
+            self._k1_form_loaded = form
+            self.calibration = {**(self.calibration or {}), "k1_form": form}
         if self._auto_step:
             self.engine.set_step(self.step_count)
 
     # -- calibration ----------------------------------------------------------------------
-    def calibrate(self, batch: Batch, steps: int = 48, rounds: int = 2, k1_forms: bool = False) -> dict:
+    INFINITY_CACHE_BYTES = 256 << 20  # MI355X MALL (MI355X_MICROARCH.md): a table beyond it really streams from HBM
+
+    def calibrate(self, batch: Batch, steps: int = 48, rounds: int = 2, k1_forms: Optional[bool] = None) -> dict:
         """Time the step's equivalent schedules on THIS device with THIS batch shape, in the regime the trainer will run
         in, and keep the fastest: phase B's two backward schedules (include/tt_hotpath.h, tt_engine_set_backward), where
         the gather's slot fence comes from (single replica), and — with a gradient exchange whose form the caller left
@@ -677,11 +702,15 @@ class TripletTrainer:
         Parameters, Adam state, step counters, the gradient bucket and loss statistics are untouched (no optimizer).
         A side effect worth knowing: the dry steps also bring the GPU from its idle power state to sustained clocks,
         which otherwise takes the first ~70 training steps (docs/LOG_r04.md §5 "Cold start").
-        `k1_forms=True` (opt-in) adds the gather's form as a candidate where the shape rule picks the binned form: that
-        rule assumes every table row is named about equally often, and on THIS batch's ids the streaming form may be
-        the faster one (log-uniform ids at configs[3]: 4.4 vs 5.6+ ms per step, profiles/r05_c4_skew.txt).  Unlike the
-        other candidates the two forms differ in fp32 summation order, so this choice moves results by rounding — which
-        is why it is not on by default: a run that must be bitwise repeatable fixes the form in `tuning`."""
+        `k1_forms` adds the gather's form as a candidate where the shape rule picks the binned form: that rule assumes
+        every table row is named about equally often, and on THIS batch's ids the streaming form may be the faster one
+        (log-uniform ids at configs[3]: 4.4 vs 5.1 ms per step, profiles/r05_c4_skew.txt).  None (default, round 6): on for
+        a table beyond the Infinity Cache — the only tables the binned form is picked for — unless `tuning` fixes a form.
+        Unlike the other candidates the two forms differ in fp32 summation order (both within the 1e-5 parity bound, each
+        bitwise run to run), so the choice is recorded — `calibration["k1_form"]`, and `state_dict()["k1_form"]`, which
+        `load_state_dict` re-applies so that a resumed run keeps its form; a run that must be bitwise repeatable ACROSS
+        calibrations fixes the form in `tuning`.  Data parallel: the candidate set is agreed between the ranks first (a
+        rank whose shard is too short to bin would otherwise run a different number of collectives)."""
         if self._pending:
             raise RuntimeError("calibrate(): call it between epochs (batches are still in flight)")
         if self.device.type != "cuda" or not hasattr(self.engine, "set_backward") or self.loss_kind != "triplet":
@@ -695,13 +724,29 @@ class TripletTrainer:
         forms = (False, True) if (self._exchange and self._split_auto) else (self._split,)
         base_tuning = dict(self.engine.tuning or {}) if hasattr(self.engine, "tuning") else {}
         gathers = (None,)
-        if (k1_forms and hasattr(self.engine, "set_tuning") and not base_tuning.get("k1_form") and b.ids is not None
-                and _lib.load().tt_k1_prefers_binned(self.engine.V, self.D, b.ids.shape[0] * b.size, b.ids.shape[2])):
+        if k1_forms is None:
+            k1_forms = (hasattr(self.engine, "V") and self.engine.V * self.D * 4 > self.INFINITY_CACHE_BYTES
+                        and getattr(self, "_k1_form_loaded", None) is None)
+        ids_like = b.ids if b.ids is not None else b.token_rows
+        width = (b.ids.shape[2] if b.ids is not None else
+                 (b.token_store if b.token_store is not None else (self.token_store or (None,))[0]))
+        if width is not None and not isinstance(width, int):
+            width = width.shape[1]
+        want = bool(k1_forms and hasattr(self.engine, "set_tuning") and not base_tuning.get("k1_form") and ids_like is not None
+                    and width is not None and b.size > 0
+                    and _lib.load().tt_k1_prefers_binned(self.engine.V, self.D, ids_like.shape[0] * b.size, width))
+        if self.world > 1 and k1_forms and hasattr(self.engine, "set_tuning"):
+            agree = torch.tensor([int(want)], dtype=torch.int32, device=self.device)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=self.pg)  # every rank times the same candidates, or none does
+            want = bool(int(agree.item()))
+        if want:
             gathers = (None, "stream")
         times = {(m, f, sp, kf): [] for m in ("fused", "fork") for f in fences for sp in forms for kf in gathers}
+        saved = (self._use_loss_fence, self._split, getattr(self.engine, "backward", None))
         self._dry = True
         if self._exchange and self.bucket is not None:
             self._dry_bucket = torch.zeros_like(self.bucket)  # the real bucket may hold an un-applied accumulation window
+        ok = False
         try:
             for _ in range(rounds):
                 for mode, fence, sp, kf in times:
@@ -721,7 +766,18 @@ class TripletTrainer:
                         self.apply(None)
                     e1.synchronize()
                     times[(mode, fence, sp, kf)].append(e0.elapsed_time(e1) / steps)
+            ok = True
         finally:
+            if not ok:  # an error mid-calibration: no candidate's settings and no dry batch may stay behind
+                try:
+                    if self._pending:
+                        self.abort_pipeline()
+                finally:
+                    self._use_loss_fence, self._split = saved[0], saved[1]
+                    if len(gathers) > 1:
+                        self.engine.set_tuning(base_tuning)
+                    if saved[2] is not None:
+                        self.engine.set_backward(saved[2])
             self._dry = False
             self._dry_bucket = None
         keys = list(times)

@@ -94,22 +94,30 @@ def _ids_mask(pair):
 
 
 def train_epoch(model: TwoTowersModel, dataloader, criterion: TripletLoss, optimizer: torch.optim.Optimizer,
-                log_wandb: bool = True, *, fused: Optional[bool] = None) -> float:
+                log_wandb: bool = True, *, fused: Optional[bool] = None, text_cache: Optional[bool] = None) -> float:
     """Train for one epoch.  Same signature, call sequence and return value as backend/training.py:26-63.
 
-    `fused` (additive): None = run the batch body on the fused engine when the arguments allow it — `FusedAdam` over
-    this model's trainable tensors, a plain `TripletLoss`, both towers in `embed` mode on one frozen table on the GPU,
-    no per-batch wandb logging — with the same results (the engine is held to the same reference fixtures as this loop)
-    at the engine's speed: no autograd graph, one gather for the three roles running two batches ahead on its own
-    stream, Adam state and parameters staying visible through `optimizer.state` / `model.state_dict()`.  False = the
-    module-by-module loop below; True = raise if the engine cannot take this call."""
+    `fused` (additive): None = run the batch body on the fused engine when the arguments allow it — the reference's own
+    `torch.optim.Adam(model.parameters(), lr)` (backend/training.py:436; any Adam whose single param group has the
+    arithmetic K4 implements: no weight decay / amsgrad / maximize / capturable) or `FusedAdam` over this model's
+    trainable tensors, a plain `TripletLoss`, both towers in `embed` mode on one frozen table on the GPU, no per-batch
+    wandb logging — with the same results (the engine is held to the same reference fixtures as this loop) at the
+    engine's speed: no autograd graph, one gather for the three roles running two batches ahead on its own stream,
+    Adam state and parameters staying visible through `optimizer.state` / `model.state_dict()` in the optimizer's OWN
+    form (a routed epoch's `optimizer.state_dict()` loads into a fresh optimizer of the same class).  False = the
+    module-by-module loop below; True = raise if the engine cannot take this call.
+    `text_cache` (additive; string batches on the engine route): None = texts are tokenised the first time they are seen
+    and live as rows of a device-resident token store afterwards (textstore.py) where the towers' tokenizer is a
+    per-text function (a transformers tokenizer); False = the three tokenizer calls of backend/model.py:43-48 on every
+    batch, as the reference does; True = raise if the tokenizer cannot be cached."""
     if fused is not False:
         route = _engine_route(model, criterion, optimizer, log_wandb)
         if route is not None:
-            return route.run_epoch(dataloader)
+            return route.run_epoch(route.admit(dataloader, text_cache))
         if fused:
-            raise ValueError("train_epoch(fused=True): needs FusedAdam over the model's trainable tensors, TripletLoss, "
-                             "`embed` towers sharing one table on a GPU, and no per-batch wandb logging")
+            raise ValueError("train_epoch(fused=True): needs torch.optim.Adam (default arithmetic) or FusedAdam over the model's "
+                             "trainable tensors, TripletLoss, `embed` towers sharing one table on a GPU, and no per-batch "
+                             "wandb logging")
     total_loss = 0.0
     num_batches = 0
     pending = []  # device-side losses not yet read: `loss.item()` (training.py:53) stalls the host on every batch, so the
@@ -137,12 +145,11 @@ def train_epoch(model: TwoTowersModel, dataloader, criterion: TripletLoss, optim
 
 def _engine_route(model, criterion, optimizer, log_wandb):
     """The _EngineRoute for (model, optimizer) if train_epoch's batch body can run on the fused engine, else None."""
-    if not isinstance(optimizer, FusedAdam) or type(criterion) is not TripletLoss or not isinstance(model, TwoTowersModel):
+    form = _adam_form(optimizer)
+    if form is None or type(criterion) is not TripletLoss or not isinstance(model, TwoTowersModel):
         return None
     if log_wandb and _HAVE_WANDB:  # per-batch wandb.log needs every batch's loss on the host: the module loop
         return None
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return None  # the reference's loop trains each process on its own; data parallel is TripletTrainer / run_training
     qt, dt = model.query_tower, model.document_tower
     if getattr(qt, "encoder_mode", None) != "embed" or getattr(dt, "encoder_mode", None) != "embed":
         return None
@@ -159,8 +166,41 @@ def _engine_route(model, criterion, optimizer, log_wandb):
     if route is None or route.model is not model:
         route = _EngineRoute(model, optimizer)
         optimizer._tt_route = route
+    route.form = form
     route.margin = float(criterion.margin)
     return route
+
+
+def _adam_form(optimizer) -> Optional[str]:
+    """"fused" for FusedAdam; "torch" for the reference's optimizer (backend/training.py:436 `torch.optim.Adam(
+    model.parameters(), lr)`) when its param group asks for exactly the update K4 computes — Adam with bias correction,
+    eps outside the square root, no weight decay / amsgrad / maximize, step counts kept on the host; else None (the
+    module loop runs whatever the optimizer is)."""
+    if isinstance(optimizer, FusedAdam):
+        return "fused"
+    if type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
+        return None
+    g = optimizer.param_groups[0]
+    if (g.get("weight_decay", 0) != 0 or g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable")
+            or g.get("fused") or g.get("decoupled_weight_decay")):
+        return None
+    if isinstance(g["lr"], torch.Tensor) and g["lr"].numel() != 1:
+        return None
+    return "torch"
+
+
+def _step_value(form: str, n: int):
+    """An optimizer step count in the form `optimizer.state[p]["step"]` has for this optimizer class: FusedAdam keeps an
+    int, torch.optim.Adam a 0-d float tensor on the host (torch/optim/adam.py `_init_group`, not capturable / fused)."""
+    if form != "torch":
+        return int(n)
+    try:
+        from torch.optim.optimizer import _get_scalar_dtype
+
+        dtype = _get_scalar_dtype()
+    except Exception:  # pragma: no cover
+        dtype = torch.float32
+    return torch.tensor(float(n), dtype=dtype)
 
 
 class _EngineRoute:
@@ -175,13 +215,18 @@ class _EngineRoute:
         self.model, self.optimizer = model, optimizer
         self.trainer = None
         self.margin = 0.3
+        self.form = "fused"  # how optimizer.state[p]["step"] is kept (see _step_value)
         self._bucket = None  # un-applied gradients between epochs: what the reference keeps in `.grad`
+        self.text_store = None  # textstore.TextRowStore behind string batches
+        self.text_cache = None  # train_epoch's `text_cache` for the running epoch
 
     def _build(self, B: int) -> None:
         group = self.optimizer.param_groups[0]
         old = self.trainer
-        tr = TripletTrainer(self.model, max_batch=B, max_seq_len=self.MAX_S, margin=self.margin, lr=group["lr"],
-                            betas=tuple(group["betas"]), eps=group["eps"], pack_roles=True)
+        # local_only: under an initialised process group the reference's loop still trains every process on its own
+        # (data parallel is TripletTrainer / run_training)
+        tr = TripletTrainer(self.model, max_batch=B, max_seq_len=self.MAX_S, margin=self.margin, lr=float(group["lr"]),
+                            betas=tuple(group["betas"]), eps=group["eps"], pack_roles=True, local_only=True)
         params = self.model.trainable_parameters()
         steps = set()
         for p, (_, off, shape) in zip(params, flat_param_slices(tr.D, tr.P)):
@@ -191,7 +236,7 @@ class _EngineRoute:
                 tr.exp_avg[off: off + n].copy_(st["exp_avg"].reshape(-1))
                 tr.exp_avg_sq[off: off + n].copy_(st["exp_avg_sq"].reshape(-1))
                 steps.add(int(st["step"]))
-            self.optimizer.state[p] = {"step": 0, "exp_avg": tr.exp_avg[off: off + n].view(shape),
+            self.optimizer.state[p] = {"step": _step_value(self.form, 0), "exp_avg": tr.exp_avg[off: off + n].view(shape),
                                        "exp_avg_sq": tr.exp_avg_sq[off: off + n].view(shape)}
         if len(steps) > 1:
             raise ValueError("train_epoch(fused): the optimizer's tensors have taken different numbers of steps")
@@ -228,7 +273,7 @@ class _EngineRoute:
 
     def _sync_steps(self, tr) -> None:
         for p in self.model.trainable_parameters():
-            self.optimizer.state[p]["step"] = tr.step_count
+            self.optimizer.state[p]["step"] = _step_value(self.form, tr.step_count)
 
     @staticmethod
     def _stack(queries, positives, negatives) -> "TripletBatch":
@@ -236,21 +281,84 @@ class _EngineRoute:
         engine packs the blocks (int64 -> int32 ids, attention masks -> prefix lengths, roles padded to the longest) in
         one pass on the gather stream (tt_engine_pool_roles).  Round 4 built [3, B, S] int64 id and mask stacks on the
         caller's stream instead — two copy kernels of ~10 us each in the projection chain — and the gather re-read the
-        int64 mask on each of its column passes (17 us): 202-219 us per configs[1] step against 170-175 for packed ids."""
+        int64 mask on each of its column passes (17 us): 202-219 us per configs[1] step against 170-175 for packed ids.
+        Integer / bool masks only.  A floating-point mask is refused like the module path refuses it (ops.gather_pool_norm:
+        "attention_mask: expected int32 or int64"): to the reference's `_mean_pooling` (backend/model.py:63-72) it would be a
+        WEIGHT mask, and truncating it to integers (round 5 did: 0.5 -> 0, 1.5 -> 1) pools something else."""
         blocks = []
         for ids, mask in (_ids_mask(x) for x in (queries, positives, negatives)):
             if mask is not None and mask.dtype not in (torch.int32, torch.int64):
-                mask = mask.to(torch.int64)  # bool / uint8 masks
+                if mask.dtype.is_floating_point or mask.dtype.is_complex:
+                    raise TypeError(f"attention_mask: expected an integer or bool 0/1 mask, got {mask.dtype} (a weight mask "
+                                    "cannot be packed; the tokenizer's masks are int64, backend/model.py:43-48)")
+                mask = mask.to(torch.int64)  # bool / uint8 / int8 / int16 masks
             blocks.append((ids.contiguous(), None if mask is None else mask.contiguous()))
         return TripletBatch(role_blocks=blocks)
+
+    @staticmethod
+    def _is_strings(x) -> bool:
+        return isinstance(x, (list, tuple)) and len(x) > 0 and isinstance(x[0], str)
+
+    def _text_batch(self, queries, positives, negatives) -> "TripletBatch":
+        """Three lists of strings -> rows of the route's token store (textstore.py): a text is tokenised the first time it
+        is seen (the towers' own tokenizer call, backend/model.py:43-45), then a batch is token_rows [3, B] int32."""
+        import numpy as np
+
+        from .data import TextColumn
+        from .textstore import TextRowStore
+
+        if not (len(queries) == len(positives) == len(negatives)):
+            raise ValueError("train_epoch(fused): queries, positives and negatives of a batch must have one length")
+        if self.text_store is None:
+            self.text_store = TextRowStore(self.model.query_tower.embedding_table().device, max_S=self.MAX_S)
+        store = self.text_store
+        rows = []
+        for tower, texts in ((self.model.query_tower, queries), (self.model.document_tower, positives),
+                             (self.model.document_tower, negatives)):
+            tok = tower.tokenizer
+            call = lambda t, tok=tok: tok(t, padding=True, truncation=True, return_tensors="pt", max_length=512)
+            if isinstance(texts, TextColumn) and texts.field in ("query", "positive"):
+                rows.append(store.rows_of_column(texts, call))
+            else:
+                rows.append(store.rows_of_texts(id(tok), texts, call))
+        host = torch.from_numpy(np.stack(rows).astype(np.int32)).pin_memory()
+        return TripletBatch(token_rows=host.to(store.device, non_blocking=True), token_store=store.ids)
+
+    def _use_text_cache(self) -> bool:
+        from .textstore import per_text_tokenizer
+
+        return (self.text_cache is not False and per_text_tokenizer(self.model.query_tower.tokenizer)
+                and per_text_tokenizer(self.model.document_tower.tokenizer))
 
     def _batches(self, dataloader):
         dt, qt = self.model.document_tower, self.model.query_tower
         for queries, positives, negatives in dataloader:
-            if isinstance(queries, (list, tuple)) and len(queries) and isinstance(queries[0], str):
+            if self._is_strings(queries):
+                if self._use_text_cache():
+                    yield self._text_batch(queries, positives, negatives)
+                    continue
                 tq, tp, tn = qt.tokenize(queries), dt.tokenize(positives), dt.tokenize(negatives)  # model.py:43-48, three calls
                 queries, positives, negatives = ((t["input_ids"], t.get("attention_mask")) for t in (tq, tp, tn))
             yield self._stack(queries, positives, negatives)
+
+    def admit(self, dataloader, text_cache: Optional[bool]):
+        """Look at the first batch before anything is enqueued or any state is touched: a mask the engine cannot pack, or
+        `text_cache=True` with a tokenizer that cannot be cached, raises here.  Returns the same sequence (the first batch
+        chained back).  A bad batch LATER in the epoch raises from run_epoch (nothing half-applied stays behind)."""
+        import itertools
+
+        self.text_cache = text_cache
+        it = iter(dataloader)
+        first = next(it, None)
+        if first is None:
+            return iter(())
+        if self._is_strings(first[0]):
+            if text_cache and not self._use_text_cache():
+                raise ValueError("train_epoch(text_cache=True): the towers' tokenizer is not a per-text function "
+                                 "(a transformers tokenizer, or a callable with tt_per_text = True)")
+        else:
+            self._stack(*first)
+        return itertools.chain([first], it)
 
     def _rebind(self) -> None:
         """The nn.Parameters and `optimizer.state[p]` must still BE views of the trainer's flat buffers.  After
@@ -266,7 +374,7 @@ class _EngineRoute:
                 p.data = view
             st = self.optimizer.state.get(p)
             if not st:  # a cleared optimizer state: zero moments, no steps taken (what torch does lazily)
-                st = self.optimizer.state[p] = {"step": 0}
+                st = self.optimizer.state[p] = {"step": _step_value(self.form, 0)}
             for key, buf in (("exp_avg", tr.exp_avg), ("exp_avg_sq", tr.exp_avg_sq)):
                 v = buf[off: off + n].view(shape)
                 t = st.get(key)
@@ -275,7 +383,7 @@ class _EngineRoute:
                 elif t.data_ptr() != v.data_ptr():
                     v.copy_(t.reshape(shape))
                 st[key] = v
-            st.setdefault("step", 0)
+            st.setdefault("step", _step_value(self.form, 0))
 
     def run_epoch(self, dataloader, accumulation_steps: Optional[int] = None) -> float:
         """One epoch.  accumulation_steps None: train_epoch (training.py:36-53: zero_grad, backward, step per batch, a
@@ -291,7 +399,7 @@ class _EngineRoute:
         self._check(first)
         if self.trainer is None or first.size > self.trainer.engine.max_B:
             self._build(first.size)
-            if first.size * max(i.shape[1] for i, _ in first.role_blocks) >= 65536:  # a batch worth timing: pick the backward schedule / fence placement
+            if first.size * self._seq_len(first) >= 65536:  # a batch worth timing: pick the backward schedule / fence placement
                 self.trainer.calibrate(first)             # for this device and shape (state-neutral, ~0.1 s once)
         self._rebind()
         accumulate = accumulation_steps is not None
@@ -374,11 +482,16 @@ class _EngineRoute:
         finally:
             tr = self.trainer
             if tr is not None:
-                if tr._pending:  # an exception mid-epoch: gathered-but-unapplied batches must not leak into the next call
-                    tr.abort_pipeline()
-                    self._sync_steps(tr)
-                    tr.engine.read_stats(reset=True)
-                tr.bucket, tr.accumulation_steps, tr._carry = None, 1, False
+                try:
+                    if tr._pending:  # an exception mid-epoch: gathered-but-unapplied batches must not leak into the next call
+                        tr.abort_pipeline()
+                        self._sync_steps(tr)
+                        try:
+                            tr.engine.read_stats(reset=True)
+                        except Exception:  # the flags it reports (weight mask, id out of range) must not replace the
+                            pass           # exception that ended the epoch; the reset has happened either way
+                finally:
+                    tr.bucket, tr.accumulation_steps, tr._carry = None, 1, False
 
     def _enter(self, accumulate: bool, accumulation_steps, carried=None) -> None:
         """Hyper-parameters, step count and the accumulation window of this call -> the trainer.  `carried` = (micro, carry)
@@ -403,7 +516,13 @@ class _EngineRoute:
             tr.bucket = None  # Adam reads the gradient slabs directly
         tr.engine.read_stats(reset=True)
 
+    @staticmethod
+    def _seq_len(b) -> int:
+        return b.token_store.shape[1] if b.role_blocks is None else max(i.shape[1] for i, _ in b.role_blocks)
+
     def _check(self, b) -> None:
+        if b.role_blocks is None:  # rows of the text store: widths and lengths were checked when the texts were stored
+            return
         S = max(i.shape[1] for i, _ in b.role_blocks)
         if S > self.MAX_S:
             raise ValueError(f"train_epoch(fused): rows of {S} tokens exceed {self.MAX_S} (the tokenizer's "
@@ -414,7 +533,8 @@ class _EngineRoute:
 
 def train_epoch_optimized(model: TwoTowersModel, dataloader, criterion: TripletLoss,
                           optimizer: torch.optim.Optimizer, device=None, scaler=None,
-                          accumulation_steps: int = 2, log_wandb: bool = True, *, fused: Optional[bool] = None) -> float:
+                          accumulation_steps: int = 2, log_wandb: bool = True, *, fused: Optional[bool] = None,
+                          text_cache: Optional[bool] = None) -> float:
     """Gradient-accumulation loop with the semantics of backend/training.py:66-133
     (`loss / accumulation_steps`, optimizer step + zero_grad every k-th batch,
     left-over gradients neither applied nor cleared at the end of the epoch), in
@@ -425,9 +545,10 @@ def train_epoch_optimized(model: TwoTowersModel, dataloader, criterion: TripletL
     model.train()
     route = _engine_route(model, criterion, optimizer, log_wandb) if fused in (None, True) else None
     if fused and route is None:
-        raise ValueError("train_epoch_optimized(fused=True): needs TwoTowersModel(embed) on a GPU, TripletLoss and FusedAdam")
+        raise ValueError("train_epoch_optimized(fused=True): needs TwoTowersModel(embed) on a GPU, TripletLoss and "
+                         "torch.optim.Adam (default arithmetic) or FusedAdam")
     if route is not None:
-        return route.run_epoch(dataloader, accumulation_steps=int(accumulation_steps))
+        return route.run_epoch(route.admit(dataloader, text_cache), accumulation_steps=int(accumulation_steps))
     total_loss = 0.0
     num_batches = 0
     for batch_idx, (queries, positives, negatives) in enumerate(dataloader):

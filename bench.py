@@ -293,6 +293,11 @@ def main():
     ap.add_argument("--epochs", type=int, default=3, help="--strings: epochs over the same --steps batches (1 cold + the rest warm)")
     ap.add_argument("--text-cache", type=int, default=1, choices=[0, 1],
                     help="--strings: 0 = train_epoch(text_cache=False): the three tokenizer calls on every batch, as the reference does")
+    ap.add_argument("--eval", action="store_true",
+                    help="SURVEY §8 f2: time evaluate_model (backend/training.py:136-380) at the reference's two shapes — queries/s "
+                         "end to end, the split, each device op alone with its roofline, the reference's per-query loop on the CPU "
+                         "oracle beside it (bench_eval.py); its own metric name")
+    ap.add_argument("--eval-repeats", type=int, default=3, help="--eval: timed calls per shape after one warm-up call (best is reported)")
     ap.add_argument("--debug-hostprof", action="store_true",
                     help="--strings: cProfile the last epoch's host side to stderr (the epoch is slower for it)")
     ap.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
@@ -382,6 +387,13 @@ def main():
             torch.cuda.synchronize(device)
             assert int(probe.item()) == world
 
+    if args.eval:
+        from bench_eval import run_eval
+
+        if world > 1:
+            sys.exit("--eval is a single-process measurement")
+        print(json.dumps(run_eval(args, device, CONFIGS)))
+        return
     if args.path != "engine":
         if world > 1:
             sys.exit("--path module is a single-process measurement")

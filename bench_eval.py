@@ -1,0 +1,258 @@
+"""bench.py --eval: SURVEY.md §8 f2 measured — `evaluate_model` (backend/training.py:136-380) on the device.
+
+Two shapes, the two the reference runs (backend/training.py:490, :505-521):
+  * validation:     20 query groups, candidate pools of <= 100 distractors per query, drawn from 1,000 sampled pairs;
+  * comprehensive:  200 query groups against EVERY unique passage of a 10,000-pair test split (`candidate_pool_size=-1`).
+Synthetic MS-MARCO-shaped data (~8 listed passages per query, 92.7 % of passages unique), texts
+through a real `transformers.BertTokenizerFast` over a synthetic vocabulary, `embed` towers at BASELINE configs[1]'s
+V / D / P.  Reported: queries/s end to end, the split sample / pools / tokenizer / encode / cosine scores / NDCG, each
+device op alone under HIP events with the roofline that bounds it, and the reference's per-query loop restated on the
+CPU oracle beside it (`cpu_baseline`, kind "port").  Own metric name; never the BASELINE headline.  Imported by bench.py only."""
+from __future__ import annotations
+
+import contextlib
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense v_mfma_f32_32x32x2_f32 peak
+HBM_GBS = 8000.0
+
+
+class MarcoLike:
+    """Map-style {"query_id", "query", "positive"} with `get_unique_passages()` (backend/data.py:13-87's surface):
+    n pairs, ~8 passages listed per query, 0.5 % of the passages listed twice (9,950 unique of 10,000)."""
+
+    def __init__(self, n: int, V: int, seed: int):
+        from bench_module import synthetic_texts
+
+        rng = np.random.default_rng(seed)
+        nq = max(n // 8, 1)
+        q_words = rng.integers(4, 15, size=nq)
+        by_len = {}
+        for w in sorted(set(q_words.tolist())):
+            by_len[w] = synthetic_texts(int((q_words == w).sum()), int(w), V, seed * 100 + w)
+        cursor = dict.fromkeys(by_len, 0)
+        queries = []
+        for w in q_words.tolist():
+            queries.append(by_len[w][cursor[w]])
+            cursor[w] += 1
+        n_unique = int(n * 0.995)  # 9,950 unique of 10,000: the test-split figure of BASELINE.md section 1
+        p_words = rng.integers(30, 127, size=n_unique)
+        by_len = {w: synthetic_texts(int((p_words == w).sum()), int(w), V, seed * 1000 + w) for w in sorted(set(p_words.tolist()))}
+        cursor = dict.fromkeys(by_len, 0)
+        passages = []
+        for w in p_words.tolist():
+            passages.append(by_len[w][cursor[w]])
+            cursor[w] += 1
+        pick = np.concatenate([np.arange(n_unique), rng.integers(0, n_unique, size=n - n_unique)])
+        rng.shuffle(pick)
+        self.items = [{"query_id": int(i % nq), "query": queries[i % nq], "positive": passages[int(pick[i])]} for i in range(n)]
+        self._unique = list(dict.fromkeys(it["positive"] for it in self.items))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+    def get_unique_passages(self):
+        return self._unique
+
+
+class TimedTokenizer:
+    """The tower's tokenizer, with the wall seconds of its calls added up (so the bench can name the tokenizer's share)."""
+
+    def __init__(self, tok):
+        self.tok, self.seconds, self.texts = tok, 0.0, 0
+
+    def __call__(self, texts, **kw):
+        t0 = time.perf_counter()
+        out = self.tok(texts, **kw)
+        self.seconds += time.perf_counter() - t0
+        self.texts += len(texts)
+        return out
+
+
+def _event_time(fn, iters: int, device) -> float:
+    """Average microseconds of fn() under HIP events on the current stream (3 untimed calls first)."""
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def _cpu_reference_loop(orc, tok, table, params, ds, sample_size, min_q, pool_size, seed, budget_s):
+    """backend/training.py:184-311 restated on the CPU oracle: per query `encode_queries([query])`, the candidate pool
+    encoded per query (or all unique passages once, pool_size -1), `torch.cosine_similarity`, sklearn `ndcg_score`
+    k = 10, 5, 1.  Stops after `budget_s` seconds of queries; returns (queries done, seconds, pre-encode seconds)."""
+    from sklearn.metrics import ndcg_score
+
+    from two_towers_overlords_amd.evaluation import candidate_pools, sample_query_groups
+
+    call = lambda texts: tok(texts, padding=True, truncation=True, return_tensors="pt", max_length=512)
+
+    def encode(texts, tower, bs=1024):
+        outs = []
+        for s in range(0, len(texts), bs):
+            enc = call(texts[s: s + bs])
+            pre = f"{tower}.projection."
+            outs.append(orc.tower_forward(table, enc["input_ids"], enc["attention_mask"], params[pre + "0.weight"],
+                                          params[pre + "0.bias"], params[pre + "2.weight"], params[pre + "2.bias"]))
+        return torch.cat(outs)
+
+    random.seed(seed)
+    t0 = time.perf_counter()
+    order, groups = sample_query_groups(ds, sample_size, min_q)
+    pre_s = 0.0
+    if pool_size == -1:
+        docs = list(ds.get_unique_passages())
+        tp = time.perf_counter()
+        all_embeds = encode(docs, "document_tower")
+        pre_s = time.perf_counter() - tp
+        pools = None
+    else:
+        pools = candidate_pools(order, groups, pool_size)
+    done = 0
+    tq = time.perf_counter()
+    for i, qid in enumerate(order):
+        rel = groups[qid].relevant
+        q = encode([groups[qid].query], "query_tower")
+        if pools is None:
+            pool, d = docs, all_embeds
+        else:
+            pool = pools[i]
+            d = encode(pool, "document_tower")
+        sims = torch.cosine_similarity(q, d, dim=1).numpy().reshape(1, -1)
+        truth = np.array([1 if doc in rel else 0 for doc in pool]).reshape(1, -1)
+        for k in (10, 5, 1):
+            ndcg_score(truth, sims, k=k)
+        done += 1
+        if time.perf_counter() - tq > budget_s:
+            break
+    return done, time.perf_counter() - t0, pre_s, len(order)
+
+
+def run_eval(args, device, CONFIGS) -> dict:
+    import two_towers_overlords_amd as pkg
+    from bench_module import synthetic_tokenizer
+    from oracle import two_towers_oracle as orc  # cpu_baseline only (the checker, timed beside the product)
+    from two_towers_overlords_amd import ops
+    from two_towers_overlords_amd.evaluation import evaluate_model
+    from two_towers_overlords_amd.model import EmbeddingOnlyEncoder, TwoTowersModel
+
+    pkg.load()
+    cfg = dict(CONFIGS[args.config])
+    V, D, P = cfg["V"], cfg["D"], cfg["P"]
+    table = torch.randn(V, D, generator=torch.Generator().manual_seed(1)) * 0.02
+    tok = TimedTokenizer(synthetic_tokenizer(V))
+    torch.manual_seed(2)
+    model = TwoTowersModel(projection_dim=P, tokenizer=tok, pretrained_model=EmbeddingOnlyEncoder(table), encoder_mode="embed").to(device)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items() if ".projection." in k}
+    val, test = MarcoLike(1000, V, 11), MarcoLike(10000, V, 12)
+    shapes = {"validation": dict(ds=val, sample_size=200, min_query_groups=20, candidate_pool_size=100, comprehensive=False),
+              "comprehensive": dict(ds=test, sample_size=len(test), min_query_groups=200, candidate_pool_size=-1, comprehensive=True)}
+    out = {}
+    with contextlib.redirect_stdout(sys.stderr):
+        for name, kw in shapes.items():
+            ds = kw.pop("ds")
+            runs = []
+            for rep in range(1 + max(args.eval_repeats, 1)):  # the first call is warm-up (allocations, first launches)
+                random.seed(100 + rep)
+                tok.seconds, tok.texts = 0.0, 0
+                tm = {}
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                res = evaluate_model(model, ds, batch_size=1024, log_wandb=False, timings=tm, **kw)
+                torch.cuda.synchronize(device)
+                total = time.perf_counter() - t0
+                tm.update(total_s=total, tokenizer_s=tok.seconds, texts_tokenized=tok.texts,
+                          ndcg_10=(res if isinstance(res, float) else res["final_ndcg_10"]))
+                if rep:
+                    runs.append(tm)
+            best = min(runs, key=lambda r: r["total_s"])
+            Q, N = best["Q"], best["N"]
+            # each device op alone, HIP events
+            q = torch.randn(Q, P, device=device)
+            d = torch.randn(N, P, device=device)
+            rel = (torch.rand(Q, N, device=device) < 8.0 / N).float()
+            valid = (torch.rand(Q, N, device=device) < 0.5).to(torch.uint8) if kw["candidate_pool_size"] != -1 else None
+            t_scores = _event_time(lambda: ops.cosine_scores(q, d), 50, device)
+            sc = ops.cosine_scores(q, d)
+            t_ndcg = _event_time(lambda: ops.ndcg_at_k(sc, rel, ks=(10, 5, 1), valid=valid), 50, device)
+            flops = 2.0 * Q * N * P
+            # rows read + unit rows written + unit rows read by the GEMM + scores written
+            bytes_scores = 4.0 * (3 * (Q + N) * P + Q * N)
+            no_tok = best["total_s"] - best["tokenizer_s"]
+            out[name] = {
+                "Q": Q, "N_unique_docs": N, "P": P, "kwargs": {k: v for k, v in kw.items()},
+                "queries_per_s_end_to_end": Q / best["total_s"], "queries_per_s_without_tokenizer": Q / no_tok,
+                "seconds": {k: best[k] for k in ("total_s", "sample_s", "pools_s", "encode_s", "tokenizer_s", "scores_s", "ndcg_s")},
+                "encode_without_tokenizer_s": best["encode_s"] - best["tokenizer_s"], "texts_tokenized": best["texts_tokenized"],
+                "ndcg_10": best["ndcg_10"], "repeats": len(runs), "all_totals_s": [r["total_s"] for r in runs],
+                "cosine_scores": {"us": t_scores, "flop": flops, "tflops": flops / t_scores / 1e6,
+                                  "frac_of_f32_mfma_peak": flops / t_scores / 1e6 / F32_MFMA_TFLOPS,
+                                  "algorithmic_bytes": bytes_scores, "gbs": bytes_scores / t_scores / 1e3,
+                                  "frac_of_hbm": bytes_scores / t_scores / 1e3 / HBM_GBS,
+                                  "floor_us": max(flops / F32_MFMA_TFLOPS / 1e6, bytes_scores / HBM_GBS / 1e3),
+                                  "kernels": "unit_rows_kernel x2 + gemm_f32_kernel<NT> (exact f32 MFMA)"},
+                "ndcg_at_10_5_1": {"us": t_ndcg, "kernels": "ndcg_kernel: one workgroup per query, <= 2 x 10 passes over its N scores",
+                                   "bytes_per_pass": Q * N * (8 + (1 if valid is not None else 0))},
+            }
+        # the reference's loop on the CPU oracle (rank 0, bounded)
+        cpu = {}
+        if not args.no_cpu_baseline:
+            try:  # the cores this process may run on, capped at the box's per-GPU CPU share (bench.py cpu_baseline)
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            cores = max(1, min(avail, 16))
+            torch.set_num_threads(cores)
+            for name, (ds, ss, mq, pool, budget) in {"validation": (val, 200, 20, 100, 8.0),
+                                                     "comprehensive": (test, len(test), 200, -1, 12.0)}.items():
+                done, secs, pre_s, planned = _cpu_reference_loop(orc, tok.tok, table, params, ds, ss, mq, pool, 100, budget)
+                cpu[name] = {"queries_done": done, "queries_planned": planned, "seconds": secs, "pre_encode_s": pre_s,
+                             "queries_per_s": done / secs,
+                             "queries_per_s_after_pre_encode": done / max(secs - pre_s, 1e-9)}
+    head = out["comprehensive"]
+    return {
+        "metric": ("queries/sec, evaluate_model (backend/training.py:136-380) end to end — sampling, candidate pools, tokenizer, "
+                   "encode, cosine scores, NDCG@10/5/1 — comprehensive shape (200 query groups x every unique passage of a "
+                   "10,000-pair split), `embed` towers; SURVEY §8 f2; NOT the BASELINE metric"),
+        "value": head["queries_per_s_end_to_end"], "unit": "queries/s", "n_gpus": 1, "steps": len(out), "warmup": 1,
+        "ms_per_step": head["seconds"]["total_s"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "evaluate_model at the reference's two shapes: validation (20 queries, pools of 100) and "
+                               "comprehensive (200 queries x all unique passages of 10,000 pairs)",
+                   "vocab": V, "embed_dim": D, "proj_dim": P, "encoder_mode": "embed",
+                   "tokenizer": "transformers.BertTokenizerFast over a synthetic vocab.txt", "queries_tokens": "6-16",
+                   "passage_tokens": "32-128", "host_threads": os.cpu_count()},
+        "shapes": out,
+        "roofline": {"bound": "mfma", "kernel": "tt_cosine_scores_f32 (comprehensive shape)",
+                     "achieved": head["cosine_scores"]["tflops"], "peak": F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": head["cosine_scores"]["frac_of_f32_mfma_peak"], "traffic": None,
+                     "note": ("2*Q*N*P = %.2f GFLOP is %.1f us at the f32 MFMA peak and its %.0f MB of operand / result traffic "
+                              "%.1f us at 8 TB/s: the op is three short launches, bound by launch latency and tile count, not by "
+                              "either roofline" % (head["cosine_scores"]["flop"] / 1e9, head["cosine_scores"]["flop"] / F32_MFMA_TFLOPS / 1e6,
+                                                   head["cosine_scores"]["algorithmic_bytes"] / 1e6,
+                                                   head["cosine_scores"]["algorithmic_bytes"] / HBM_GBS / 1e3))},
+        "cpu_baseline": ({"value": cpu["comprehensive"]["queries_per_s"], "unit": "queries/s", "cores": cores, "kind": "port",
+                          "sample": ("the reference's per-query loop (encode_queries([q]), torch.cosine_similarity against the "
+                                     "pre-encoded passages, sklearn ndcg_score k=10,5,1) on the CPU oracle, comprehensive shape, "
+                                     f"{cpu['comprehensive']['queries_done']} of {cpu['comprehensive']['queries_planned']} queries "
+                                     "+ the one-off pre-encode of all unique passages, tokenizer included"),
+                          "shapes": cpu} if cpu else None),
+        "published_context": {"value": 57.4, "unit": "queries/s", "hardware": "RTX 5090", "encoder_mode": "bert (full frozen MiniLM)",
+                              "source": "BASELINE.md section 1: sweeps/250617-8x5w5jxn-buffer.txt:616 — 57 it/s against 9,950 pre-encoded "
+                                        "documents; other hardware, other encoder mode: context, not a baseline"},
+    }

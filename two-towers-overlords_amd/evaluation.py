@@ -17,9 +17,11 @@ not need the host copies the reference makes.
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 import random
-from typing import Dict, List, Set, Tuple, Union
+import time
+from typing import Dict, List, Optional, Set, Tuple, Union
 
 import numpy as np
 import torch
@@ -79,47 +81,70 @@ def evaluate_model(
     log_wandb: bool = False,
     wandb_prefix: str = "final_",
     batch_size: int = 1024,
+    *,
+    timings: Optional[dict] = None,
 ) -> Union[float, dict]:
-    """NDCG@{10,5,1} over sampled query groups.  Mirrors backend/training.py:136-380."""
+    """NDCG@{10,5,1} over sampled query groups.  Mirrors backend/training.py:136-380.
+    `timings` (additive): a dict that receives the wall seconds of each stage (the device is synchronised at every stage
+    boundary, so the stages add up to the call; leave it None outside measurements) plus the evaluation's shape."""
+
+    @contextlib.contextmanager
+    def stage(name):
+        if timings is None:
+            yield
+            return
+        t0 = time.perf_counter()
+        yield
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        timings[name] = timings.get(name, 0.0) + time.perf_counter() - t0
+
     print(f"Sampling documents for evaluation (initial sample size: {sample_size})...")
     model.eval()
-    query_ids, groups = sample_query_groups(dataset, sample_size, min_query_groups)
+    with stage("sample_s"):
+        query_ids, groups = sample_query_groups(dataset, sample_size, min_query_groups)
     total_relevant_docs = sum(len(groups[qid].relevant) for qid in query_ids)
     avg_relevant_per_query = total_relevant_docs / len(query_ids)
     print(f"Selected {len(query_ids)} queries for evaluation")
 
     # candidate pools as (unique document list, per-query membership mask): -1 = every unique passage of the dataset
-    if candidate_pool_size == -1:
-        docs = list(dataset.get_unique_passages())
-        pools = None
-    else:
-        pools = candidate_pools(query_ids, groups, candidate_pool_size)
-        docs = list(dict.fromkeys(d for pool in pools for d in pool))
-    doc_index = {d: j for j, d in enumerate(docs)}
-    Q, N = len(query_ids), len(docs)
+    with stage("pools_s"):
+        if candidate_pool_size == -1:
+            docs = list(dataset.get_unique_passages())
+            pools = None
+        else:
+            pools = candidate_pools(query_ids, groups, candidate_pool_size)
+            docs = list(dict.fromkeys(d for pool in pools for d in pool))
+        doc_index = {d: j for j, d in enumerate(docs)}
+        Q, N = len(query_ids), len(docs)
 
-    relevance = np.zeros((Q, N), dtype=np.float32)
-    valid = None if pools is None else np.zeros((Q, N), dtype=np.uint8)
-    for i, query_id in enumerate(query_ids):
-        for d in groups[query_id].relevant:
-            j = doc_index.get(d)
-            if j is not None:
-                relevance[i, j] = 1.0
-        if pools is not None:
-            valid[i, [doc_index[d] for d in pools[i]]] = 1
+        relevance = np.zeros((Q, N), dtype=np.float32)
+        valid = None if pools is None else np.zeros((Q, N), dtype=np.uint8)
+        for i, query_id in enumerate(query_ids):
+            for d in groups[query_id].relevant:
+                j = doc_index.get(d)
+                if j is not None:
+                    relevance[i, j] = 1.0
+            if pools is not None:
+                valid[i, [doc_index[d] for d in pools[i]]] = 1
 
     # -- embeddings through the hot path, similarities and NDCG on the device
     with torch.no_grad():
-        query_embeds = model.encode_queries([groups[qid].query for qid in query_ids])
-        doc_embeds = model.encode_documents_batched(docs, batch_size=batch_size)
-        scores = ops.cosine_scores(query_embeds.contiguous(), doc_embeds.contiguous())
-        dev = scores.device
-        ndcg = ops.ndcg_at_k(
-            scores,
-            torch.from_numpy(relevance).to(dev),
-            ks=(10, 5, 1),
-            valid=None if valid is None else torch.from_numpy(valid).to(dev),
-        ).double().cpu().numpy()
+        with stage("encode_s"):  # tokenizer + K1 + K2 (the tokenizer's share: TwoTowersModel's towers time it, see bench_eval.py)
+            query_embeds = model.encode_queries([groups[qid].query for qid in query_ids])
+            doc_embeds = model.encode_documents_batched(docs, batch_size=batch_size)
+        with stage("scores_s"):
+            scores = ops.cosine_scores(query_embeds.contiguous(), doc_embeds.contiguous())
+        with stage("ndcg_s"):
+            dev = scores.device
+            ndcg = ops.ndcg_at_k(
+                scores,
+                torch.from_numpy(relevance).to(dev),
+                ks=(10, 5, 1),
+                valid=None if valid is None else torch.from_numpy(valid).to(dev),
+            ).double().cpu().numpy()
+    if timings is not None:
+        timings.update(Q=Q, N=N, P=int(query_embeds.shape[1]))
 
     ndcg_10_scores = ndcg[:, 0]
     mean_ndcg_10 = float(np.mean(ndcg_10_scores))

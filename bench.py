@@ -58,6 +58,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 
 # MI355X_MICROARCH.md "Indexed rows: gather into LDS": rows shared by every workgroup and served by the XCD's L2 are
 # gathered at 66-73 GB/s per CU = 16.8-18.8 TB/s chip-wide — the ceiling that binds a gather whose table is cache-resident
 L2_SHARED_ROWS_GBS = (16800.0, 18800.0)
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggregate
 CONFIG0 = dict(V=30522, D=384, P=64, B=256, S=128)  # BASELINE.json configs[0]: --batch-size 256 --projection-dim 64 (reference README.md:64-75)
 
 
@@ -76,7 +77,7 @@ def k2_mfma_util(config):
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_k2_mfma_util.txt")))
     if not paths:
         return None
-    want = {"c2": "configs[1] B=2048", "c3": "configs[2] one GPU", "c4": "configs[3]"}.get(config)
+    want = {"c2": "configs[1] B=2048", "c3": "configs[2] one GPU", "c4": "configs[3]"}.get(config, config)
     kernels, on = {}, False
     for line in open(paths[-1]):
         if line.startswith("=="):
@@ -258,9 +259,10 @@ def main():
                          "bucket) with the all-reduce replaced by a kernel of this duration on the caller's stream (where a "
                          "synchronous-op RCCL collective runs) — how much of an N-GPU all-reduce's latency the step would "
                          "expose (RCCL's own CU use is not modelled)")
-    ap.add_argument("--calibrate-k1", action="store_true",
-                    help="calibrate() also times the gather's form on this run's ids where the shape rule picks the binned form "
-                         "(TripletTrainer.calibrate(k1_forms=True)); the pick is in calibration.k1_form")
+    ap.add_argument("--calibrate-k1", type=int, default=None, choices=[0, 1],
+                    help="whether calibrate() also times the gather's form on this run's ids where the shape rule picks the "
+                         "binned form (TripletTrainer.calibrate(k1_forms=...)); default: the trainer's rule — on for a table "
+                         "beyond the Infinity Cache; the pick is in calibration.k1_form")
     ap.add_argument("--ids-form", default="packed", choices=["packed", "lens", "roles", "padids"],
                     help="diagnostic: how the engine path's batches carry their ids — packed int32 [3,B,S] (headline), the same "
                          "with full prefix lengths, or the tokenizer's form: three (int64 input_ids, int64 attention_mask) "
@@ -298,6 +300,11 @@ def main():
                          "end to end, the split, each device op alone with its roofline, the reference's per-query loop on the CPU "
                          "oracle beside it (bench_eval.py); its own metric name")
     ap.add_argument("--eval-repeats", type=int, default=3, help="--eval: timed calls per shape after one warm-up call (best is reported)")
+    ap.add_argument("--debug-trace", default=None, choices=["10", "step"],
+                    help="diagnostic: timing events inside the timed loop (every 10th step, or every step) printed to stderr")
+    ap.add_argument("--debug-prewarm-ms", type=float, default=0.0, help="diagnostic: keep the GPU busy this long before warm-up")
+    ap.add_argument("--debug-idle-ms", type=float, default=0.0, help="diagnostic: idle gap between warm-up and the timed region")
+    ap.add_argument("--debug-no-gc-freeze", action="store_true", help="diagnostic: skip gc.freeze() before the timed loop")
     ap.add_argument("--debug-hostprof", action="store_true",
                     help="--strings: cProfile the last epoch's host side to stderr (the epoch is slower for it)")
     ap.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
@@ -673,20 +680,20 @@ def run_config(args, world, rank, device) -> dict:
             else:
                 trainer.advance(None, B * world)
 
-    trace_every = 1 if os.environ.get("TT_TRACE") == "step" else 10  # TT_TRACE=step: one event per step
-    trace_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // trace_every)] if os.environ.get("TT_TRACE") else []
+    trace_every = 1 if args.debug_trace == "step" else 10  # --debug-trace step: one event per step
+    trace_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // trace_every)] if args.debug_trace else []
     trace_host = []
 
-    if os.environ.get("TT_GC_FREEZE", "1") == "1":  # (0: A/B of this very effect)
+    if not args.debug_no_gc_freeze:  # (--debug-no-gc-freeze: A/B of this very effect)
         # A full (generation-2) pass of Python's cyclic GC over the ~10^6 objects that importing torch leaves
         # behind takes 60-90 ms of host time; it used to land inside about one timed region in fifteen and
         # starve the GPU (step 200 -> 500 us).  Freeze what exists now: later passes only look at new objects.
         import gc
         gc.collect()
         gc.freeze()
-    if os.environ.get("TT_PREWARM_MS"):  # experiment: keep the GPU busy for a while before warm-up
+    if args.debug_prewarm_ms:  # experiment: keep the GPU busy for a while before warm-up
         a = torch.randn(4096, 4096, device=device)
-        tend = time.perf_counter() + float(os.environ["TT_PREWARM_MS"]) * 1e-3
+        tend = time.perf_counter() + args.debug_prewarm_ms * 1e-3
         while time.perf_counter() < tend:
             a @ a
             torch.cuda.synchronize(device)
@@ -701,7 +708,7 @@ def run_config(args, world, rank, device) -> dict:
     if not args.no_calibrate and not args.k1_only and args.loss == "triplet":
         trainer.calibrate(batches[0], steps=getattr(args, "calibrate_steps", 48),
                           rounds=getattr(args, "calibrate_rounds", 2),   # set-up: part of what run_training does before its first epoch
-                          k1_forms=bool(getattr(args, "calibrate_k1", False)))
+                          k1_forms=(None if getattr(args, "calibrate_k1", None) is None else bool(args.calibrate_k1)))
     set_up_steps = 0  # steps of this workload executed before the timed region besides --warmup
     if trainer.calibration:
         combos = len(trainer.calibration.get("ms_per_step_by_fence") or (0, 0))  # backward schedules x fence placements timed
@@ -720,8 +727,8 @@ def run_config(args, world, rank, device) -> dict:
             set_up_steps += 4
         run(args.warmup, timed=False)
         barrier()
-        if os.environ.get("TT_IDLE_MS"):  # experiment: idle gap between warm-up and the timed region
-            time.sleep(float(os.environ["TT_IDLE_MS"]) * 1e-3)
+        if args.debug_idle_ms:  # experiment: idle gap between warm-up and the timed region
+            time.sleep(args.debug_idle_ms * 1e-3)
         t0 = time.perf_counter()
         run(args.steps, timed=True)
         host_issue = time.perf_counter() - t0  # all K steps enqueued (no device sync inside the loop)
@@ -803,40 +810,55 @@ def run_config(args, world, rank, device) -> dict:
     if args.e2e:
         metric = (f"triplets/sec, one whole epoch of {args.steps} batches through TokenTripletLoader(sampler=device) + "
                   f"TripletTrainer.train_epoch, inputs={args.inputs} (end-to-end loop; NOT the BASELINE metric)")
-    # The bound that BINDS the gather: HBM where the table streams from it; where the table is cache-resident (or the binned
-    # form gathers a big table block by block out of the XCDs' L2s) the rate at which rows shared by all workgroups come out
-    # of the L2s (MI355X_MICROARCH.md, "Indexed rows: gather into LDS": 66-73 GB/s per CU = 16.8-18.8 TB/s; `peak` is the
-    # upper figure, so `frac` is the conservative one).  The 8 TB/s HBM figure BASELINE.json's metric names stays in the
-    # line as `nominal_hbm`: against a cache-resident table it is not a bound (its fraction can exceed 1).
+    # `bound` / `peak` / `frac` are the contract's figure on SURVEY.md section 8(d)'s definition: ALGORITHMIC bytes per launch ÷
+    # the launch's duration against the nominal 8 TB/s of HBM — the same denominator in every round (rounds 1-4 quoted it
+    # as `frac`, round 5 as `nominal_hbm.frac`), so the trend stays readable.  Against a cache-resident table that figure is
+    # not a physical bound (rows named many times are served by the caches; it can exceed 1), so what actually bounds the
+    # launch is spelled out beside it: `binding` says where the rows come from, `l2_peak` is the XCD L2s' aggregate rate
+    # (MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s), `reference_loop_rate` the guide's MEASURED rate of one LDS-staging
+    # gather loop over L2-resident shared rows (16.8-18.8 TB/s: "Per-CU rates (lower bounds)", not a hardware peak).
     cache_resident = V * D * 4 <= 200e6
     l2_bound = cache_resident or binned
     achieved_alone = alg / (iso_ms * 1e-3) / 1e9
-    peak = L2_SHARED_ROWS_GBS[1] if l2_bound else HBM_PEAK_GBS
+    table_bytes = V * D * 4
+    crossings = (traffic / table_bytes) if (traffic and binned) else None
     roofline = {
-        "kernel": k1_label, "bound": "l2_shared_rows" if l2_bound else "hbm",
-        "bound_note": ("the table (%.0f MB) is cache-resident: rows shared by every workgroup come out of the XCDs' L2s; the "
-                       "HBM figure the metric names is `nominal_hbm`" % (V * D * 4 / 1e6)) if cache_resident else
-                      ("the table (%.0f MB) exceeds the 256 MiB Infinity Cache, but the binned form gathers it block by block "
-                       "out of the XCDs' L2s — a table line crosses the fabric about once per launch however many tokens "
-                       "name it (`traffic`) — so the bound that binds is the L2s' shared-row rate" % (V * D * 4 / 1e6)) if binned else
-                      "the table (%.0f MB) exceeds the 256 MiB Infinity Cache and streams from HBM" % (V * D * 4 / 1e6),
-        "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-        "peak_range": list(L2_SHARED_ROWS_GBS) if l2_bound else None,
-        "peak_source": ("MI355X_MICROARCH.md, 'Indexed rows: gather into LDS': 66-73 GB/s per CU x 256 CUs" if l2_bound else
-                        "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)"),
+        "kernel": k1_label, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)",
         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms,
         "launches_timed": len(k1_ev),
+        "binding": "l2" if l2_bound else "hbm",
+        "bound_note": ("the table (%.0f MB) is cache-resident: rows shared by every workgroup come out of the XCDs' L2s and the "
+                       "Infinity Cache, so the nominal-HBM `frac` is a rate of algorithmic bytes, not a fraction of a physical "
+                       "bound (alone it exceeds 1); `l2_peak` / `reference_loop_rate` are the rates that bind" % (table_bytes / 1e6)) if cache_resident else
+                      (("the table (%.0f MB) exceeds the 256 MiB Infinity Cache; the binned form gathers it as (row class x 32-column "
+                        "slice) blocks out of the XCDs' L2s.  " % (table_bytes / 1e6))
+                       + (("Committed counters: %.2f GB cross the L2s' fabric side per launch = %.1f x the table (a 4.0 MB block "
+                           "shares its 4 MiB L2 with the id and partial-sum streams, so lines are re-fetched), against %.2f GB of "
+                           "algorithmic bytes; launch time is insensitive to the block size (profiles/r05_binned_k1.txt), so the L2s' "
+                           "delivery rate, not the fabric, binds" % (traffic / 1e9, crossings, alg / 1e9)) if crossings else
+                          "No committed counter pass matches this workload, so nothing is claimed about fabric traffic.")) if binned else
+                      "the table (%.0f MB) exceeds the 256 MiB Infinity Cache and streams from HBM" % (table_bytes / 1e6),
+        "table_fabric_crossings_per_launch": crossings,
+        "l2_peak": {"peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS, "alone_frac": achieved_alone / L2_PEAK_GBS,
+                    "source": "MI355X_MICROARCH.md 'L2 (per XCD)': 4 MiB per XCD, ~34.5 TB/s aggregate", "applies": l2_bound},
+        "reference_loop_rate": {"range": list(L2_SHARED_ROWS_GBS), "unit": "GB/s", "frac_of_upper": achieved / L2_SHARED_ROWS_GBS[1],
+                                "alone_frac_of_upper": achieved_alone / L2_SHARED_ROWS_GBS[1], "applies": l2_bound,
+                                "source": "MI355X_MICROARCH.md 'Indexed rows: gather into LDS': 66-73 GB/s per CU x 256 CUs — the "
+                                          "measured rate of ONE staging loop over 2,048 L2-resident shared rows (the guide labels the "
+                                          "table 'lower bounds'); round 5 quoted its upper figure as `peak`"},
         "note": "timed inside the step loop (HIP events on the gather's stream); with gather_overlap the launch shares the "
                 "chip with the projection kernels of the previous batch, so it takes longer than alone.  `achieved` counts "
                 "algorithmic bytes (every row read, SURVEY.md section 8d); `traffic` is what crossed the L2s' fabric side",
         "served_from": ("XCD L2 + Infinity Cache (the table fits the 256 MiB Infinity Cache)" if cache_resident else
                         "XCD L2s, block by block (binned form; the table exceeds the Infinity Cache)" if binned
                         else "HBM (the table exceeds the Infinity Cache)"),
-        "alone": {"avg_launch_ms": iso_ms, "achieved": achieved_alone, "frac": achieved_alone / peak},
+        "alone": {"avg_launch_ms": iso_ms, "achieved": achieved_alone, "frac": achieved_alone / HBM_PEAK_GBS},
         "nominal_hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                         "alone_frac": achieved_alone / HBM_PEAK_GBS,
                         "is_the_binding_bound": not l2_bound},
-        "k2": k2_mfma_util(args.config) if not (args.batch or args.vocab) else None,
+        "k2": (None if args.vocab else k2_mfma_util(f"in-batch negatives B={B} ") if args.loss == "inbatch"
+               else None if args.batch else k2_mfma_util(args.config)),
     }
     result = {
         "metric": metric,
@@ -897,7 +919,7 @@ def run_config(args, world, rank, device) -> dict:
         print(f"TRACE host ms per {trace_every} step(s):", hgaps, file=sys.stderr)
         print("TRACE K1 in-loop ms (every %d-th launch):" % trainer.k1_event_every,
               [round(a.elapsed_time(b), 3) for a, b in k1_ev], file=sys.stderr)
-    if os.environ.get("TT_TRACE") and hasattr(trainer.engine, "k1_census"):
+    if args.debug_trace and hasattr(trainer.engine, "k1_census"):
         print("TRACE streaming-K1 census per slot (admitted workgroups, CUs used, max candidates on one CU, planned):",
               [trainer.engine.k1_census(s) for s in range(trainer.SLOTS)], file=sys.stderr)
     trainer.engine.close()  # the workspace goes back to the allocator before a `secondary` configuration is set up

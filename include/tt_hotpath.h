@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 3
+#define TT_ABI_VERSION 4
 
 typedef void* tt_stream_t; /* hipStream_t */
 
@@ -602,12 +602,16 @@ int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event);
  * so does this batch's forward.  In the fork backward it IS the fork point (the engine's second stream waits for this
  * record instead of one of its own), so a caller whose gather stream needs "phase B of the previous batch has
  * finished with its pooled slot" gets that edge without an event packet of its own on the critical stream.
+ * Setting a non-NULL event ARMS it (see tt_engine_arm_loss_event): both backward schedules record it from then on, so a
+ * caller that sets the event and waits for it is always waiting for a record that happened.  NULL disarms.
  */
 int tt_engine_set_loss_event(tt_engine* e, tt_event_t event);
 /*
  * The fork backward always records the loss event (it IS its fork point).  The fused backward (one stream, no event of
- * its own) records it only while `armed` != 0 — a caller that is not going to wait for it this step saves the packet
- * on the critical chain (round-4 advisor finding).  Off after tt_engine_create.
+ * its own) records it only while `armed` != 0 — a caller that is NOT going to wait for it this step may disarm it and
+ * save the packet on the critical chain (round-4 advisor finding).  Off after tt_engine_create, on after
+ * tt_engine_set_loss_event(non-NULL); waiting for the event of a step during which it was disarmed under the fused
+ * backward waits for an OLDER record (or none).
  */
 int tt_engine_arm_loss_event(tt_engine* e, int32_t armed);
 

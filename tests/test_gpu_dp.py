@@ -345,3 +345,57 @@ def test_split_exchange_two_ranks_is_bitwise_the_one_bucket_exchange():
 def test_two_ranks_over_rccl_both_exchange_forms():
     """The same over RCCL (nccl backend), one rank per GPU — runs wherever two GPUs are visible."""
     _check_split(_run_split("nccl"))
+
+
+# --------------------------------------------------------------------------- the drop-in route under a process group
+def _route_worker(rank, world, port, q):
+    """Each rank runs the reference's literal call — train_epoch(model, batches, TripletLoss, torch.optim.Adam) — on ITS OWN
+    batches under an initialised process group: the route must take it (round 5 declined) and must not exchange anything."""
+    try:
+        from conftest import load_golden
+        from two_towers_overlords_amd.model import EmbeddingOnlyEncoder, TripletLoss, TwoTowersModel
+        from two_towers_overlords_amd.training import train_epoch
+
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        g = load_golden("step_mid.npz")
+        T = torch.from_numpy
+        P_ = g["init/query_tower.projection.0.bias"].shape[0]
+        m = TwoTowersModel(projection_dim=P_, tokenizer=lambda *a, **k: None, pretrained_model=EmbeddingOnlyEncoder(T(g["table"])),
+                           encoder_mode="embed")
+        sd = m.state_dict()
+        for k in orc.PARAM_KEYS:
+            sd[k] = T(g["init/" + k])
+        m.load_state_dict(sd)
+        m = m.cuda()
+        nb = int(g["n_batches"])
+        order = list(range(nb)) if rank == 0 else list(reversed(range(nb)))  # the ranks see DIFFERENT data: nothing may be averaged
+        batches = [tuple((T(g[f"batch{i}/ids_{r}"]).cuda(), T(g[f"batch{i}/mask_{r}"]).cuda()) for r in "qpn") for i in order]
+        opt = torch.optim.Adam(m.parameters(), lr=float(g["lr"]))
+        avg = train_epoch(m, batches, TripletLoss(margin=float(g["margin"])), opt, log_wandb=False)
+        routed = getattr(opt, "_tt_route", None) is not None and opt._tt_route.trainer.world == 1
+        out = [None] * world
+        dist.all_gather_object(out, (avg, routed, {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items() if ".projection." in k}))
+        if rank == 0:
+            q.put(("ok", out, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put(("error", f"rank {rank}: {e}\n{traceback.format_exc()}", None))
+        raise
+
+
+def test_train_epoch_route_under_a_process_group_trains_each_process_on_its_own():
+    from conftest import assert_params_close, load_golden
+
+    _, out, _ = _ranks(_route_worker, 2, salt=7)
+    g = load_golden("step_mid.npz")
+    (avg0, routed0, p0), (avg1, routed1, p1) = out
+    assert routed0 and routed1
+    assert abs(avg0 - float(g["epoch/avg_loss"])) <= 1e-5           # rank 0 saw the reference's order: the reference's epoch
+    for k in orc.PARAM_KEYS:
+        assert_params_close(p0[k], g["final/" + k], float(g["lr"]), int(g["n_batches"]))
+    assert any(np.abs(p0[k] - p1[k]).max() > 1e-6 for k in orc.PARAM_KEYS)  # rank 1 trained on its own order: other weights

@@ -1534,3 +1534,114 @@ def test_engine_create_refuses_a_device_that_is_not_the_callers_current_one(tt):
     e = engine.HotPathEngine(torch.zeros(1000, 64, device="cuda"), 64, 32, 16)
     assert e.device.index == cur
     e.close()
+
+
+def test_pool_packed_refuses_a_layout_other_than_the_one_that_was_packed(tt):
+    """Round-5 advisor finding: tt_engine_pool_packed trusted the caller's (n_roles, B, S) against what tt_engine_pack_roles had
+    written into the slot — a mismatch read staging rows of another layout (or of an older batch) without any error.  The
+    engine now remembers what was packed per slot: anything else is TT_ERR_BAD_SHAPE, nothing is launched."""
+    _, engine = tt
+    from two_towers_overlords_amd import _lib
+
+    V, D, B = 500, 64, 24
+    table = (orc.synthetic_table(V, D, seed=1) * 30).cuda()
+    eng = engine.HotPathEngine(table, 16, B, 40, pack_roles=True)
+    flat = torch.zeros(eng.n_params, device="cuda")
+    eng.bind(flat, torch.zeros_like(flat), torch.zeros_like(flat))
+    gen = torch.Generator().manual_seed(3)
+    blocks = [(torch.randint(0, V, (B, s), generator=gen).cuda(), None) for s in (9, 40, 17)]
+    with pytest.raises(_lib.TTError):
+        eng.pool_packed(0, 3, B, 40)                 # nothing has been packed into slot 0 yet
+    S = eng.pack_roles(0, blocks)
+    assert S == 40
+    for roles, b, s in ((2, B, 40), (3, B - 1, 40), (3, B, 39), (3, B, 17)):
+        with pytest.raises(_lib.TTError):
+            eng.pool_packed(0, roles, b, s)
+    with pytest.raises(_lib.TTError):
+        eng.pool_packed(1, 3, B, 40)                 # the other slot holds nothing
+    eng.pool_packed(0, 3, B, S)
+    want = torch.stack([__import__("two_towers_overlords_amd").ops.gather_pool_norm(table, i.contiguous(), sliced=False) for i, _ in blocks])
+    close(eng.pooled(0, B, 3), want, atol=2e-6)
+    eng.close()
+
+
+def test_setting_a_loss_event_arms_it_for_the_fused_backward(tt):
+    """Round-5 advisor finding (ABI 3 -> 4): tt_engine_set_loss_event(event) followed by a wait on that event must wait for a
+    record that HAPPENED, whatever the backward schedule — under the fused backward the event used to stay unrecorded unless
+    tt_engine_arm_loss_event(1) had been called.  A non-NULL event now arms; disarming is the caller's explicit choice."""
+    _, engine = tt
+    from two_towers_overlords_amd import _lib
+
+    V, D, P, B, S = 400, 64, 32, 64, 12
+    table = (orc.synthetic_table(V, D, seed=2) * 30).cuda()
+    params = orc.init_params(D, P, seed=4)
+    eng = engine.HotPathEngine(table, P, B, S)
+    flat = _flat(params).cuda()
+    eng.bind(flat, torch.zeros_like(flat), torch.zeros_like(flat))
+    eng.set_backward("fused")
+    ids = torch.randint(0, V, (3, B, S), generator=torch.Generator().manual_seed(5), dtype=torch.int32).cuda()
+    lib = _lib.load()
+    for armed_by, expect_recorded in (("set", True), ("disarm", False), ("rearm", True)):
+        ev = _lib.StreamEvent(1)
+        eng.set_loss_event(ev)
+        if armed_by == "disarm":
+            eng.arm_loss_event(False)
+        if armed_by == "rearm":
+            eng.arm_loss_event(False)
+            eng.arm_loss_event(True)
+        torch.cuda.synchronize()
+        spin = torch.empty(64 << 20, device="cuda")
+        eng.pool(0, ids)
+        for _ in range(20):                      # keep the stream busy so that a recorded event is still pending when queried
+            spin.normal_()
+        eng.fwd_bwd(0, B, 0.3)
+        done_now = lib.tt_event_done(ev._h)      # a never-recorded HIP event reports "done" at once; a recorded one is pending
+        torch.cuda.synchronize()
+        assert lib.tt_event_done(ev._h) == 1
+        assert (done_now == 0) == expect_recorded, armed_by
+        eng.set_loss_event(None)
+    eng.close()
+
+
+def test_calibrate_picks_the_gather_form_for_a_table_beyond_the_infinity_cache_and_a_resumed_run_keeps_it(tt):
+    """at BASELINE configs[3]'s table (768 MB: beyond the 256 MiB Infinity Cache) `calibrate()` times the binned
+    and the streaming gather on the ids at hand BY DEFAULT (log-uniform ids: the streaming form is 13 % faster, profiles/
+    r05_c4_skew.txt); the pick is recorded in `calibration` and in `state_dict()`, a fresh trainer that loads the checkpoint
+    runs the same form, and calibrating it again leaves the form alone.  A cache-resident table has no such candidate."""
+    _, engine = tt
+    from two_towers_overlords_amd import _lib
+    from two_towers_overlords_amd.training import TripletBatch, TripletTrainer
+
+    V, D, P, B, S = 250000, 768, 64, 16384, 256
+    gen = torch.Generator().manual_seed(8)
+    table = (torch.randn(V, D, generator=gen) * 0.02).cuda()
+    params = {k: v.cuda() for k, v in orc.init_params(D, P, seed=3).items()}
+    u = torch.rand(3, B, S, generator=gen, dtype=torch.float64)
+    ids = (torch.exp(u * torch.log(torch.tensor(float(V)))) - 1).long().clamp_(0, V - 1).int().cuda()  # bench.py --zipf
+    batch = TripletBatch(ids=ids)
+    a = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3)
+    cal = a.calibrate(batch, steps=6, rounds=1)
+    assert cal["k1_form"] in ("stream", "shape rule")
+    assert any("k1=stream" in k for k in cal["ms_per_step_by_fence"])        # both forms were timed, nobody asked for it
+    forced = (a.engine.tuning or {}).get("k1_form")
+    assert (forced == _lib.TT_K1_STREAM) == (cal["k1_form"] == "stream")
+    a.train_step(batch)
+    sd = a.state_dict()
+    assert sd["k1_form"] == cal["k1_form"]
+    b = TripletTrainer(table=table, params=params, max_batch=B, max_seq_len=S, margin=0.3, lr=1e-3)
+    b.load_state_dict(sd)
+    assert (b.engine.tuning or {}).get("k1_form") == forced and b.calibration["k1_form"] == cal["k1_form"]
+    again = b.calibrate(batch, steps=4, rounds=1)
+    assert again["k1_form"] == cal["k1_form"] and not any("k1=" in k for k in again["ms_per_step_by_fence"])
+    assert (b.engine.tuning or {}).get("k1_form") == forced
+    b.train_step(batch)
+    assert torch.equal(a.flat, torch.as_tensor(sd["flat"]).cuda())           # a's checkpointed step ...
+    a.train_step(batch)
+    assert torch.equal(a.flat, b.flat)                                        # ... and the resumed one: bit for bit, same form
+    a.engine.close(); b.engine.close()
+    small = (torch.randn(30522, 384, generator=gen) * 0.02).cuda()
+    c = TripletTrainer(table=small, params={k: v.cuda() for k, v in orc.init_params(384, 64, seed=3).items()}, max_batch=256,
+                       max_seq_len=32, margin=0.3, lr=1e-3)
+    cal = c.calibrate(TripletBatch(ids=torch.randint(0, 30522, (3, 256, 32), generator=gen).int().cuda()), steps=4, rounds=1)
+    assert cal["k1_form"] is None and c.state_dict()["k1_form"] is None
+    c.engine.close()

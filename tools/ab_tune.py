@@ -5,7 +5,7 @@ typically `--tune FIELD=VALUE` (tt_tuning: per-engine, nothing process-wide).
 
     tools/ab_tune.py [--rounds 3] [--out gpurun_out/ab.txt] -v "base:" -v "t22:--tune proj_tile=22" -- --config c3 --steps 200
 
-Prints one line per run (step time, K1 in the loop, streaming-K1 census if TT_TRACE is set) and the per-variant medians."""
+Prints one line per run (step time, K1 in the loop, streaming-K1 census from bench.py --debug-trace) and the per-variant medians."""
 import argparse
 import json
 import os
@@ -30,10 +30,10 @@ def main():
     variants = [(v.split(":", 1)[0], v.split(":", 1)[1].split()) for v in a.variant]
     res = {k: [] for k, _ in variants}
     lines = []
-    env = dict(os.environ, TT_TRACE=os.environ.get("TT_TRACE", "1"))
+    env = dict(os.environ)
     for rnd in range(a.rounds):
         for label, extra in variants:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary"] + common + extra,
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary", "--debug-trace", "10"] + common + extra,
                                capture_output=True, text=True, env=env, cwd=ROOT)
             if r.returncode != 0:
                 print(f"{label}: bench failed\n{r.stderr[-2000:]}", file=sys.stderr)

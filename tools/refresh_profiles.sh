@@ -62,6 +62,8 @@ PY
 mfma c2 "configs[1] B=2048 D=P=384 (one stream)" --steps 40 --warmup 2
 mfma c2fork "configs[1], fork backward (TN and NN as separate launches)" --steps 40 --warmup 2 --tune backward=fork
 mfma c3 "configs[2] one GPU's share B=1024 P=512 (one stream)" --config c3 --steps 40 --warmup 2
+mfma ib4096 "in-batch negatives B=4096 (configs[4] on one GPU; B x B products: NT with the hinge epilogue, NN, TN)" --loss inbatch --batch 4096 --steps 20 --warmup 2
+mfma ib512 "in-batch negatives B=512 (one GPU's share of configs[4])" --loss inbatch --batch 512 --steps 40 --warmup 2
 mfma c4bk16 "configs[3] with the tiles used beside the streaming gather (K-step 16, 128x128 TN, XCD order)" --config c4 --steps 6 --warmup 2 --tune proj_tile=22 --tune proj_bk=16 --tune tn_tile=22 --tune xcd_order=1
 cat $out/${r}_k2_mfma_util.txt
 # K1 fabric-side traffic: FETCH_SIZE / WRITE_SIZE in separate passes of bench.py --k1-only

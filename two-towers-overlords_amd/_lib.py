@@ -22,7 +22,7 @@ TT_K1_SHARE_AUTO = -1  # tt_engine_config.k1_blocks_per_cu: pair the K1 form wit
 TT_K1_AUTO, TT_K1_PER_TEXT, TT_K1_ROW_SLICES, TT_K1_COLUMN_SLICES, TT_K1_STREAM, TT_K1_BINNED = 0, 1, 2, 3, 4, 5
 K1_FORMS = {"auto": TT_K1_AUTO, "per_text": TT_K1_PER_TEXT, "rows": TT_K1_ROW_SLICES, "columns": TT_K1_COLUMN_SLICES,
             "stream": TT_K1_STREAM, "binned": TT_K1_BINNED}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 _lock = threading.Lock()

@@ -59,6 +59,7 @@ struct tt_engine {
   float* k1_partial[TT_ENGINE_SLOTS];  // XCD-sliced K1: per-slice partial sums + mask sums of one batch
   size_t k1_partial_bytes;
   int32_t* stage_ids[TT_ENGINE_SLOTS];   // tt_engine_pool_roles: packed int32 ids [3, max_B, max_S] of one batch (cfg.pack_roles)
+  int32_t staged[TT_ENGINE_SLOTS][3];    // (n_roles, B, S_out) of the last tt_engine_pack_roles into the slot; zeros = nothing staged
   int32_t* stage_lens[TT_ENGINE_SLOTS];  // ... and their prefix lengths [3, max_B]
   void* k1_stream_ctl[TT_ENGINE_SLOTS];  // streaming K1: queue head + per-CU registry of one launch (every engine has them: 16 KB each)
   bool k1_streamed[TT_ENGINE_SLOTS];     // the last tt_engine_pool* into this slot used the streaming form
@@ -474,6 +475,7 @@ static int pack_roles(tt_engine* e, int slot, const tt_role_tokens* roles, int32
   hipLaunchKernelGGL(pack_roles_kernel, dim3((unsigned)((texts + 3) / 4)), dim3(256), 0, st, a, (int)B, S_out,
                      e->stage_ids[slot], e->stage_lens[slot], e->oob);
   TT_CHECK_LAUNCH();
+  e->staged[slot][0] = n_roles; e->staged[slot][1] = B; e->staged[slot][2] = S_out;
   *S_out_p = S_out;
   return TT_OK;
 }
@@ -491,6 +493,9 @@ extern "C" int tt_engine_pool_packed(tt_engine* e, int slot, int32_t n_roles, in
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   TT_REQUIRE(e->cfg.pack_roles, TT_ERR_WORKSPACE);
   TT_REQUIRE(slot >= 0 && slot < TT_ENGINE_SLOTS, TT_ERR_BAD_SHAPE);
+  // the staging rows are laid out [n_roles, B, S_out] as the last pack wrote them: any other (n_roles, B, S) would read
+  // rows of another layout, or of an older batch
+  TT_REQUIRE(e->staged[slot][0] == n_roles && e->staged[slot][1] == B && e->staged[slot][2] == S, TT_ERR_BAD_SHAPE);
   // no mask and no lengths: the packed rows mark their own padding (TT_PAD_ID32)
   return engine_k1(e, slot, e->stage_ids[slot], TT_I32, nullptr, TT_I32, nullptr, n_roles, B, S, nullptr, 0, stream);
 }
@@ -693,6 +698,10 @@ extern "C" int tt_engine_set_dw2_event(tt_engine* e, tt_event_t event) {
 extern "C" int tt_engine_set_loss_event(tt_engine* e, tt_event_t event) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   e->ev_loss = static_cast<hipEvent_t>(event);
+  // a caller that hands over an event means to wait for it: recorded by BOTH backward schedules until the caller says
+  // otherwise (tt_engine_arm_loss_event(0)) — a wait on an event the fused backward never recorded would be a no-op and the
+  // gather could overwrite a slot still in use (round-5 advisor finding)
+  e->loss_event_armed = event != nullptr;
   return TT_OK;
 }
 

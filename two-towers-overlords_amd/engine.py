@@ -59,7 +59,7 @@ class HotPathEngine:
         self.n_slabs = int(lib.tt_engine_grad_slabs(h))
         self.params = self.exp_avg = self.exp_avg_sq = None
         self.tuning = None
-        self.backward = "auto"  # the schedule last set through set_backward (a tuning's `backward` field overrides it in the engine)
+        self.backward_mode = "auto"  # the schedule last set through set_backward (a tuning's `backward` field overrides it in the engine)
         if tuning:
             self.set_tuning(tuning)
 
@@ -181,7 +181,7 @@ class HotPathEngine:
         """"auto" | "fork" | "fused": phase B's backward schedule (include/tt_hotpath.h, tt_engine_set_backward)."""
         call("tt_engine_set_backward", self._h, {"auto": _lib.TT_BWD_AUTO, "fork": _lib.TT_BWD_FORK,
                                                  "fused": _lib.TT_BWD_FUSED}[mode])
-        self.backward = mode
+        self.backward_mode = mode
 
     def pool_cached(self, slot: int, cache: torch.Tensor, rows: torch.Tensor, stream: Optional[int] = None) -> None:
         """Phase A from a frozen-feature cache: pooled[slot] = cache[rows], rows [roles, B]."""

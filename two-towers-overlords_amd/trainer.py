@@ -273,7 +273,7 @@ class TripletTrainer:
         else:
             self._loss_event, self._use_loss_fence, self._fence_arg = None, False, fence_at_loss
             self._join_carries_gather = False
-        self._loss_armed = False              # tt_engine_arm_loss_event's current value
+        self._loss_armed = self._loss_event is not None  # tt_engine_arm_loss_event's current value (set_loss_event arms)
         self._prep = self._prep_fence = None  # third stream for the role-packing pass of role_blocks batches (see _timed_pool)
         if pack_roles and self.side is not None and self.event_scope != 3:
             self._prep = torch.cuda.Stream(self.device)
@@ -742,7 +742,7 @@ class TripletTrainer:
         if want:
             gathers = (None, "stream")
         times = {(m, f, sp, kf): [] for m in ("fused", "fork") for f in fences for sp in forms for kf in gathers}
-        saved = (self._use_loss_fence, self._split, getattr(self.engine, "backward", None))
+        saved = (self._use_loss_fence, self._split, getattr(self.engine, "backward_mode", None))
         self._dry = True
         if self._exchange and self.bucket is not None:
             self._dry_bucket = torch.zeros_like(self.bucket)  # the real bucket may hold an un-applied accumulation window
@@ -798,7 +798,7 @@ class TripletTrainer:
                             "regime": ("data-parallel step: slab reduce + exchange inside the timed dry steps, the gather under "
                                        "the exchange" if self._exchange else "single replica: gathers beside the chain"),
                             "ms_per_step": {m: min(best[kf] for kf in keys if kf[0] == m) for m in ("fused", "fork")},
-                            "k1_form": (pick[3] or "shape rule") if len(gathers) > 1 else None,
+                            "k1_form": (pick[3] or "shape rule") if len(gathers) > 1 else getattr(self, "_k1_form_loaded", None),
                             "ms_per_step_by_fence": {f"{m},{'loss' if f else 'own'}" + (",two-part" if sp else "") + (f",k1={kf}" if kf else ""):
                                                      best[(m, f, sp, kf)] for m, f, sp, kf in keys},
                             "steps": steps, "rounds": rounds}

@@ -83,12 +83,9 @@ typedef struct {
   int32_t k1_stream_offer; /* streaming K1: candidate workgroups launched per workgroup the chip may keep (auto: 16) */
   int32_t k1_share_lds_kb; /* engine: KiB of LDS a gather workgroup occupies while it shares the chip with the
                               projection kernels (auto: paired with the projection tile; -1: no reservation) */
-  int32_t proj_tile;       /* projection block tile, rows x columns in units of 64: 11, 21, 22 (auto: by shape); or, in
-                              units of 32, 33 / 32: panels of 96 rows x 96 / 64 columns over the towers' rows laid end to
-                              end, one tile per compute unit at BASELINE.json configs[1] / configs[2]'s share (ABI 3,
-                              opt-in: the one tile whose results differ from the others' by fp32 rounding — a ninth or a
-                              third of the outputs is summed as four k-interleaved partial chains; shapes it does not
-                              cover — rows % 32, P % 96 or 64, D % 32 — take the 64x64 tiles) */
+  int32_t proj_tile;       /* projection block tile, rows x columns in units of 64: 11, 21, 22 (auto: by shape).  Every tile
+                              gives bitwise the same product.  (ABI 3 also took 33 / 32, K-split panels of 96 rows: left
+                              the library in ABI 4 — no policy ever picked them; any other value means auto) */
   int32_t proj_bk;         /* K-step of the 128x128 projection tile: 16 or 32 */
   int32_t tn_tile;         /* weight-gradient (split-K) tile: 11 or 22 */
   int32_t xcd_order;       /* XCD-aware workgroup order of the projection GEMMs: 1 on, -1 off (auto: beside the streaming

@@ -245,44 +245,23 @@ def test_projection_fwd_bwd_vs_oracle(tt, M, D, P, tuning):
         assert all(torch.equal(a, b) for a, b in zip((dW1, db1, dW2, db2), g0))
 
 
-@pytest.mark.parametrize("tile", [33, 32])
-@pytest.mark.parametrize("M,D,P", [(2048, 384, 384), (3072, 384, 512), (640, 768, 512), (96, 32, 192), (32, 64, 96), (100, 30, 37)])
-def test_projection_ksplit_tiles_vs_oracle(tt, M, D, P, tile):
-    """tt_tuning.proj_tile = 33 / 32 (round 5): panels of 96 rows x 96 / 64 columns, the four waves of a workgroup splitting
-    K (gemm_f32.hip) — the ONE tile choice whose outputs are not bitwise the default's: ((c0 + c1) + c2) + c3 of four
-    k-ordered chains instead of one.  Held to the oracle at the same 1e-5, run-to-run bitwise, within a few ulp of the
-    default tiles; shapes the tiles do not cover (rows not a multiple of 32, columns not a multiple of the tile) take the
-    64x64 tiles and are bitwise the default.  Last panels of 32 and 64 rows included (2048 = 21 x 96 + 32, 640 = 6 x 96 + 64)."""
+def test_every_projection_tile_the_library_ships_gives_the_same_bits(tt):
+    """ABI 4: round 5's opt-in K-split tiles (proj_tile = 33 / 32, the one choice whose rounding differed) left the library
+    (tools/gemm_ksplit_tiles.inc); the values are now 'auto' like any other unknown value — so EVERY tile a tuning can name
+    gives bitwise the default's outputs, hidden activations and gradients."""
     ops, _ = tt
-    gen = torch.Generator().manual_seed(M + D + P)
-    x = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=1)
-    prm = orc.init_params(D, P, seed=M)
-    w1, b1, w2, b2 = (prm["query_tower.projection." + k].clone().requires_grad_(True) for k in ("0.weight", "0.bias", "2.weight", "2.bias"))
-    ref = orc.projection(x, w1, b1, w2, b2)
-    d_out = torch.randn(M, P, generator=gen) / M
-    dev_ = lambda t: t.detach().cuda()
-    tuning = {"proj_tile": tile}
-    out, h = ops.proj_fwd(x.cuda(), dev_(w1), dev_(b1), dev_(w2), dev_(b2), tuning=tuning)
-    out2, h2 = ops.proj_fwd(x.cuda(), dev_(w1), dev_(b1), dev_(w2), dev_(b2), tuning=tuning)
-    assert torch.equal(out, out2) and torch.equal(h, h2)
-    close(out, ref.detach())
-    out0, h0 = ops.proj_fwd(x.cuda(), dev_(w1), dev_(b1), dev_(w2), dev_(b2))
-    covered = M % 32 == 0 and P % (32 * (tile % 10)) == 0 and D % 32 == 0 and P % 32 == 0
-    if covered:
-        assert (out - out0).abs().max().item() <= 2e-6 and (h - h0).abs().max().item() <= 2e-6
-        assert not torch.equal(h, h0)  # the K-split tiles did run
-    else:
-        assert torch.equal(out, out0) and torch.equal(h, h0)
-    # backward through the kernel's OWN hidden activations (a pre-activation within rounding of the ReLU kink may sit on
-    # the other side of it than in the CPU oracle: the mask is part of the input here), against fp64
-    g = ops.proj_bwd(d_out.cuda(), x.cuda(), h, dev_(w2), tuning=tuning)
-    g2 = ops.proj_bwd(d_out.cuda(), x.cuda(), h, dev_(w2), tuning=tuning)
-    assert all(torch.equal(a, b) for a, b in zip(g, g2))
-    hd, dd, xd = h.cpu().double(), d_out.double(), x.double()
-    dh = (dd @ w2.detach().double()) * (hd > 0)
-    want = (dh.T @ xd, dh.sum(0), dd.T @ hd, dd.sum(0))
-    for a, r in zip(g, want):
-        close(a, r.float(), rel_to_max=True)
+    M, D, P = 3072, 384, 512
+    gen = torch.Generator().manual_seed(5)
+    x = torch.nn.functional.normalize(torch.randn(M, D, generator=gen), dim=1).cuda()
+    prm = orc.init_params(D, P, seed=1)
+    w1, b1, w2, b2 = (prm["query_tower.projection." + k].cuda() for k in ("0.weight", "0.bias", "2.weight", "2.bias"))
+    d_out = (torch.randn(M, P, generator=gen) / M).cuda()
+    out0, h0 = ops.proj_fwd(x, w1, b1, w2, b2)
+    g0 = ops.proj_bwd(d_out, x, h0, w2)
+    for tile in (11, 21, 22, 33, 32):
+        out, h = ops.proj_fwd(x, w1, b1, w2, b2, tuning={"proj_tile": tile})
+        assert torch.equal(out, out0) and torch.equal(h, h0), tile
+        assert all(torch.equal(a, b) for a, b in zip(ops.proj_bwd(d_out, x, h, w2, tuning={"proj_tile": tile}), g0)), tile
 
 
 # --------------------------------------------------------------------------- K3
@@ -506,7 +485,7 @@ def _relu_kink_mask(table, batch, params, D, P, near=2e-7):
     return mask
 
 
-@pytest.mark.parametrize("tuning", [None, {"proj_tile": 33}, {"proj_tile": 32}], ids=_tid)
+@pytest.mark.parametrize("tuning", [None, {"proj_tile": 21, "backward": "fork"}], ids=_tid)
 def test_engine_vs_oracle_metric_shape(tt, tuning):
     """BASELINE metric shape (V=30522, S=128, D=384, P=384) at a batch the oracle finishes in seconds, int32
     ids + prefix lengths, three optimizer steps.  Every step is checked from the engine's own state (the

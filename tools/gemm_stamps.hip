@@ -4,7 +4,7 @@
 // the chain at BASELINE.json configs[2]'s one-GPU share (3072 rows, P = 512, D = 384) and configs[1] (6144 rows, 384):
 // the launch's span (first entry -> last exit), the spread of workgroup start times, and the median / max length of each
 // phase, next to the MFMA time the tile's K-steps need (1024 cycles per K-step of 32 on a 64x64 tile at 2.4 GHz).
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DTT_GEMM_STAMPS -Iinclude -Itwo-towers-overlords_amd/csrc tools/gemm_stamps.hip -o /tmp/gemm_stamps
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DTT_GEMM_STAMPS -DTT_GEMM_KSPLIT -Iinclude -Itwo-towers-overlords_amd/csrc -Itools tools/gemm_stamps.hip -o /tmp/gemm_stamps
 #include "../two-towers-overlords_amd/csrc/gemm_f32.hip"
 #include <algorithm>
 #include <cstdio>

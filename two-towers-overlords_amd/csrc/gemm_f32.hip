@@ -564,298 +564,9 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_nn_kernel(const Batch bt, co
 template <int LAYOUT>
 bool problem_vec_ok(const Problem& p);
 
-// ---- K-split 96-row tiles (round 5) ---------------------------------------------------------------------------------
-// The [rows x N] products of the projection are small: 6144 x 384 outputs are 576 tiles of 64x64 = 2.25 per compute unit,
-// paid as three rounds (in-kernel stamps, profiles/r05_gemm_stamps.txt); 3072 x 512 are 384 = 1.5, paid as two.  Here the
-// rows of ALL problems of a launch are tiled as ONE virtual row space in panels of 96 rows (a panel that straddles two
-// problems — the towers have their own weights — is computed as two segments of 32 or 64 rows, one after the other, by
-// the same workgroup), the columns in tiles of 96 or 64: 6144 x 384 -> 64 x 4 = 256 tiles, 3072 x 512 -> 32 x 8 = 256:
-// ONE tile per compute unit, nine (six) 32x32 MFMA blocks each.  Nine blocks do not divide over four waves: every wave
-// owns two (one) whole blocks over all of K, and the ninth (the last two) is SHARED — of every K-step of 32, wave w
-// multiplies k in [8w, 8w + 8) of it, and its four partials are added in wave order through LDS before the epilogue:
-// 36 (24) MFMAs per wave and K-step for every wave, one barrier per K-step.
-// Numerics: an own block's elements are the single k-ordered fmaf chain of the 64x64 / 128x64 / 128x128 tiles, bit for
-// bit; a shared block's elements are ((c0 + c1) + c2) + c3, c_w the k-ordered chain over wave w's k — a fixed order,
-// run-to-run bitwise reproducible, but not the other tiles' rounding: the one tile choice that changes results (a ninth
-// or a third of the outputs, by fp32 rounding; tests/test_gpu_parity.py holds it to the oracle separately).
-// Shapes: every M % 32 == 0, N % (32 RN) == 0, K % 32 == 0, 16-byte aligned operands; anything else takes the 64x64 tiles.
-template <int LAYOUT, int RN>
-struct KsCfg {
-  static constexpr int BK = 32, BKP = 36, BN = 32 * RN;
-  static constexpr bool B_KC = (LAYOUT == kNT);
-  static constexpr int A_TILE = 96 * BKP;
-  static constexpr int B_TILE = B_KC ? BN * BKP : BK * BN;
-  static constexpr int CP = BN + 4;
-  static constexpr int LDS_FLOATS = (2 * (A_TILE + B_TILE) > 96 * CP) ? 2 * (A_TILE + B_TILE) : 96 * CP;
-};
-
-template <int LAYOUT, int EPI, int RM, int RN>
-__device__ __forceinline__ void ks_tile(const float* __restrict__ gA, const float* __restrict__ gB, float* __restrict__ gC,
-                                        const float* __restrict__ gbias, const float* __restrict__ gaux, int K, int lda,
-                                        int ldb, int ldc, int ldaux, int m0, int n0, float* __restrict__ lds) {
-  using Cfg = KsCfg<LAYOUT, RN>;
-  constexpr int BK = 32, BM = 32 * RM, BN = 32 * RN;
-  constexpr bool B_KC = Cfg::B_KC;
-  constexpr int A_TILE = Cfg::A_TILE, B_TILE = Cfg::B_TILE, CP = Cfg::CP;
-  constexpr int NVA = BM * BK / 4 / kThreads, NVB = BN * BK / 4 / kThreads;
-  static_assert(NVA >= 1 && NVB >= 1, "a K-step of the tile is at least one 16-byte chunk per thread");
-  // the tile's RM x RN blocks of 32x32, row-major: wave w owns blocks [w NOWN, (w + 1) NOWN) over all of K; the last NSH
-  // blocks are shared — of every K-step wave w multiplies k in [8w, 8w + 8) for them
-  constexpr int NB = RM * RN, NOWN = NB / 4, NSH = NB % 4;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-
-  f32x16 acc[NOWN + NSH];
-#pragma unroll
-  for (int i = 0; i < NOWN + NSH; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-  int orow[NOWN > 0 ? NOWN : 1], ocol[NOWN > 0 ? NOWN : 1];  // first row / column of this wave's own blocks in the tile
-#pragma unroll
-  for (int o = 0; o < NOWN; ++o) {
-    const int bidx = wave * NOWN + o;
-    orow[o] = (bidx / RN) * 32;
-    ocol[o] = (bidx % RN) * 32;
-  }
-
-  float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
-  auto gload = [&](float4 (&ra)[NVA], float4 (&rb)[NVB], int k0) __attribute__((always_inline)) {
-    gload_kc<BM, BK, true, true>(ra, gA, lda, m0, 0, k0, 0, tid);
-    if constexpr (B_KC) gload_kc<BN, BK, true, true>(rb, gB, ldb, n0, 0, k0, 0, tid);
-    else gload_ks<BN, BK, true, true>(rb, gB, ldb, n0, 0, k0, 0, tid);
-  };
-  auto sstore = [&](const float4 (&ra)[NVA], const float4 (&rb)[NVB], int buf) __attribute__((always_inline)) {
-    float* As = lds + buf * (A_TILE + B_TILE);
-    float* Bs = As + A_TILE;
-    // component-wise copies: staging arrays that are only ever copied whole (16-byte memcpy in, memcpy out) are not
-    // promoted to registers by the compiler — they would live in scratch
-    float4 ta[NVA], tb[NVB];
-#pragma unroll
-    for (int i = 0; i < NVA; ++i) ta[i] = make_float4(ra[i].x, ra[i].y, ra[i].z, ra[i].w);
-#pragma unroll
-    for (int i = 0; i < NVB; ++i) tb[i] = make_float4(rb[i].x, rb[i].y, rb[i].z, rb[i].w);
-    sstore_kc<BM, BK>(ta, As, tid);
-    if constexpr (B_KC) sstore_kc<BN, BK>(tb, Bs, tid);
-    else sstore_ks<BN, BK>(tb, Bs, tid);
-  };
-  auto bfrag = [&](const float* __restrict__ Bs, int col, int j) __attribute__((always_inline)) -> float4 {
-    if constexpr (B_KC) return frag_kc<BK>(Bs, col, j, h);
-    else return frag_ks<BN>(Bs, col, j, h);
-  };
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const float* __restrict__ As = lds + buf * (A_TILE + B_TILE);
-    const float* __restrict__ Bs = As + A_TILE;
-    // shared blocks first (their fragments are the same k-group for all of them), then the own blocks, k ascending:
-    // an own block's elements are the same k-ordered fmaf chain as in the 64x64 tiles, bit for bit
-#pragma unroll
-    for (int q = 0; q < NSH; ++q) {
-      constexpr int dummy = 0; (void)dummy;
-      const int bidx = 4 * NOWN + q;
-      const float4 fa = frag_kc<BK>(As, (bidx / RN) * 32 + r, wave, h);
-      const float4 fb = bfrag(Bs, (bidx % RN) * 32 + r, wave);
-      acc[NOWN + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[NOWN + q], 0, 0, 0);
-      acc[NOWN + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[NOWN + q], 0, 0, 0);
-      acc[NOWN + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[NOWN + q], 0, 0, 0);
-      acc[NOWN + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[NOWN + q], 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < BK / 8; ++j) {
-      float4 fa[NOWN > 0 ? NOWN : 1], fb[NOWN > 0 ? NOWN : 1];
-#pragma unroll
-      for (int o = 0; o < NOWN; ++o) {
-        fa[o] = frag_kc<BK>(As, orow[o] + r, j, h);
-        fb[o] = bfrag(Bs, ocol[o] + r, j);
-      }
-#pragma unroll
-      for (int o = 0; o < NOWN; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[o].x, fb[o].x, acc[o], 0, 0, 0);
-#pragma unroll
-      for (int o = 0; o < NOWN; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[o].y, fb[o].y, acc[o], 0, 0, 0);
-#pragma unroll
-      for (int o = 0; o < NOWN; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[o].z, fb[o].z, acc[o], 0, 0, 0);
-#pragma unroll
-      for (int o = 0; o < NOWN; ++o) acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[o].w, fb[o].w, acc[o], 0, 0, 0);
-    }
-  };
-  // The order inside a K-step is pinned: the requests for K-step t + 2 go out first, then the products of K-step t, then
-  // K-step t + 1 (requested one step earlier) moves from its registers to the other LDS buffer.  Left to itself the
-  // scheduler sinks the requests behind the MFMAs and hoists the LDS writes (and their vmcnt waits) in front of them —
-  // with ONE wave per SIMD nothing else hides that latency (in-kernel stamps: K loop at 0.68 of its MFMA time).
-#define TT_KS_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-  const int nk = K / BK;
-  __syncthreads();  // a previous segment of this workgroup has left the LDS
-  TT_STAMP(0);
-  gload(ra0, rb0, 0);
-  if (nk > 1) gload(ra1, rb1, BK);
-  sstore(ra0, rb0, 0);
-  __syncthreads();
-  TT_STAMP(1);
-  int kt = 0;
-  for (; kt + 3 < nk; kt += 2) {
-    gload(ra0, rb0, (kt + 2) * BK);
-    TT_KS_FENCE();
-    compute(0);
-    TT_KS_FENCE();
-    sstore(ra1, rb1, 1);
-    __syncthreads();
-    gload(ra1, rb1, (kt + 3) * BK);
-    TT_KS_FENCE();
-    compute(1);
-    TT_KS_FENCE();
-    sstore(ra0, rb0, 0);
-    __syncthreads();
-  }
-  if (kt < nk) {
-    const bool t1 = kt + 1 < nk, t2 = kt + 2 < nk;
-    if (t2) gload(ra0, rb0, (kt + 2) * BK);
-    TT_KS_FENCE();
-    compute(0);
-    TT_KS_FENCE();
-    if (t1) {
-      sstore(ra1, rb1, 1);
-      __syncthreads();
-      compute(1);
-      TT_KS_FENCE();
-      if (t2) {
-        sstore(ra0, rb0, 0);
-        __syncthreads();
-        compute(0);
-      }
-    }
-    __syncthreads();
-  }
-#undef TT_KS_FENCE
-  TT_STAMP(2);
-
-  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h.  Own blocks go to the LDS tile as
-  // they are; a shared block's four partials are added in wave order.
-  float* __restrict__ Cs = lds;
-#pragma unroll
-  for (int o = 0; o < NOWN; ++o)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Cs[(orow[o] + 4 * h + (e & 3) + 8 * (e >> 2)) * CP + ocol[o] + r] = acc[o][e];
-  if constexpr (NSH > 0) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (wave == w) {
-#pragma unroll
-        for (int q = 0; q < NSH; ++q)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int bidx = 4 * NOWN + q;
-            float* __restrict__ c = Cs + ((bidx / RN) * 32 + 4 * h + (e & 3) + 8 * (e >> 2)) * CP + (bidx % RN) * 32 + r;
-            if (w == 0) *c = acc[NOWN + q][e];
-            else *c += acc[NOWN + q][e];
-          }
-      }
-      __syncthreads();
-    }
-  } else {
-    __syncthreads();
-  }
-  constexpr int NI = BM * BN / 4 / kThreads;
-  constexpr int CQ = BN / 4;
-  constexpr int CH = NI % 3 == 0 ? 3 : (NI % 2 == 0 ? 2 : 1);  // chunks per pass: loads first, then the stores back to back
-#pragma unroll
-  for (int i0 = 0; i0 < NI; i0 += CH) {
-    float4 v[CH], am[CH], bv[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int f = tid + (i0 + i) * kThreads;
-      const int row = f / CQ, c4 = (f % CQ) * 4;
-      v[i] = *reinterpret_cast<const float4*>(Cs + row * CP + c4);
-      if (EPI == kBias || EPI == kBiasRelu) bv[i] = *reinterpret_cast<const float4*>(gbias + n0 + c4);
-      if (EPI == kReluMask) am[i] = *reinterpret_cast<const float4*>(gaux + (long long)(m0 + row) * ldaux + n0 + c4);
-    }
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int f = tid + (i0 + i) * kThreads;
-      const int row = f / CQ, c4 = (f % CQ) * 4;
-      float4 x = v[i];
-      if (EPI == kBias || EPI == kBiasRelu) { x.x += bv[i].x; x.y += bv[i].y; x.z += bv[i].z; x.w += bv[i].w; }
-      if (EPI == kBiasRelu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-      if (EPI == kReluMask) {
-        x.x = am[i].x > 0.f ? x.x : 0.f; x.y = am[i].y > 0.f ? x.y : 0.f;
-        x.z = am[i].z > 0.f ? x.z : 0.f; x.w = am[i].w > 0.f ? x.w : 0.f;
-      }
-      *reinterpret_cast<float4*>(gC + (long long)(m0 + row) * ldc + n0 + c4) = x;
-    }
-  }
-  TT_STAMP(3);
-}
-
-// 1-D grid: workgroup i belongs to XCD class i % 8 and is the (i / 8)-th of its class; a class takes the row panels
-// p % 8 == class, the column tiles of a panel back to back (they re-read the panel's rows: one XCD's L2).
-template <int LAYOUT, int EPI, int RN>
-__global__ __launch_bounds__(kThreads) void gemm_ks_kernel(const Batch b) {
-  __shared__ __attribute__((aligned(16))) float lds[KsCfg<LAYOUT, RN>::LDS_FLOATS];
-  const int cls = blockIdx.x & 7, t = blockIdx.x >> 3;
-  const int panel = (t / b.gx) * 8 + cls;
-  if (panel >= b.gy) return;
-  const int n0 = (t % b.gx) * 32 * RN;
-  const int v1 = panel * 96 + 96;  // virtual rows [panel * 96, v1) of the problems' rows laid end to end
-  for (int v = panel * 96; v < v1;) {  // one pass per problem the panel touches: one, or two where it straddles
-    // the problem that holds virtual row v, its fields picked with constant indices (a dynamic index would copy the
-    // whole descriptor to scratch)
-    const float* A = nullptr; const float* B = nullptr; float* C = nullptr; const float* bias = nullptr; const float* aux = nullptr;
-    int K = 0, lda = 0, ldb = 0, ldc = 0, ldaux = 0, base = 0, Mg = 0, off = 0;
-#pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) {
-      if (g < b.count) {
-        const int M = b.p[g].M;
-        if (v >= off && v < off + M) {
-          A = b.p[g].A; B = b.p[g].B; C = b.p[g].C; bias = b.p[g].bias; aux = b.p[g].aux;
-          K = b.p[g].K; lda = b.p[g].lda; ldb = b.p[g].ldb; ldc = b.p[g].ldc; ldaux = b.p[g].ldaux;
-          base = off; Mg = M;
-        }
-        off += M;
-      }
-    }
-    if (Mg == 0) break;  // past the last problem's rows
-    const int hi = v1 < base + Mg ? v1 : base + Mg;
-    const int m0 = v - base, rm = (hi - v) >> 5;
-    if (rm == 3) ks_tile<LAYOUT, EPI, 3, RN>(A, B, C, bias, aux, K, lda, ldb, ldc, ldaux, m0, n0, lds);
-    else if (rm == 2) ks_tile<LAYOUT, EPI, 2, RN>(A, B, C, bias, aux, K, lda, ldb, ldc, ldaux, m0, n0, lds);
-    else ks_tile<LAYOUT, EPI, 1, RN>(A, B, C, bias, aux, K, lda, ldb, ldc, ldaux, m0, n0, lds);
-    v = hi;
-  }
-}
-
-// TT_OK, or TT_ERR_UNSUPPORTED for shapes the K-split tiles do not cover (the caller then takes the 64x64 tiles)
-template <int LAYOUT, int EPI>
-int launch_ks(const Batch& b_in, int rn, hipStream_t st) {
-  if constexpr (EPI == kHinge || LAYOUT == kTN) {
-    return TT_ERR_UNSUPPORTED;
-  } else {
-    Batch b = b_in;
-    if (b.nsplit != 1 || (rn != 2 && rn != 3)) return TT_ERR_UNSUPPORTED;
-    long long rows = 0;
-    int N = 0;
-    for (int i = 0; i < b.count; ++i) {
-      const Problem& p = b.p[i];
-      if (p.M == 0) continue;
-      if (N == 0) N = p.N;
-      const bool ok = p.N == N && p.M % 32 == 0 && p.N % (32 * rn) == 0 && p.K % 32 == 0 && p.K >= 32 &&
-                      problem_vec_ok<LAYOUT>(p) && tt_aligned16(p.C) && p.ldc % 4 == 0 &&
-                      ((EPI != kBias && EPI != kBiasRelu) || tt_aligned16(p.bias)) &&
-                      (EPI != kReluMask || (tt_aligned16(p.aux) && p.ldaux % 4 == 0));
-      if (!ok) return TT_ERR_UNSUPPORTED;
-      rows += p.M;
-    }
-    if (rows == 0 || N == 0) return TT_OK;
-    b.gx = N / (32 * rn);
-    b.gy = (int)((rows + 95) / 96);
-    b.gz = 1;
-    const long long total = 8LL * ((b.gy + 7) / 8) * b.gx;
-    if (rows > 0x7fffffffLL || total > 0x7fffffffLL) return TT_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)total), block(kThreads);
-    if (rn == 3) hipLaunchKernelGGL((gemm_ks_kernel<LAYOUT, EPI, 3>), grid, block, 0, st, b);
-    else hipLaunchKernelGGL((gemm_ks_kernel<LAYOUT, EPI, 2>), grid, block, 0, st, b);
-    TT_CHECK_LAUNCH();
-    return TT_OK;
-  }
-}
+#ifdef TT_GEMM_KSPLIT  // tools/gemm_stamps.hip only: round 5's K-split 96-row tiles (tools/gemm_ksplit_tiles.inc)
+#include "gemm_ksplit_tiles.inc"
+#endif
 
 // VEC requirements of one problem (see gload_kc / gload_ks)
 template <int LAYOUT>
@@ -883,11 +594,13 @@ int launch_le(const Batch& b_in, int wm, int wn, hipStream_t st, int bk = 32) {
     maxN = b.p[i].N > maxN ? b.p[i].N : maxN;
   }
   if (maxM == 0 || maxN == 0) return TT_OK;
+#ifdef TT_GEMM_KSPLIT
   if (wm == 3) {  // K-split 96-row tiles where the shapes allow them, the 64x64 tiles elsewhere
     const int rc = launch_ks<LAYOUT, EPI>(b, wn, st);
     if (rc != TT_ERR_UNSUPPORTED) return rc;
     wm = wn = 1;
   }
+#endif
   const int BM = 64 * wm, BN = 64 * wn;
   dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, b.count * b.nsplit);
   const dim3 block(kThreads);
@@ -955,11 +668,13 @@ static size_t lds_of(Layout layout) {
 }
 
 size_t tile_lds_bytes(Layout layout, int wm, int wn, int bk) {
+#ifdef TT_GEMM_KSPLIT
   if (wm == 3) {
     const int f = layout == kNT ? (wn == 3 ? KsCfg<kNT, 3>::LDS_FLOATS : KsCfg<kNT, 2>::LDS_FLOATS)
                                 : (wn == 3 ? KsCfg<kNN, 3>::LDS_FLOATS : KsCfg<kNN, 2>::LDS_FLOATS);
     return (size_t)f * sizeof(float);
   }
+#endif
   if (wm == 2 && wn == 2 && bk == 16) return lds_of<2, 2, 16>(layout);
   if (wm == 2 && wn == 2) return lds_of<2, 2, 32>(layout);
   if (wm == 2 && wn == 1) return lds_of<2, 1, 32>(layout);

@@ -66,19 +66,19 @@ static void pick_tn_tile(int M, int N, const Plan& pl, int& wm, int& wn, int& bk
 // [6144 x 384] matrix where 64x64 gives 576 = 2.25 per CU — were built in round 3, parity-green, and measured slower at
 // BASELINE.json configs[1]: the two towers' 2048 + 4096 rows make 260 such tiles, cache-fed 132 vs 129 us, one stream
 // 253 vs 235 us, beside the gathers 233 vs 194 us; profiles/r03_gemm16_ab.txt.  Removed in round 4.)
-// (Round 5: K-split 96-row tiles, proj_tile = 33 / 32 — ONE tile per CU at BASELINE.json configs[1] and configs[2]'s share
-// (gemm_f32.hip).  Opt-in only: alone on the chip a launch is 19.2 / 23.4 / 24.6 us against 19.8 / 24.1 / 25.3 at configs[2]'s
-// share and 27.5 / 27.1 / 28.6 against 27.4 / 27.2 / 27.9 at configs[1] (profiles/r05_gemm_stamps_ksplit.txt), and no step
-// got faster: docs/LOG_r05.md section 1 says what is missing — the panel that straddles the towers runs two K loops, one
-// wave per SIMD leaves a bubble at every K-step's barrier (K loop at 0.70 of its MFMA time), and the fused backward loses
-// its TN + NN pairing.)
+// (Round 5: K-split 96-row tiles, proj_tile = 33 / 32 — ONE tile per CU at BASELINE.json configs[1] and configs[2]'s share.
+// Alone on the chip a launch was 19.2 / 23.4 / 24.6 us against 19.8 / 24.1 / 25.3 at configs[2]'s share and 27.5 / 27.1 / 28.6
+// against 27.4 / 27.2 / 27.9 at configs[1] (profiles/r05_gemm_stamps_ksplit.txt), no step got faster and no policy picked
+// them: out of the library in round 6 — tools/gemm_ksplit_tiles.inc, built only by tools/gemm_stamps.hip.)
 static void pick_tile(long long total_rows, int N, int& wm, int& wn, int& bk, const Plan& pl) {
   const bool low_traffic = pl.policy == kTileLowTraffic;
   bk = 32;
-  if (pl.t.proj_tile == 33 || pl.t.proj_tile == 32) {  // K-split 96-row tiles, 96 or 64 columns (gemm_f32.hip)
+#ifdef TT_GEMM_KSPLIT
+  if (pl.t.proj_tile == 33 || pl.t.proj_tile == 32) {  // K-split 96-row tiles, 96 or 64 columns (tools/gemm_ksplit_tiles.inc)
     wm = 3; wn = pl.t.proj_tile % 10;
     return;
   }
+#endif
   if (pl.t.proj_tile == 11 || pl.t.proj_tile == 21 || pl.t.proj_tile == 22) {
     wm = pl.t.proj_tile / 10; wn = pl.t.proj_tile % 10;
     if (wm == 2 && wn == 2 && pl.t.proj_bk == 16) bk = 16;
@@ -99,7 +99,6 @@ static void pick_tile(long long total_rows, int N, int& wm, int& wn, int& bk, co
 size_t chain_lds_bytes(long long rows, int P, const Plan& pl) {
   int wm, wn, bk;
   pick_tile(rows, P, wm, wn, bk, pl);
-  if (wm == 3) wm = wn = 1;  // a K-split 96-row tile has its CU to itself (registers): the gather keeps the 64x64 pairing
   size_t m = ttg::tile_lds_bytes(ttg::kNT, wm, wn, bk);
   const size_t nn = ttg::tile_lds_bytes(ttg::kNN, wm, wn, bk);
   const size_t tn = ttg::tile_lds_bytes(ttg::kTN, 1, 1);

@@ -1,6 +1,8 @@
 """TripletTrainer — the batch body of backend/training.py:36-53 on the fused engine (flat parameters, no autograd graph,
-device-side loss accumulation), its batch / config types and the data-parallel helpers.  The reference-signature loops
-that route to it live in training.py."""
+device-side loss accumulation).  This file holds the pipeline (slots, streams, gather / apply / advance), the epoch loop and
+the checkpoint; its batch / config types and sharding helpers live in trainer_types.py, calibration in
+trainer_calibrate.py, the replicas' gradient exchange and the in-batch loss in trainer_exchange.py, hipGraph replay in
+trainer_graphs.py.  The reference-signature loops that route here live in training.py."""
 from __future__ import annotations
 
 import collections
@@ -15,98 +17,14 @@ import torch.distributed as dist
 from . import _lib, ops
 from .engine import HotPathEngine, flat_param_slices
 from .model import TwoTowersModel
+from .trainer_calibrate import CalibrationMixin
+from .trainer_exchange import ExchangeMixin
+from .trainer_graphs import GraphReplayMixin
+from .trainer_types import (Batch, TrainerConfig, TripletBatch, _proj_dim, _require_same_frozen_encoder, _TorchEvent,  # noqa: F401
+                            as_batch, shard_batch, shard_sizes)
 
 
-Batch = Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]  # ids[3,B,S], mask[3,B,S]|None, lens[3,B]|None
-
-
-@dataclasses.dataclass
-class TripletBatch:
-    """One batch for the fused engine.  Either token ids (`ids` [roles,B,S] + `mask` or `lens`),
-    or rows of the trainer's token store (`token_rows` [roles,B] int32: the texts were tokenised
-    once into `TripletTrainer.set_token_store`, a batch is 12 bytes per triplet), or rows of the
-    trainer's frozen-feature cache (`cache_rows` [roles,B]).  roles = 3: query, positive,
-    negative.  roles = 2 + `neg_index` (int32 [B]): the negatives are in-batch positives
-    (backend/data.py:113-137), negative i = positive neg_index[i] — no third encode."""
-
-    ids: Optional[torch.Tensor] = None
-    mask: Optional[torch.Tensor] = None
-    lens: Optional[torch.Tensor] = None
-    neg_index: Optional[torch.Tensor] = None
-    cache_rows: Optional[torch.Tensor] = None
-    query_ids: Optional[torch.Tensor] = None  # int64 [B]; in-batch-negatives loss: same-query documents are not negatives
-    token_rows: Optional[torch.Tensor] = None
-    # recorded by the producer on ITS stream once the batch's tensors are complete (e.g. after the non_blocking
-    # host->device copies on a copy stream); the gather then waits for it.  Not needed for tensors produced on the
-    # stream that calls gather(): that stream is fenced anyway.
-    ready_event: Optional["torch.cuda.Event"] = None
-    # roles as SEPARATE (input_ids [B, S_r], attention_mask [B, S_r] | None) blocks, the tokenizer's own output per encode
-    # call (backend/model.py:43-48): the engine packs them on the gather stream (tt_engine_pool_roles; single replica,
-    # an engine built with pack_roles=True)
-    role_blocks: Optional[list] = None
-    # the store `token_rows` index, when it is not the trainer's own (set_token_store): ids [N, S] int32/int64 with
-    # TT_PAD_ID behind each text's tokens — the drop-in route's growing text store hands every batch the tensor that was
-    # current when the batch was made
-    token_store: Optional[torch.Tensor] = None
-
-    @property
-    def size(self) -> int:
-        for t in (self.ids, self.token_rows, self.cache_rows):
-            if t is not None:
-                return t.shape[1]
-        if self.role_blocks is not None:
-            return self.role_blocks[0][0].shape[0]
-        raise ValueError("empty TripletBatch")
-
-    def expand_negatives(self) -> "TripletBatch":
-        """roles 2 + neg_index -> roles 3 (negatives materialised by a row gather)."""
-        if self.neg_index is None:
-            return self
-        if self.role_blocks is not None:
-            raise ValueError("role_blocks batches carry their negatives as a third block")
-        ni = self.neg_index.long()
-        cat = lambda t: None if t is None else torch.cat([t, t[1:2].index_select(1, ni)], dim=0).contiguous()
-        return TripletBatch(cat(self.ids), cat(self.mask), cat(self.lens), None, cat(self.cache_rows), self.query_ids,
-                            cat(self.token_rows), self.ready_event, token_store=self.token_store)
-
-
-def as_batch(b) -> TripletBatch:
-    return b if isinstance(b, TripletBatch) else TripletBatch(*b)
-
-
-@dataclasses.dataclass
-class TrainerConfig:
-    """Every knob of TripletTrainer in one place (bench.py mirrors it: `--trainer FIELD=VALUE`).  The first block is the
-    reference's hyper-parameters (backend/training.py:383-397, :436); the rest steer HOW the same arithmetic is run —
-    none of them changes a result beyond fp32 summation order, and only `tuning["k1_form"]` does even that."""
-
-    # -- what is computed (backend/training.py:433-436: TripletLoss(margin), Adam(lr), defaults of torch.optim.Adam)
-    margin: float = 0.3
-    lr: float = 1e-3
-    betas: tuple = (0.9, 0.999)
-    eps: float = 1e-8
-    accumulation_steps: int = 1          # backend/training.py:66-133: loss / k, optimizer step every k-th batch of an epoch
-    loss: str = "triplet"                # "triplet" (the reference's sampled negative) | "inbatch" (BASELINE.json configs[4])
-    # -- how the two streams share the chip
-    overlap_streams: Optional[bool] = None   # gathers of the next batches on a side stream (None: on a GPU with the HIP engine)
-    k1_blocks_per_cu: Optional[int] = None   # tt_engine_config.k1_blocks_per_cu (None: TT_K1_SHARE_AUTO with a side stream)
-    tuning: Optional[dict] = None            # tt_tuning fields for this trainer's engine (include/tt_hotpath.h)
-    grad_slabs: int = 0                      # split-K slabs of the weight-gradient GEMMs (0: the engine's rule)
-    event_scope: Optional[int] = None        # release scope of the cross-stream events: 1 no system fence (default), 2, 3
-    fence_at_loss: Optional[bool] = None     # the gather's slot fence = the engine's loss event (None: calibrate() decides)
-    join_carries_gather: bool = True         # the fork backward's join also carries the wait for the next gather
-    use_graphs: Optional[bool] = None        # hipGraph replay of whole steps (opt-in; slower on ROCm 7.2)
-    pack_roles: bool = False                 # engine staging for role_blocks batches (the drop-in train_epoch route)
-    freeze_gc: bool = True                   # gc.freeze() once before the first epoch
-    # -- data parallel
-    exchange: Optional[bool] = None          # gradients are exchanged (None: iff more than one replica; True on one rank: tests)
-    split_exchange: Optional[bool] = False   # the exchange in two parts (None: calibrate() times both forms on the fabric)
-    gather_under_exchange: bool = True       # the next gather is issued right before the exchange
-    local_only: bool = False                 # ignore an initialised process group: this process trains on its own (what the
-    #                                          reference's train_epoch does under any launcher; the drop-in route sets it)
-
-
-class TripletTrainer:
+class TripletTrainer(CalibrationMixin, ExchangeMixin, GraphReplayMixin):
     """The batch body of backend/training.py:36-53 on the fused engine.
 
     Data parallel: every rank holds the frozen table and the 8
@@ -131,11 +49,11 @@ class TripletTrainer:
         which overrides the config's value.  `engine`: an injected engine (tests); `process_group`: the replicas."""
         cfg = dataclasses.replace(config or TrainerConfig(), **overrides)  # an unknown keyword raises TypeError, like a signature
         self.config = cfg
-        (margin, lr, betas, eps, accumulation_steps, loss, overlap_streams, k1_blocks_per_cu, use_graphs, freeze_gc, exchange,
-         split_exchange, gather_under_exchange, tuning, event_scope, fence_at_loss, grad_slabs, join_carries_gather, pack_roles) = (
-            cfg.margin, cfg.lr, cfg.betas, cfg.eps, cfg.accumulation_steps, cfg.loss, cfg.overlap_streams, cfg.k1_blocks_per_cu,
-            cfg.use_graphs, cfg.freeze_gc, cfg.exchange, cfg.split_exchange, cfg.gather_under_exchange, cfg.tuning,
-            cfg.event_scope, cfg.fence_at_loss, cfg.grad_slabs, cfg.join_carries_gather, cfg.pack_roles)
+        margin, lr, betas, eps, accumulation_steps, loss = cfg.margin, cfg.lr, cfg.betas, cfg.eps, cfg.accumulation_steps, cfg.loss
+        overlap_streams, k1_blocks_per_cu, use_graphs, freeze_gc = cfg.overlap_streams, cfg.k1_blocks_per_cu, cfg.use_graphs, cfg.freeze_gc
+        exchange, split_exchange, gather_under_exchange = cfg.exchange, cfg.split_exchange, cfg.gather_under_exchange
+        tuning, event_scope, fence_at_loss, grad_slabs = cfg.tuning, cfg.event_scope, cfg.fence_at_loss, cfg.grad_slabs
+        join_carries_gather, pack_roles = cfg.join_carries_gather, cfg.pack_roles
         local_only = bool(cfg.local_only)
         if model is not None:
             # `embed`: K1 gathers from this table.  `bert` (backend/model.py:51-52 as executed: the frozen encoder
@@ -685,356 +603,6 @@ class TripletTrainer:
         if self._auto_step:
             self.engine.set_step(self.step_count)
 
-    # -- calibration ----------------------------------------------------------------------
-    INFINITY_CACHE_BYTES = 256 << 20  # MI355X MALL (MI355X_MICROARCH.md): a table beyond it really streams from HBM
-
-    def calibrate(self, batch: Batch, steps: int = 48, rounds: int = 2, k1_forms: Optional[bool] = None) -> dict:
-        """Time the step's equivalent schedules on THIS device with THIS batch shape, in the regime the trainer will run
-        in, and keep the fastest: phase B's two backward schedules (include/tt_hotpath.h, tt_engine_set_backward), where
-        the gather's slot fence comes from (single replica), and — with a gradient exchange whose form the caller left
-        open (`split_exchange=None`) — the exchange in one bucket or in two parts.  Single replica: dry steps with the
-        gathers running beside the chain exactly as in training.  Data parallel (round 5): the dry steps ARE the
-        data-parallel step — slab reduce into a scratch bucket, the next gather issued under the exchange, the real
-        collective on the caller's stream — because there the chain runs alone on the chip and the ranking may differ
-        from the one beside the gathers (configs[2]'s share under a 60 us stand-in: the two tie at 186 us without a
-        profiler, fused is 4.6 us ahead under rocprofv3; docs/LOG_r05.md section 1).  All
-        candidates write bitwise the same gradients, so the choice never changes a training run's parameters.
-        Parameters, Adam state, step counters, the gradient bucket and loss statistics are untouched (no optimizer).
-        A side effect worth knowing: the dry steps also bring the GPU from its idle power state to sustained clocks,
-        which otherwise takes the first ~70 training steps (docs/LOG_r04.md §5 "Cold start").
-        `k1_forms` adds the gather's form as a candidate where the shape rule picks the binned form: that rule assumes
-        every table row is named about equally often, and on THIS batch's ids the streaming form may be the faster one
-        (log-uniform ids at configs[3]: 4.4 vs 5.1 ms per step, profiles/r05_c4_skew.txt).  None (default, round 6): on for
-        a table beyond the Infinity Cache — the only tables the binned form is picked for — unless `tuning` fixes a form.
-        Unlike the other candidates the two forms differ in fp32 summation order (both within the 1e-5 parity bound, each
-        bitwise run to run), so the choice is recorded — `calibration["k1_form"]`, and `state_dict()["k1_form"]`, which
-        `load_state_dict` re-applies so that a resumed run keeps its form; a run that must be bitwise repeatable ACROSS
-        calibrations fixes the form in `tuning`.  Data parallel: the candidate set is agreed between the ranks first (a
-        rank whose shard is too short to bin would otherwise run a different number of collectives)."""
-        if self._pending:
-            raise RuntimeError("calibrate(): call it between epochs (batches are still in flight)")
-        if self.device.type != "cuda" or not hasattr(self.engine, "set_backward") or self.loss_kind != "triplet":
-            return {}
-        b = as_batch(batch)
-        depth = self.SLOTS - 1 if self.side is not None else 1
-        # second dimension: where the gather's slot fence comes from (see __init__, fence_at_loss) — only where the
-        # caller left it open and the engine's loss event exists
-        fences = (False, True) if (self.side is not None and self._loss_event is not None and self._fence_arg is None) else (self._use_loss_fence,)
-        # third: the exchange in one bucket or two parts — only where the caller left it open
-        forms = (False, True) if (self._exchange and self._split_auto) else (self._split,)
-        base_tuning = dict(self.engine.tuning or {}) if hasattr(self.engine, "tuning") else {}
-        gathers = (None,)
-        if k1_forms is None:
-            k1_forms = (hasattr(self.engine, "V") and self.engine.V * self.D * 4 > self.INFINITY_CACHE_BYTES
-                        and getattr(self, "_k1_form_loaded", None) is None)
-        ids_like = b.ids if b.ids is not None else b.token_rows
-        width = (b.ids.shape[2] if b.ids is not None else
-                 (b.token_store if b.token_store is not None else (self.token_store or (None,))[0]))
-        if width is not None and not isinstance(width, int):
-            width = width.shape[1]
-        want = bool(k1_forms and hasattr(self.engine, "set_tuning") and not base_tuning.get("k1_form") and ids_like is not None
-                    and width is not None and b.size > 0
-                    and _lib.load().tt_k1_prefers_binned(self.engine.V, self.D, ids_like.shape[0] * b.size, width))
-        if self.world > 1 and k1_forms and hasattr(self.engine, "set_tuning"):
-            agree = torch.tensor([int(want)], dtype=torch.int32, device=self.device)
-            dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=self.pg)  # every rank times the same candidates, or none does
-            want = bool(int(agree.item()))
-        if want:
-            gathers = (None, "stream")
-        times = {(m, f, sp, kf): [] for m in ("fused", "fork") for f in fences for sp in forms for kf in gathers}
-        saved = (self._use_loss_fence, self._split, getattr(self.engine, "backward_mode", None))
-        self._dry = True
-        if self._exchange and self.bucket is not None:
-            self._dry_bucket = torch.zeros_like(self.bucket)  # the real bucket may hold an un-applied accumulation window
-        ok = False
-        try:
-            for _ in range(rounds):
-                for mode, fence, sp, kf in times:
-                    self._use_loss_fence = fence
-                    self._split = sp
-                    if len(gathers) > 1:
-                        self.engine.set_tuning({**base_tuning, **({"k1_form": kf} if kf else {})})
-                    self.engine.set_backward(mode)
-                    while len(self._pending) < depth:
-                        self.gather(b)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(steps):
-                        self.apply(None, issue_next=lambda fence=None: self.gather(b, fence=fence))
-                    e1.record()
-                    while self._pending:
-                        self.apply(None)
-                    e1.synchronize()
-                    times[(mode, fence, sp, kf)].append(e0.elapsed_time(e1) / steps)
-            ok = True
-        finally:
-            if not ok:  # an error mid-calibration: no candidate's settings and no dry batch may stay behind
-                try:
-                    if self._pending:
-                        self.abort_pipeline()
-                finally:
-                    self._use_loss_fence, self._split = saved[0], saved[1]
-                    if len(gathers) > 1:
-                        self.engine.set_tuning(base_tuning)
-                    if saved[2] is not None:
-                        self.engine.set_backward(saved[2])
-            self._dry = False
-            self._dry_bucket = None
-        keys = list(times)
-        best = {kf: min(v) for kf, v in times.items()}
-        if self.world > 1:  # every replica must take the same decision: decide on the slowest rank's times
-            t = torch.tensor([best[kf] for kf in keys], dtype=torch.float64, device=self.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
-            best = {kf: float(t[i]) for i, kf in enumerate(keys)}
-        pick = min(best, key=best.get)
-        if len(gathers) > 1:
-            self.engine.set_tuning({**base_tuning, **({"k1_form": pick[3]} if pick[3] else {})})
-        self.engine.set_backward(pick[0])
-        self._use_loss_fence = pick[1]
-        self._split = pick[2]
-        self.engine.read_stats(reset=True)  # the dry steps' losses do not belong to any epoch
-        self.calibration = {"backward": pick[0], "fence_at_loss": pick[1],
-                            "exchange_form": (None if not self._exchange else ("two-part" if pick[2] else "one-bucket")),
-                            "regime": ("data-parallel step: slab reduce + exchange inside the timed dry steps, the gather under "
-                                       "the exchange" if self._exchange else "single replica: gathers beside the chain"),
-                            "ms_per_step": {m: min(best[kf] for kf in keys if kf[0] == m) for m in ("fused", "fork")},
-                            "k1_form": (pick[3] or "shape rule") if len(gathers) > 1 else getattr(self, "_k1_form_loaded", None),
-                            "ms_per_step_by_fence": {f"{m},{'loss' if f else 'own'}" + (",two-part" if sp else "") + (f",k1={kf}" if kf else ""):
-                                                     best[(m, f, sp, kf)] for m, f, sp, kf in keys},
-                            "steps": steps, "rounds": rounds}
-        return self.calibration
-
-    def _split_step(self, local_B: int, first_micro: bool, do_step: bool, issue_next, mark=None, dry: bool = False) -> None:
-        """Slab reduce + exchange + Adam with the bucket cut in two (split_exchange=True).  `early` = dW2 / db2 of both
-        towers: their slabs are complete when the engine records `_ev_dw2` (inside fwd_bwd, before dH -> dW1), so a
-        second stream reduces and all-reduces them while the caller's stream is still computing dW1 / db1; `late` =
-        dW1 / db1, reduced and exchanged on the caller's stream after that chain, as the whole bucket is otherwise."""
-        eng, bucket = self.engine, (self._dry_bucket if dry else self.bucket)
-        cuda = self.device.type == "cuda"
-        main = torch.cuda.current_stream(self.device) if cuda else None
-
-        def reduce(parts):
-            for off, n in parts:
-                if local_B > 0:
-                    eng.reduce_grads_range(bucket, off, n, accumulate=not first_micro)
-                elif first_micro:  # an empty shard contributes zeros but takes part in every collective
-                    bucket[off: off + n].zero_()
-
-        if cuda:
-            if local_B > 0:
-                self._comm.wait_event(self._ev_dw2)   # recorded by the engine once dW2 / db2 are complete
-            else:
-                self._comm.wait_stream(main)
-            with torch.cuda.stream(self._comm):
-                reduce(self._early)
-                if do_step:
-                    self._all_reduce_parts(self._early, bucket)
-                self._ev_early.record(self._comm)
-        else:
-            reduce(self._early)
-            if do_step:
-                self._all_reduce_parts(self._early, bucket)
-        reduce(self._late)
-        if issue_next is not None:
-            issue_next()
-        if mark:
-            mark(1)
-        if do_step:
-            self._all_reduce_parts(self._late, bucket)
-        if cuda:
-            main.wait_event(self._ev_early)  # before Adam — or, on a micro-batch, before the next fwd_bwd rewrites the slabs
-        if mark:
-            mark(2)
-        if do_step and not dry:
-            self.step_count += 1
-            eng.adam(self.step_count, self.lr, bucket, self.betas[0], self.betas[1], self.eps)
-        if mark:
-            mark(3)
-
-    def _all_reduce_parts(self, parts, bucket=None) -> None:
-        """The views of one part of the flat bucket (W2 | b2 of each tower, or W1 | b1 of each), summed over the
-        replicas: one public `dist.all_reduce` per view, issued back to back on the current stream (the early part's
-        stream is off the critical chain; per-element sums do not depend on how the bucket is cut)."""
-        bucket = self.bucket if bucket is None else bucket
-        for off, n in parts:
-            dist.all_reduce(bucket[off: off + n], op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
-
-    def _all_reduce(self, bucket: torch.Tensor) -> None:
-        """The step's one gradient exchange: sum of the flat bucket over the replicas (RCCL over xGMI on GPUs).
-        A synchronous-op call on purpose: torch's NCCL backend enqueues such a collective on the CALLER's stream,
-        where an async_op=True call hops to the backend's own stream and back — two cross-queue event waits of
-        10-15 us each on this hardware (tools/nccl_stream_probe.py: 45 vs 31 us per iteration), right on the critical
-        chain reduce -> exchange -> Adam.  Nothing blocks on the host either way; the gather of the next batch runs
-        beside it on the side stream."""
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
-
-    # -- data parallel: replicas --------------------------------------------------------
-    def _src0(self) -> int:
-        return dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
-
-    def sync_replicas(self) -> None:
-        """Every replica takes rank 0's parameters, Adam moments and step count (what
-        DistributedDataParallel's constructor does for the parameters).  Called at construction —
-        nn.Linear's default init comes from each process's own RNG, and identical all-reduced Adam
-        updates never bring different starting points together — and after loading a checkpoint
-        on one rank."""
-        if self.world == 1:
-            return
-        src = self._src0()
-        for t in (self.flat, self.exp_avg, self.exp_avg_sq):
-            dist.broadcast(t, src=src, group=self.pg)
-        if self.bucket is not None:
-            dist.broadcast(self.bucket, src=src, group=self.pg)  # an unfinished accumulation window travels too
-        steps = torch.tensor([self.step_count, self._micro, int(self._carry)], dtype=torch.int64, device=self.device)
-        dist.broadcast(steps, src=src, group=self.pg)
-        self.step_count, self._micro, self._carry = int(steps[0]), int(steps[1]), bool(steps[2])
-
-    def replica_divergence(self) -> float:
-        """max over ranks of |parameter checksum - rank 0's| (0.0 when the replicas are in step);
-        a debug check, one small all-gather."""
-        if self.world == 1:
-            return 0.0
-        mine = torch.stack([self.flat.double().sum(), self.flat.double().abs().sum()])
-        allc = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(allc, mine, group=self.pg)
-        return float(max((c - allc[0]).abs().max() for c in allc))
-
-    def _inbatch_fwd_bwd(self, slot: int, B: int, query_ids, k: int, global_B: int) -> None:
-        """In-batch-negatives loss between the two halves of the engine's phase B.  Data parallel
-        (SURVEY.md §8e/f4): the documents' embeddings (and query ids) are all-gathered, each rank
-        scores its queries against every document of the global batch, and the documents' gradient
-        is summed over ranks before each rank keeps its own rows — the one real exchange of
-        activations on this path.  Shards may be uneven (`shard_batch`: the first global_B % world
-        ranks hold one row more) or empty; every rank takes part in every collective."""
-        eng = self.engine
-        if global_B < 2:
-            raise ValueError("in-batch-negatives loss: a (global) batch of one has no negatives")
-        if self.world == 1:
-            eng.forward(slot, B, 2)
-            emb, dout = eng.embeddings(B, 2), eng.d_out(B, 2)
-            qid = None if query_ids is None else query_ids.to(torch.int64).contiguous()
-            z = float(B * (B - 1))
-            loss, _, _ = ops.inbatch_triplet_fwd_bwd(emb[0], emb[1], self.margin, None, qid, qid, 1.0 / (z * k), z,
-                                                     dq_out=dout[0], dd_out=dout[1], workspace=self._inbatch_ws(B, B))
-            eng.add_loss(loss)
-            eng.backward(slot, B, 2)
-            return
-        W, r = self.world, self.rank
-        sizes, offs = shard_sizes(global_B, W)
-        if B != sizes[r]:
-            raise ValueError(f"in-batch loss: rank {r} holds {B} rows of a global batch of {global_B}; the contiguous "
-                             f"split (shard_batch) gives it {sizes[r]}")
-        mb = sizes[0]  # largest shard: all-gathers run on equal, zero-padded blocks
-        have_qid = query_ids is not None
-        pad_d = torch.zeros((mb, self.P), dtype=torch.float32, device=self.device)
-        pad_q = torch.zeros(mb, dtype=torch.int64, device=self.device) if have_qid else None
-        if B > 0:
-            eng.forward(slot, B, 2)
-            emb, dout = eng.embeddings(B, 2), eng.d_out(B, 2)
-            pad_d[:B].copy_(emb[1])
-            if have_qid:
-                pad_q[:B].copy_(query_ids.to(torch.int64))
-        d_pad = torch.empty((W * mb, self.P), dtype=torch.float32, device=self.device)
-        dist.all_gather_into_tensor(d_pad, pad_d, group=self.pg)
-        even = sizes[-1] == mb
-        rows = None if even else self._valid_rows(sizes, mb)
-        d_all = d_pad if even else d_pad.index_select(0, rows)
-        qid_all = None
-        if have_qid:
-            q_pad = torch.empty(W * mb, dtype=torch.int64, device=self.device)
-            dist.all_gather_into_tensor(q_pad, pad_q, group=self.pg)
-            qid_all = q_pad if even else q_pad.index_select(0, rows)
-        z = float(global_B * (global_B - 1))
-        if B > 0:
-            pos = (torch.arange(B, device=self.device, dtype=torch.int32) + offs[r]).contiguous()
-            loss, _, dd_all = ops.inbatch_triplet_fwd_bwd(emb[0], d_all.contiguous(), self.margin, pos,
-                                                          pad_q[:B].contiguous() if have_qid else None,
-                                                          None if qid_all is None else qid_all.contiguous(),
-                                                          1.0 / (z * k), z, dq_out=dout[0], workspace=self._inbatch_ws(B, global_B))
-        else:
-            dd_all = torch.zeros((global_B, self.P), dtype=torch.float32, device=self.device)
-        dist.all_reduce(dd_all, op=dist.ReduceOp.SUM, group=self.pg)
-        if B > 0:
-            dout[1].copy_(dd_all[offs[r]: offs[r] + B])
-            eng.add_loss(loss)
-            eng.backward(slot, B, 2)
-
-    def _inbatch_ws(self, Bq: int, Bd: int) -> Optional[torch.Tensor]:
-        """Grow-only workspace of the in-batch loss (the [Bq, Bd] similarity matrix and the gradient slabs), kept between
-        steps: stream-ordered reuse on the stream phase B runs on."""
-        if self.device.type != "cuda":
-            return None
-        need = (int(_lib.load().tt_inbatch_workspace_bytes(Bq, Bd, self.P)) + 3) // 4
-        ws = getattr(self, "_inbatch_workspace", None)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(need, dtype=torch.float32, device=self.device)
-            self._inbatch_workspace = ws
-        return ws
-
-    def _valid_rows(self, sizes, mb: int) -> torch.Tensor:
-        """Row indices of the real (non-padding) rows inside the [world * mb] all-gathered blocks."""
-        key = (tuple(sizes), mb)
-        cache = getattr(self, "_valid_rows_cache", None)
-        if cache is None or cache[0] != key:
-            idx = torch.cat([torch.arange(n) + i * mb for i, n in enumerate(sizes)])
-            cache = (key, idx.to(self.device))
-            self._valid_rows_cache = cache
-        return cache[1]
-
-    # -- hipGraph replay ---------------------------------------------------------------
-    def _graphable(self, entry, nxt: Optional[TripletBatch]) -> bool:
-        if not self.use_graphs:
-            return False
-        if self.eager_every and self._steps_done % self.eager_every == self.eager_every - 1:
-            return False
-        _, _, B, neg_index, _ = entry
-        if neg_index is not None or B != self.engine.max_B or self.loss_kind != "triplet":
-            return False
-        if nxt is None:
-            return True
-        return (nxt.ids is not None and nxt.ids.shape[0] == 3 and nxt.ids.shape[1] == B
-                and nxt.ids.shape[2] <= self.engine.max_S and nxt.mask is None and nxt.neg_index is None
-                and nxt.cache_rows is None and nxt.token_rows is None)
-
-    def _ring_load(self, slot: int, nxt: TripletBatch) -> None:
-        """Stage a batch's ids in the fixed ring buffer the captured K1 launch reads (main stream)."""
-        if self._ring_ids is None:
-            B, S = self.engine.max_B, self.engine.max_S
-            self._ring_ids = torch.zeros((self.SLOTS, 3, B, S), dtype=torch.int32, device=self.device)
-            self._ring_lens = torch.zeros((self.SLOTS, 3, B), dtype=torch.int32, device=self.device)
-        S = nxt.ids.shape[2]
-        if nxt.ids.data_ptr() != self._ring_ids[slot].data_ptr():  # a caller may fill the ring slot itself
-            self._ring_ids[slot][:, :, :S].copy_(nxt.ids)
-        if nxt.lens is not None:
-            self._ring_lens[slot].copy_(nxt.lens)
-            self._ring_fill[slot] = None
-        elif self._ring_fill[slot] != S:
-            self._ring_lens[slot].fill_(S)
-            self._ring_fill[slot] = S
-
-    def _graph(self, slot_fb: int, slot_k1: Optional[int]):
-        key = (slot_fb, slot_k1)
-        g = self._graphs.get(key)
-        if g is not None:
-            return g
-        B = self.engine.max_B
-        if self._ring_ids is None and slot_k1 is not None:
-            raise RuntimeError("ring not initialised")
-        torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        cap = torch.cuda.Stream(self.device)
-        with torch.cuda.graph(g, stream=cap):
-            if slot_k1 is not None:  # branch: the gather of the batch two steps ahead
-                self.side.wait_stream(cap)
-                self.engine.pool(slot_k1, self._ring_ids[slot_k1], None, self._ring_lens[slot_k1],
-                                 stream=self.side.cuda_stream)
-            self.engine.fwd_bwd(slot_fb, B, self.margin, 1.0 / B, float(B))
-            self.engine.adam_auto(self.lr, None, self.betas[0], self.betas[1], self.eps)
-            if slot_k1 is not None:
-                cap.wait_stream(self.side)
-        self._graphs[key] = g
-        return g
-
     def advance(self, nxt: Optional[Batch] = None, global_B: Optional[int] = None) -> None:
         """One step of the pipeline: weight-dependent part of the oldest gathered batch, and the
         gather of `nxt` (the batch that enters the pipeline now, if any) — as one hipGraph replay
@@ -1113,60 +681,3 @@ class TripletTrainer:
             dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.pg)
             n = int(c.item())
         return loss_sum / max(n, 1)
-
-
-class _TorchEvent:
-    """torch.cuda.Event behind the record(stream) / wait(stream) / query() interface of _lib.StreamEvent."""
-
-    def __init__(self):
-        self.ev = torch.cuda.Event()
-
-    def record(self, stream) -> None:
-        self.ev.record(stream)
-
-    def wait(self, stream) -> None:
-        stream.wait_event(self.ev)
-
-    def query(self) -> bool:
-        return self.ev.query()
-
-
-def shard_sizes(global_B: int, world: int):
-    """Contiguous split of `global_B` rows over `world` ranks: (sizes, offsets); the first
-    global_B % world ranks hold one row more."""
-    base, rem = divmod(int(global_B), int(world))
-    sizes = [base + (1 if r < rem else 0) for r in range(world)]
-    offs = [r * base + min(r, rem) for r in range(world)]
-    return sizes, offs
-
-
-def shard_batch(batch: Batch, rank: int, world: int) -> Tuple[Batch, int]:
-    """Contiguous split of a global batch over `world` ranks; the
-    last ranks get one triplet fewer when B % world != 0 (none at all when B < world: such a
-    rank still takes part in the step's collectives).  Returns (shard, B_global)."""
-    tb = as_batch(batch).expand_negatives() if world > 1 else as_batch(batch)
-    B = tb.size
-    sizes, offs = shard_sizes(B, world)
-    lo, hi = offs[rank], offs[rank] + sizes[rank]
-    cut = lambda t: None if t is None else t[:, lo:hi].contiguous()
-    if isinstance(batch, TripletBatch):
-        ni = tb.neg_index if world == 1 else None
-        qid = None if tb.query_ids is None else tb.query_ids[lo:hi].contiguous()  # [B], not [roles, B]
-        return TripletBatch(cut(tb.ids), cut(tb.mask), cut(tb.lens), ni, cut(tb.cache_rows), qid, cut(tb.token_rows),
-                            tb.ready_event), B
-    return (cut(tb.ids), cut(tb.mask), cut(tb.lens)), B
-
-
-def _require_same_frozen_encoder(model: TwoTowersModel) -> None:
-    """One feature cache serves both towers only if they hold the same frozen encoder — the reference loads the same
-    pretrained model into each tower (backend/model.py:84-85), this package shares one object by default."""
-    a, b = model.query_tower.pretrained_model, model.document_tower.pretrained_model
-    if a is b:
-        return
-    sa, sb = a.state_dict(), b.state_dict()
-    if sa.keys() != sb.keys() or any(not torch.equal(sa[k], sb[k]) for k in sa):
-        raise ValueError("the two towers hold different frozen encoders: one feature cache cannot serve both")
-
-
-def _proj_dim(params: dict) -> int:
-    return params["query_tower.projection.0.bias"].shape[0]

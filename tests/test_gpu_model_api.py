@@ -931,3 +931,33 @@ def test_float_attention_mask_is_refused_not_truncated():
     avg = train_epoch(m, boolean, crit, opt, log_wandb=False)
     assert opt._tt_route is not None and abs(avg - float(g["epoch/avg_loss"])) <= TOL
     assert {int(opt.state[p]["step"]) for p in m.trainable_parameters()} == {nb}
+
+
+def test_step_graphs_survive_engines_created_and_destroyed_around_them():
+    """Round 6: a routed `train_epoch` left behind as cyclic garbage (optimizer <-> route), collected while the next trainers
+    were being built, made the first graph launch of the SECOND graph-replaying trainer crash inside the HIP runtime
+    (hip::Graph::UpdateStreams; tools/r06_graph_probe2.py) — the engine's second stream and its events were destroyed and
+    re-created between the captures.  The library now recycles them (engine.hip ForkKit), a trainer releases its graphs
+    before its engine, and nothing is collected or destroyed inside a capture.  The scenario, end to end."""
+    import gc
+
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import train_epoch
+
+    g = load_golden("step_mid.npz")
+    nb, lr = int(g["n_batches"]), float(g["lr"])
+    was_enabled = gc.isenabled()
+    gc.disable()                      # the garbage must still be there when the graph trainers are built
+    try:
+        for _ in range(2):
+            m, _ = build_model(g)
+            opt = torch.optim.Adam(m.parameters(), lr=lr)
+            train_epoch(m, [_pretok(g, i) for i in range(nb)], TripletLoss(margin=float(g["margin"])), opt, log_wandb=False)
+            assert opt._tt_route is not None
+            del m, opt                # optimizer._tt_route <-> route.optimizer: only the cycle collector frees the engine
+    finally:
+        if was_enabled:
+            gc.enable()
+    test_graph_replay_equals_eager_and_oracle()   # eager trainer, graph trainer, second graph trainer: captures + replays
+    gc.collect()
+    test_graph_replay_equals_eager_and_oracle()

@@ -1624,3 +1624,26 @@ def test_calibrate_picks_the_gather_form_for_a_table_beyond_the_infinity_cache_a
     cal = c.calibrate(TripletBatch(ids=torch.randint(0, 30522, (3, 256, 32), generator=gen).int().cuda()), steps=4, rounds=1)
     assert cal["k1_form"] is None and c.state_dict()["k1_form"] is None
     c.engine.close()
+
+
+def test_engine_close_inside_a_stream_capture_is_deferred(tt):
+    """An engine's finaliser may run wherever the garbage collector does — also between capture_begin and capture_end of
+    a hipGraph, where its device synchronise would invalidate the capture (round 6: a step graph captured while dead
+    engines of earlier tests were being collected crashed the process at its first replay).  close() inside a capture parks
+    the handle; the next close() outside a capture destroys both; the captured graph replays."""
+    _, engine = tt
+    table = torch.randn(64, 32).cuda()
+    a, b = engine.HotPathEngine(table, 8, 4, 6), engine.HotPathEngine(table, 8, 4, 6)
+    x = torch.zeros(16, device="cuda")
+    torch.cuda.synchronize()
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    before = len(engine.HotPathEngine._deferred)
+    with torch.cuda.graph(g, stream=s):
+        a.close()          # what a collected engine's __del__ does
+        x.add_(1.0)
+    assert len(engine.HotPathEngine._deferred) == before + 1 and a._h is None
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert float(x[0]) == 2.0
+    b.close()
+    assert not engine.HotPathEngine._deferred

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import two_towers_overlords_amd as pkg  # noqa: E402
-from bench_eval import MarcoLike, TimedTokenizer  # noqa: E402
+from bench_eval import MarcoLike, timed_tokenizer  # noqa: E402
 from bench_module import synthetic_tokenizer  # noqa: E402
 from two_towers_overlords_amd.evaluation import evaluate_model  # noqa: E402
 from two_towers_overlords_amd.model import EmbeddingOnlyEncoder, TwoTowersModel  # noqa: E402
@@ -21,7 +21,7 @@ from two_towers_overlords_amd.model import EmbeddingOnlyEncoder, TwoTowersModel 
 pkg.load()
 V, D, P = 30522, 384, 384
 table = torch.randn(V, D) * 0.02
-tok = TimedTokenizer(synthetic_tokenizer(V))
+tok = timed_tokenizer(synthetic_tokenizer(V))
 model = TwoTowersModel(projection_dim=P, tokenizer=tok, pretrained_model=EmbeddingOnlyEncoder(table), encoder_mode="embed").cuda()
 test = MarcoLike(10000, V, 12)
 kw = dict(sample_size=len(test), min_query_groups=200, candidate_pool_size=-1, comprehensive=True, batch_size=1024)

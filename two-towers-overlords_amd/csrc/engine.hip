@@ -10,6 +10,9 @@
 #include <new>
 #include "proj.h"
 
+#include <mutex>
+#include <vector>
+
 // text_rows != NULL: text t reads row text_rows[t] of a token store [n_store, S] (ids / mask / lens are the store's)
 int tt_k1_launch(const float* table, const void* ids, int ids_dtype, const void* mask, int mask_dtype,
                  const int32_t* lens, float* out, int64_t N, int S, int D, int64_t V, int32_t* oob_flag,
@@ -98,6 +101,41 @@ struct tt_engine {
 };
 
 namespace {
+// The engine's second stream and its fork / join events are RECYCLED between handles of a device, never destroyed — what
+// torch does with its own stream pool.  Round 6: with engines created and destroyed between the captures of hipGraphs (a
+// trainer with use_graphs per test), the HIP runtime's graph launch crashed in hip::Graph::UpdateStreams depending on which
+// engines had been destroyed before (tools/r06_graph_probe2.py); a process that only ever creates these objects does not
+// exercise that path.  The free list is the library's one piece of process-wide state: a cache of idle HIP objects, no
+// behaviour hangs on it.
+struct ForkKit {
+  int device;
+  hipStream_t aux;
+  hipEvent_t ev_fork[3], ev_join[3];
+};
+std::mutex g_kits_mu;
+std::vector<ForkKit> g_kits;
+
+bool take_fork_kit(int device, tt_engine* e) {
+  std::lock_guard<std::mutex> lock(g_kits_mu);
+  for (size_t i = 0; i < g_kits.size(); ++i) {
+    if (g_kits[i].device != device) continue;
+    e->aux = g_kits[i].aux;
+    for (int k = 0; k < 3; ++k) { e->ev_fork[k] = g_kits[i].ev_fork[k]; e->ev_join[k] = g_kits[i].ev_join[k]; }
+    g_kits.erase(g_kits.begin() + (long)i);
+    return true;
+  }
+  return false;
+}
+
+void give_fork_kit(tt_engine* e) {
+  ForkKit kit{};
+  kit.device = e->cfg.device;
+  kit.aux = e->aux;
+  for (int k = 0; k < 3; ++k) { kit.ev_fork[k] = e->ev_fork[k]; kit.ev_join[k] = e->ev_join[k]; }
+  std::lock_guard<std::mutex> lock(g_kits_mu);
+  g_kits.push_back(kit);
+}
+
 constexpr uint32_t kMagic = 0x7754454eu;
 inline bool ok(const tt_engine* e) { return e && e->magic == kMagic; }
 inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
@@ -213,22 +251,24 @@ extern "C" int tt_engine_create(const tt_engine_config* cfg, void* workspace, si
   e->arena = static_cast<char*>(workspace);
   carve(e, e->arena, &total);
   // the fork/join stream is optional: without it the backward is one chain on the caller's stream
-  if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) e->aux = nullptr;
-  for (int k = 0; k < 3 && e->aux; ++k) {
-    const unsigned flags = tt_event_flags(k);
-    if (hipEventCreateWithFlags(&e->ev_fork[k], flags) != hipSuccess) {
-      e->ev_fork[k] = nullptr;
-    } else if (hipEventCreateWithFlags(&e->ev_join[k], flags) != hipSuccess) {
-      (void)hipEventDestroy(e->ev_fork[k]);
-      e->ev_fork[k] = nullptr;
-    }
-    if (!e->ev_fork[k]) {  // without its events the second stream is of no use: one chain on the caller's stream
-      for (int j = 0; j < k; ++j) {
-        (void)hipEventDestroy(e->ev_fork[j]);
-        (void)hipEventDestroy(e->ev_join[j]);
+  if (!take_fork_kit(cfg->device, e)) {
+    if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) e->aux = nullptr;
+    for (int k = 0; k < 3 && e->aux; ++k) {
+      const unsigned flags = tt_event_flags(k);
+      if (hipEventCreateWithFlags(&e->ev_fork[k], flags) != hipSuccess) {
+        e->ev_fork[k] = nullptr;
+      } else if (hipEventCreateWithFlags(&e->ev_join[k], flags) != hipSuccess) {
+        (void)hipEventDestroy(e->ev_fork[k]);
+        e->ev_fork[k] = nullptr;
       }
-      (void)hipStreamDestroy(e->aux);
-      e->aux = nullptr;
+      if (!e->ev_fork[k]) {  // without its events the second stream is of no use: one chain on the caller's stream
+        for (int j = 0; j < k; ++j) {
+          (void)hipEventDestroy(e->ev_fork[j]);
+          (void)hipEventDestroy(e->ev_join[j]);
+        }
+        (void)hipStreamDestroy(e->aux);
+        e->aux = nullptr;
+      }
     }
   }
   e->gathers_share_chip = true;
@@ -247,11 +287,7 @@ extern "C" int tt_engine_destroy(tt_engine* e) {
   TT_REQUIRE(ok(e), TT_ERR_BAD_HANDLE);
   if (e->aux) {
     (void)hipStreamSynchronize(e->aux);
-    for (int k = 0; k < 3; ++k) {
-      (void)hipEventDestroy(e->ev_fork[k]);
-      (void)hipEventDestroy(e->ev_join[k]);
-    }
-    (void)hipStreamDestroy(e->aux);
+    give_fork_kit(e);  // the stream and its six events go back to the free list: never destroyed (see ForkKit)
   }
   e->magic = 0;
   delete e;

@@ -317,6 +317,13 @@ class TokenTripletLoader:
         self._padded = None  # (q_ids, p_ids) padded to one common S (pad="max")
 
     def _tokenize(self, tokenizer, texts, max_length):
+        from .textstore import hf_token_rows, is_hf_tokenizer
+
+        if is_hf_tokenizer(tokenizer) and len(texts):  # the same ids without transformers' tensor conversion
+            rows, lens = hf_token_rows(tokenizer, texts, max_length)
+            ids = torch.from_numpy(rows)
+            ids = torch.where(ids == -(2 ** 31), torch.zeros((), dtype=torch.int32), ids)  # this loader's rows are zero-padded + lens
+            return ids.to(self.device), torch.from_numpy(lens).to(self.device)
         tok = tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=max_length)
         ids, mask = tok["input_ids"], tok["attention_mask"]
         lens = mask.sum(1)

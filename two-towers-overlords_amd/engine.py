@@ -73,11 +73,24 @@ class HotPathEngine:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    _deferred = []  # (handle, workspace) of engines whose close() fell inside a stream capture: destroyed at the next safe close()
+
     def close(self) -> None:
-        if getattr(self, "_h", None):
-            torch.cuda.synchronize(self.device)
-            _lib.load().tt_engine_destroy(self._h)
-            self._h = None
+        """Destroy the handle (synchronises the device).  Never inside a stream capture: a garbage-collected engine's
+        `__del__` may run at any allocation — also between capture_begin and capture_end of somebody's hipGraph, where a
+        device synchronise invalidates the capture (round 6: a graph captured that way crashed the process at its first
+        replay).  There the handle and its workspace are parked and destroyed by the next close() outside a capture."""
+        h = getattr(self, "_h", None)
+        if not h:
+            return
+        self._h = None
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            HotPathEngine._deferred.append((h, self.workspace, self.device))
+            return
+        pending, HotPathEngine._deferred = HotPathEngine._deferred + [(h, self.workspace, self.device)], []
+        for handle, _ws, dev in pending:
+            torch.cuda.synchronize(dev)
+            _lib.load().tt_engine_destroy(handle)
 
     def __del__(self):
         try:

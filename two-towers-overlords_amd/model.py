@@ -148,7 +148,19 @@ class AveragePoolingTower(nn.Module):
 
     # -- the reference entry point ------------------------------------------------
     def forward(self, texts: list[str]) -> Tensor:
-        """model.py:40-60: tokenize, move to the model's device, pool, project."""
+        """model.py:40-60: tokenize, move to the model's device, pool, project.  `embed` mode behind a transformers
+        tokenizer: the same ids reach the gather as int32 rows with TT_PAD_ID behind each text's tokens
+        (textstore.hf_token_rows) — a quarter of the bytes of int64 ids + int64 mask over PCIe, and none of transformers'
+        Python-side tensor conversion, which costs more than the tokenisation."""
+        if self.encoder_mode == "embed" and len(texts):
+            from .textstore import hf_token_rows, is_hf_tokenizer
+
+            if is_hf_tokenizer(self.tokenizer):
+                rows, _ = hf_token_rows(self.tokenizer, texts)
+                ids = torch.from_numpy(rows).to(_module_device(self.pretrained_model))
+                with torch.no_grad():
+                    pooled = ops.gather_pool_norm(self.embedding_table().detach(), ids)
+                return self.project(pooled)
         return self.encode_tokens(self.tokenize(texts))
 
     def tokenize(self, texts: list[str]) -> dict:

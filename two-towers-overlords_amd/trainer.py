@@ -233,6 +233,29 @@ class TripletTrainer(CalibrationMixin, ExchangeMixin, GraphReplayMixin):
         if self._auto_step:
             self.engine.set_step(0)
 
+    # -- lifetime ---------------------------------------------------------------
+    def close(self) -> None:
+        """Release the captured step graphs BEFORE the engine.  A hipGraph captured by `_graph()` holds nodes that ran on
+        the engine's own second stream and on its events; attribute teardown on a plain refcount drop destroys `engine`
+        (assigned first) before `_graphs` — the graph execs then outlive a stream they reference, and destroying them
+        afterwards corrupted the HIP runtime's heap: the NEXT trainer's first graph launch crashed in
+        hip::Graph::UpdateStreams, depending on what else had been allocated and freed in the process (round 6,
+        tools/r06_graph_probe2.py)."""
+        graphs = self.__dict__.get("_graphs")
+        if graphs:
+            if self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize(self.device)
+            graphs.clear()
+        eng = self.__dict__.get("engine")
+        if eng is not None and hasattr(eng, "close"):
+            eng.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # -- helpers ---------------------------------------------------------------
     def named_parameters(self) -> dict:
         return {name: self.flat[off: off + int(math.prod(shape))].view(shape)

@@ -48,17 +48,28 @@ class GraphReplayMixin:
         B = self.engine.max_B
         if self._ring_ids is None and slot_k1 is not None:
             raise RuntimeError("ring not initialised")
-        torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        cap = torch.cuda.Stream(self.device)
-        with torch.cuda.graph(g, stream=cap):
-            if slot_k1 is not None:  # branch: the gather of the batch two steps ahead
-                self.side.wait_stream(cap)
-                self.engine.pool(slot_k1, self._ring_ids[slot_k1], None, self._ring_lens[slot_k1],
-                                 stream=self.side.cuda_stream)
-            self.engine.fwd_bwd(slot_fb, B, self.margin, 1.0 / B, float(B))
-            self.engine.adam_auto(self.lr, None, self.betas[0], self.betas[1], self.eps)
-            if slot_k1 is not None:
-                cap.wait_stream(self.side)
+        # Nothing but this step's launches may happen between capture_begin and capture_end: a cyclic-garbage collection
+        # in there can run the finaliser of some dead engine or tensor (device synchronise, frees) and invalidate the capture.
+        import gc
+
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(self.device)
+            with torch.cuda.graph(g, stream=cap):
+                if slot_k1 is not None:  # branch: the gather of the batch two steps ahead
+                    self.side.wait_stream(cap)
+                    self.engine.pool(slot_k1, self._ring_ids[slot_k1], None, self._ring_lens[slot_k1],
+                                     stream=self.side.cuda_stream)
+                self.engine.fwd_bwd(slot_fb, B, self.margin, 1.0 / B, float(B))
+                self.engine.adam_auto(self.lr, None, self.betas[0], self.betas[1], self.eps)
+                if slot_k1 is not None:
+                    cap.wait_stream(self.side)
+        finally:
+            if was_enabled:
+                gc.enable()
         self._graphs[key] = g
         return g

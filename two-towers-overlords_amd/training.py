@@ -305,7 +305,7 @@ class _EngineRoute:
         import numpy as np
 
         from .data import TextColumn
-        from .textstore import TextRowStore
+        from .textstore import TextRowStore, hf_token_rows, is_hf_tokenizer
 
         if not (len(queries) == len(positives) == len(negatives)):
             raise ValueError("train_epoch(fused): queries, positives and negatives of a batch must have one length")
@@ -316,7 +316,10 @@ class _EngineRoute:
         for tower, texts in ((self.model.query_tower, queries), (self.model.document_tower, positives),
                              (self.model.document_tower, negatives)):
             tok = tower.tokenizer
-            call = lambda t, tok=tok: tok(t, padding=True, truncation=True, return_tensors="pt", max_length=512)
+            if is_hf_tokenizer(tok):  # the same ids without transformers' tensor conversion (textstore.hf_token_rows)
+                call = lambda t, tok=tok: hf_token_rows(tok, t)
+            else:
+                call = lambda t, tok=tok: tok(t, padding=True, truncation=True, return_tensors="pt", max_length=512)
             if isinstance(texts, TextColumn) and texts.field in ("query", "positive"):
                 rows.append(store.rows_of_column(texts, call))
             else:

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Runs the bench modes reported in DESIGN.md section 5 on ONE box and writes the JSON lines, rocprofv3 kernel stats,
 # timelines, MFMA utilisation and K1 fabric-traffic (PMC) summaries to gpurun_out/refresh/ (copied into profiles/ afterwards).
-#   usage: tools/refresh_profiles.sh [rNN]         (every variant is a bench argument: nothing reads the environment)
-r=${1:-r05}
+#   usage: tools/refresh_profiles.sh [rNN] [benches|profiles|all]   (every variant is a bench argument: nothing reads the
+#   environment; the two halves fit one 20-minute gpurun call each)
+r=${1:-r06}; part=${2:-all}
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/refresh; mkdir -p $out
 cd $root
 B="python bench.py --no-cpu-baseline --no-secondary"
+if [ "$part" != "profiles" ]; then
 python bench.py > $out/${r}_bench_c2_default.json 2> $out/${r}_bench_c2_default.err || exit 1
 $B --steps 20 --warmup 5 > $out/${r}_bench_c2_default_k20_w5.json
 $B --no-overlap > $out/${r}_bench_c2_no_overlap.json
@@ -14,8 +16,14 @@ $B --zipf > $out/${r}_bench_c2_zipf.json
 $B --inputs index > $out/${r}_bench_c2_inputs_index.json
 $B --inputs cache > $out/${r}_bench_c2_inputs_cache.json
 $B --e2e --steps 1000 > $out/${r}_bench_c2_e2e_epoch1000.json
-$B --path module --steps 200 > $out/${r}_bench_c2_module_path.json
+$B --path module --steps 400 --warmup 50 > $out/${r}_bench_c2_module_path.json                         # the reference's own torch.optim.Adam, routed
+$B --path module --optimizer fused --steps 400 --warmup 50 > $out/${r}_bench_c2_module_path_fused_adam.json
 $B --path module-unfused --steps 200 > $out/${r}_bench_c2_module_unfused.json
+$B --path module --strings columns --steps 64 --epochs 12 > $out/${r}_bench_c2_strings_columns.json 2> /dev/null
+$B --path module --strings lists --steps 64 --epochs 12 > $out/${r}_bench_c2_strings_lists.json 2> /dev/null
+$B --path module --strings loader --steps 16 --epochs 6 > $out/${r}_bench_c2_strings_loader.json 2> /dev/null
+$B --path module --strings lists --steps 4 --epochs 2 --text-cache 0 > $out/${r}_bench_c2_strings_lists_nocache.json 2> /dev/null
+python bench.py --eval > $out/${r}_eval.json 2> /dev/null
 $B --loss inbatch > $out/${r}_bench_c2_inbatch_b2048.json
 $B --loss inbatch --batch 4096 > $out/${r}_bench_inbatch_b4096.json
 $B --loss inbatch --batch 512 > $out/${r}_bench_inbatch_b512_share.json
@@ -29,6 +37,8 @@ $B --config c4 --steps 40 --warmup 8 --ragged --tune k1_form=stream > $out/${r}_
 $B --config c4 --steps 20 --warmup 4 --no-overlap > $out/${r}_bench_c4_no_overlap.json
 $B --config c4 --steps 12 --warmup 4 --inputs index > $out/${r}_bench_c4_inputs_index.json
 echo "benches done"
+fi
+if [ "$part" = "benches" ]; then exit 0; fi
 cd /tmp && export TMPDIR=/tmp
 prof() { tag=$1; first=$2; shift 2
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -o ks -- python3 $root/bench.py --no-cpu-baseline --no-secondary "$@" > /dev/null 2>&1
@@ -75,4 +85,8 @@ traffic() { cfg=$1; alg=$2; kern=$3; tag=$4; shift 4
 traffic c2 1220542464 pool_colsliced_kernel,pool_colnorm_kernel c2
 traffic c4 38856032256 pool_binned_kernel,pool_bincombine_kernel,pool_bin_kernel c4
 traffic c4 38856032256 pool_norm_stream_kernel c4_stream --tune k1_form=stream
+# SURVEY section 8 f2 under the profiler: kernel stats + MFMA utilisation of the cosine-score GEMM
+bash $root/tools/r06_eval_prof.sh $out/evalprof > /dev/null 2>&1 && cp $out/evalprof/r06_eval_kernel_stats.csv $out/${r}_eval_kernel_stats.csv && cp $out/evalprof/r06_eval_mfma_util.txt $out/${r}_eval_mfma_util.txt
+# the data-parallel step under a stand-in exchange at configs[2]'s share (the table of DESIGN.md section 6)
+cd $root && python tools/ab_tune.py --rounds 2 --out $out/${r}_dp_sim_c3.txt -v "single:" -v "x0:--simulate-allreduce-us 0" -v "x30:--simulate-allreduce-us 30" -v "x60:--simulate-allreduce-us 60" -v "x100:--simulate-allreduce-us 100" -- --config c3 --steps 200 --warmup 20 > /dev/null 2>&1
 echo refreshed

@@ -42,13 +42,18 @@ rows = [
     ("`--zipf` ids (SURVEY §8d's text-like id distribution)", R + "_bench_c2_zipf.json"),
     ("`--inputs index` (negatives by in-batch index, 2 gathers)", R + "_bench_c2_inputs_index.json"),
     ("`--inputs cache` (cache-fed step: no gather)", R + "_bench_c2_inputs_cache.json"),
-    ("**`--path module`**: the drop-in `train_epoch(model, batches, TripletLoss, FusedAdam)` — batch body routed to the engine; fill, drain, engine-side role packing and the loss reads inside the timed epoch", R + "_bench_c2_module_path.json"),
-    ("`--path module-unfused`: the same call with `fused=False` (autograd Functions, module by module)", R + "_bench_c2_module_unfused.json"),
+    ("**`--path module`**: the reference's literal call `train_epoch(model, batches, TripletLoss(), torch.optim.Adam(model.parameters(), lr))` on pre-tokenised int64 (ids, mask) per role — batch body routed to the engine; fill, drain, engine-side role packing and the loss reads inside the timed epoch", R + "_bench_c2_module_path.json"),
+    ("… with `--optimizer fused` (`FusedAdam`)", R + "_bench_c2_module_path_fused_adam.json"),
+    ("`--path module-unfused`: the same call with `fused=False` (autograd Functions, module by module, torch's own Adam kernels)", R + "_bench_c2_module_unfused.json"),
+    ("**`--path module --strings columns`**: STRING batches (real `BertTokenizerFast`) as the row-tagged lists this package's `TripletDataLoader` yields; best epoch ≥ 2 (text store, no tokenizer call)", R + "_bench_c2_strings_columns.json"),
+    ("`--strings lists`: plain `list[str]` batches, best epoch ≥ 2 (one dict look-up per text on the host)", R + "_bench_c2_strings_lists.json"),
+    ("`--strings loader`: through `TripletDataLoader` itself (the reference's shuffle + negative draws per batch), best epoch ≥ 2", R + "_bench_c2_strings_loader.json"),
+    ("`--strings lists --text-cache 0`: three tokenizer calls per batch, every epoch — what the reference does", R + "_bench_c2_strings_lists_nocache.json"),
     ("configs[2], one GPU's share (B = 1024 of 8192, P = 512)", R + "_bench_c3_share.json"),
     ("**configs[3]** (V = 250k, D = P = 768, S = 256, B = 16384; binned K1)", R + "_bench_c4_full.json"),
     ("configs[3] with the streaming K1 (`--tune k1_form=stream`: round 3's form, same box)", R + "_bench_c4_stream_form.json"),
-    ("configs[3] `--zipf` ids, the shape rule's binned K1", R + "_bench_c4_zipf.json"),
-    ("configs[3] `--zipf` ids, streaming K1 (what `calibrate(k1_forms=True)` picks)", R + "_bench_c4_zipf_stream_form.json"),
+    ("configs[3] `--zipf` ids, DEFAULT (round 6: `calibrate()` times both gather forms for a table beyond the Infinity Cache and picked the streaming one)", R + "_bench_c4_zipf.json"),
+    ("configs[3] `--zipf` ids, streaming K1 forced (`--tune k1_form=stream`)", R + "_bench_c4_zipf_stream_form.json"),
     ("configs[3] `--ragged` lengths, binned K1", R + "_bench_c4_ragged.json"),
     ("configs[3] `--ragged` lengths, streaming K1", R + "_bench_c4_ragged_stream_form.json"),
     ("configs[3] one stream `--no-overlap`", R + "_bench_c4_no_overlap.json"),

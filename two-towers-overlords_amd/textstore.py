@@ -144,6 +144,8 @@ class TextRowStore:
     # -- the two look-ups ------------------------------------------------------------
     def rows_of_texts(self, key, texts: Sequence[str], tokenize: Callable) -> np.ndarray:
         d = self._by_text.setdefault(key, {})
+        if len(texts) == 0:
+            return np.zeros(0, dtype=np.int64)
         try:
             got = operator.itemgetter(*texts)(d) if len(texts) > 1 else (d[texts[0]],)
         except KeyError:

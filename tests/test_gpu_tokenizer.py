@@ -236,3 +236,43 @@ def test_triplet_dataloader_batches_carry_their_dataset_rows_through_the_text_st
         assert abs(a - b) <= 1e-5
     for x, y in zip(out[False][1], out[None][1]):
         assert (x - y).abs().max().item() <= 2e-5 * max(1.0, x.abs().max().item())
+
+
+def test_string_batches_through_accumulation_and_an_engine_rebuild_mid_epoch(tok):
+    """`train_epoch_optimized(model, string batches, ..., accumulation_steps=2)` (backend/training.py:66-133) on the engine
+    with the text store, over batches whose sizes GROW mid-epoch (16, 32, 40, 8: the engine is rebuilt for the larger ones
+    while the store, the optimizer state and the un-applied gradient window carry over) — against the module loop that
+    tokenises every batch like the reference; two epochs, so the odd batch's gradient crosses the epoch boundary."""
+    from two_towers_overlords_amd.model import TripletLoss
+    from two_towers_overlords_amd.training import train_epoch_optimized
+
+    rng = random.Random(13)
+    items = _marco_like(30, 136, rng)
+    sizes, batches, s = [16, 32, 40, 8, 40], [], 0
+    for n in sizes:
+        chunk = items[s: s + n]
+        s += n
+        neg = [(i * 5 + 1) % n for i in range(n)]
+        batches.append(([c["query"] for c in chunk], [c["positive"] for c in chunk], [chunk[j]["positive"] for j in neg]))
+    crit = TripletLoss(margin=0.3)
+    out = {}
+    for fused in (False, None):
+        model, _ = _model(tok, 40, 9)
+        opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+        losses = [train_epoch_optimized(model, batches, crit, opt, torch.device("cuda"), None, accumulation_steps=2,
+                                        log_wandb=False, fused=fused) for _ in range(2)]
+        grads = [None if p.grad is None else p.grad.clone() for p in model.trainable_parameters()]
+        out[fused] = (losses, [p.detach().clone() for p in model.trainable_parameters()], grads,
+                      {int(opt.state[p]["step"]) for p in model.trainable_parameters()})
+        if fused is None:
+            route = opt._tt_route
+            assert route.trainer.engine.max_B == 40 and route.text_store.stats()["texts_tokenized"] == route.text_store.stats()["rows"]
+    assert out[False][3] == out[None][3] == {4}     # two optimizer steps per epoch (batch_idx restarts); epoch 1's fifth gradient is applied with epoch 2's first window
+    for a, b in zip(out[False][0], out[None][0]):
+        assert abs(a - b) <= 1e-5
+    for x, y in zip(out[False][1], out[None][1]):
+        assert (x - y).abs().max().item() <= 2e-5 * max(1.0, x.abs().max().item())
+    for x, y in zip(out[False][2], out[None][2]):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert (x - y).abs().max().item() <= 1e-5 * max(1.0, x.abs().max().item())

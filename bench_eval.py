@@ -213,6 +213,17 @@ def run_eval(args, device, CONFIGS) -> dict:
                 "ndcg_at_10_5_1": {"us": t_ndcg, "kernels": "ndcg_kernel: one workgroup per query, <= 2 x 10 passes over its N scores",
                                    "bytes_per_pass": Q * N * (8 + (1 if valid is not None else 0))},
             }
+        # what the reference's search path pays per request (backend/search.py:365: `encode_queries([query])`, B = 1, then the
+        # vector goes to the host): wall time per call incl. tokenizer, H2D, K1 + K2 and the read-back
+        one = [test[i]["query"] for i in range(64)]
+        with torch.no_grad():
+            for q_ in one[:8]:
+                model.encode_queries([q_]).cpu()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for q_ in one:
+                model.encode_queries([q_]).cpu()
+            single_us = (time.perf_counter() - t0) / len(one) * 1e6
         # the reference's loop on the CPU oracle (rank 0, bounded)
         cpu = {}
         if not args.no_cpu_baseline:
@@ -242,6 +253,7 @@ def run_eval(args, device, CONFIGS) -> dict:
                    "tokenizer": "transformers.BertTokenizerFast over a synthetic vocab.txt", "queries_tokens": "6-16",
                    "passage_tokens": "32-128", "host_threads": os.cpu_count()},
         "shapes": out,
+        "single_query_encode_us": single_us,
         "roofline": {"bound": "mfma", "kernel": "tt_cosine_scores_f32 (comprehensive shape)",
                      "achieved": head["cosine_scores"]["tflops"], "peak": F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": head["cosine_scores"]["frac_of_f32_mfma_peak"], "traffic": None,

@@ -292,7 +292,15 @@ def main():
                          "package's TripletDataLoader yields, pre-built; loader = the TripletDataLoader itself "
                          "(shuffle + the reference's in-batch negative draws per batch).  Reports epoch 1 (tokenises) and "
                          "epochs >= 2 (the text store) separately")
-    ap.add_argument("--epochs", type=int, default=3, help="--strings: epochs over the same --steps batches (1 cold + the rest warm)")
+    ap.add_argument("--epochs", type=int, default=None, help="--strings: epochs over the same --steps batches (1 cold + the rest warm; "
+                    "default 3).  --run-training: num_epochs (default 15)")
+    ap.add_argument("--run-training", action="store_true",
+                    help="time a WHOLE run_training(...) call (backend/training.py:383-529) end to end: tokenizer, frozen-feature cache, "
+                         "epochs, per-epoch validation, final test (bench_run_training.py); its own metric name")
+    ap.add_argument("--pairs", type=int, default=100000, help="--run-training: (query, positive) pairs = max_samples")
+    ap.add_argument("--proj", type=int, default=512, help="--run-training: projection_dim")
+    ap.add_argument("--encoders", default="bert,embed", help="--run-training: encoder modes to run, comma-separated (bert = the reference's "
+                    "executed forward with a MiniLM-L6-shaped frozen encoder; embed = the word-embedding gather)")
     ap.add_argument("--text-cache", type=int, default=1, choices=[0, 1],
                     help="--strings: 0 = train_epoch(text_cache=False): the three tokenizer calls on every batch, as the reference does")
     ap.add_argument("--eval", action="store_true",
@@ -394,6 +402,13 @@ def main():
             torch.cuda.synchronize(device)
             assert int(probe.item()) == world
 
+    if args.run_training:
+        from bench_run_training import run_training_bench
+
+        if world > 1:
+            sys.exit("--run-training is a single-process measurement")
+        print(json.dumps(run_training_bench(args, device)))
+        return
     if args.eval:
         from bench_eval import run_eval
 

@@ -111,11 +111,11 @@ def run_module_path(args, device, CONFIGS, make_ids) -> dict:
         batches, n_items, build_s = _string_batches(args, B, S, V, tok)
         epochs = []
         with contextlib.redirect_stdout(sys.stderr):  # train_epoch prints every 10th batch's loss, like the reference
-            for e in range(max(args.epochs, 2)):
+            for e in range(max(args.epochs or 3, 2)):
                 st0 = route().text_store.stats() if route() is not None and route().text_store is not None else None
                 torch.cuda.synchronize(device)
                 prof = None
-                if args.debug_hostprof and e == max(args.epochs, 2) - 1:  # cProfile of the last (warm) epoch's host side
+                if args.debug_hostprof and e == max(args.epochs or 3, 2) - 1:  # cProfile of the last (warm) epoch's host side
                     import cProfile
 
                     prof = cProfile.Profile()

@@ -156,3 +156,26 @@ def test_which_optimizers_the_engine_route_takes():
     opt.step()
     native = opt.state[w[0]]["step"]
     assert type(native) is type(_step_value("torch", 1)) and native.dtype == _step_value("torch", 1).dtype and native.device == s.device
+
+
+def test_tower_tokenize_rebuilds_the_reference_calls_tensors(tok):
+    """`AveragePoolingTower.tokenize` behind a right-padding transformers tokenizer: the same keys, dtypes and values as
+    `tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=512)` (backend/model.py:43-45)."""
+    from two_towers_overlords_amd.model import AveragePoolingTower, EmbeddingOnlyEncoder
+
+    rng = random.Random(4)
+    texts = _texts(33, rng, 1, 30) + [" ".join(["mu"] * 600)]
+    tower = AveragePoolingTower(projection_dim=8, tokenizer=tok, pretrained_model=EmbeddingOnlyEncoder(torch.zeros(tok.vocab_size, 16)),
+                                encoder_mode="embed")
+    got = tower.tokenize(texts)
+    ref = tok(texts, padding=True, truncation=True, return_tensors="pt", max_length=512)
+    assert set(got) == set(ref.keys())
+    for k in ref.keys():
+        assert got[k].dtype == ref[k].dtype and torch.equal(got[k], ref[k]), k
+    tok.padding_side = "left"                     # a left-padding tokenizer keeps the reference's literal call
+    try:
+        left = tower.tokenize(texts[:5])
+        ref = tok(texts[:5], padding=True, truncation=True, return_tensors="pt", max_length=512)
+        assert all(torch.equal(left[k], ref[k]) for k in ref.keys()) and int(left["attention_mask"][0, 0]) in (0, 1)
+    finally:
+        tok.padding_side = "right"

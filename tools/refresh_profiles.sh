@@ -24,6 +24,7 @@ $B --path module --strings lists --steps 64 --epochs 12 > $out/${r}_bench_c2_str
 $B --path module --strings loader --steps 16 --epochs 6 > $out/${r}_bench_c2_strings_loader.json 2> /dev/null
 $B --path module --strings lists --steps 4 --epochs 2 --text-cache 0 > $out/${r}_bench_c2_strings_lists_nocache.json 2> /dev/null
 python bench.py --eval > $out/${r}_eval.json 2> /dev/null
+python bench.py --run-training > $out/${r}_run_training.json 2> /dev/null   # the whole run_training call end to end, bert + embed
 $B --loss inbatch > $out/${r}_bench_c2_inbatch_b2048.json
 $B --loss inbatch --batch 4096 > $out/${r}_bench_inbatch_b4096.json
 $B --loss inbatch --batch 512 > $out/${r}_bench_inbatch_b512_share.json

@@ -164,9 +164,26 @@ class AveragePoolingTower(nn.Module):
         return self.encode_tokens(self.tokenize(texts))
 
     def tokenize(self, texts: list[str]) -> dict:
-        """model.py:43-48: the tokenizer call and the `.to(device)` of its tensors."""
-        tokens = self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=512)
+        """model.py:43-48: the tokenizer call and the `.to(device)` of its tensors.  A right-padding transformers tokenizer is
+        asked for plain lists and its padded int64 `input_ids` / `attention_mask` (/ all-zero `token_type_ids`) are rebuilt
+        here — the tensors the reference's call returns, element for element (tests/test_textstore_cpu.py), without
+        transformers' Python-side tensor conversion (textstore.hf_token_rows)."""
         device = _module_device(self.pretrained_model)
+        tok = self.tokenizer
+        if len(texts) and getattr(tok, "padding_side", None) == "right":
+            from .textstore import PAD32, hf_token_rows, is_hf_tokenizer
+
+            if is_hf_tokenizer(tok):
+                rows, _ = hf_token_rows(tok, texts)
+                rows = torch.from_numpy(rows).to(device)
+                keep = rows != PAD32
+                pad_id = tok.pad_token_id if tok.pad_token_id is not None else 0
+                out = {"input_ids": torch.where(keep, rows, torch.full((), pad_id, dtype=torch.int32, device=device)).long()}
+                if "token_type_ids" in getattr(tok, "model_input_names", ()):
+                    out["token_type_ids"] = torch.zeros_like(out["input_ids"])
+                out["attention_mask"] = keep.long()
+                return out
+        tokens = tok(texts, padding=True, truncation=True, return_tensors="pt", max_length=512)
         return {k: v.to(device) for k, v in tokens.items()}
 
     # -- tensor-level entry points (additive) -------------------------------------

@@ -584,12 +584,12 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
                  encoder_mode: Optional[str] = None, calibrate: bool = True, three_encodes: bool = False) -> TwoTowersModel:
     """Same keyword surface and defaults as backend/training.py:383-397; builds the
     model / criterion / Adam exactly like :433-436 and runs `num_epochs` epochs on
-    the fused engine.  Differences, all outside the hot path: the dataset is passed
-    in (`train_dataset`, any map-style {"query_id","query","positive"}; the
-    reference's MSMarcoDataset is a network fetch), wandb and the NDCG evaluation
-    harness (training.py:136-380) are not reproduced, `use_mixed_precision` /
-    `num_workers` / `run_comprehensive_test` are accepted for signature parity and
-    ignored (fp32 is the parity path; tokenisation happens once, up front).
+    the fused engine.  Differences, all outside the hot path: the datasets are passed
+    in (`train_dataset`, `val_dataset`, `test_dataset`: any map-style {"query_id","query","positive"}; the
+    reference's MSMarcoDataset is a network fetch), wandb is not reproduced; the per-epoch validation NDCG@10
+    (training.py:490) and the final comprehensive test (:505-521, `run_comprehensive_test`) run on the device
+    (`evaluation.evaluate_model`) when their dataset is given; `use_mixed_precision` / `num_workers` are accepted for
+    signature parity and ignored (fp32 is the parity path; tokenisation happens once, up front).
     `encoder_mode` None = the model's own default (`TwoTowersModel`: "bert" for a pretrained model with encoder layers —
     what the reference executes — else "embed"), so a default `run_training` and a default-constructed model that later
     loads its weights agree; the mode travels with the checkpoint (state_dict metadata) and a mismatch at load time

@@ -300,7 +300,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=100000, help="--run-training: (query, positive) pairs = max_samples")
     ap.add_argument("--proj", type=int, default=512, help="--run-training: projection_dim")
     ap.add_argument("--encoders", default="bert,embed", help="--run-training: encoder modes to run, comma-separated (bert = the reference's "
-                    "executed forward with a MiniLM-L6-shaped frozen encoder; embed = the word-embedding gather)")
+                    "executed forward with a MiniLM-L6-shaped frozen encoder; bert:fp16 / bert:bf16 = the same with the frozen encoder under "
+                    "torch.autocast like the reference's GPU loop (NOT the parity path); embed = the word-embedding gather)")
     ap.add_argument("--text-cache", type=int, default=1, choices=[0, 1],
                     help="--strings: 0 = train_epoch(text_cache=False): the three tokenizer calls on every batch, as the reference does")
     ap.add_argument("--eval", action="store_true",

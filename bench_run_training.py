@@ -39,7 +39,7 @@ def run_training_bench(args, device) -> dict:
     out = {}
     for mode in args.encoders.split(","):
         torch.manual_seed(0)
-        if mode == "bert":
+        if mode.startswith("bert"):
             cfg = transformers.BertConfig(vocab_size=V, hidden_size=D, num_hidden_layers=6, num_attention_heads=12,
                                           intermediate_size=1536, max_position_embeddings=512)
             encoder = transformers.BertModel(cfg).eval()
@@ -72,7 +72,8 @@ def run_training_bench(args, device) -> dict:
                 model = run_training(num_epochs=E, batch_size=B, learning_rate=1e-4, max_samples=N, projection_dim=P, margin=0.3,
                                      use_wandb=False, accumulation_steps=1, use_mixed_precision=False, num_workers=0,
                                      run_comprehensive_test=True, train_dataset=train, val_dataset=val, test_dataset=test,
-                                     tokenizer=tok, pretrained_model=encoder, encoder_mode=mode, seed=5)
+                                     tokenizer=tok, pretrained_model=encoder, encoder_mode=mode.split(":")[0], seed=5,
+                                     encoder_autocast=(mode.split(":")[1] if ":" in mode else None))
                 torch.cuda.synchronize(device)
                 wall = time.perf_counter() - t0
         finally:

@@ -961,3 +961,32 @@ def test_step_graphs_survive_engines_created_and_destroyed_around_them():
     test_graph_replay_equals_eager_and_oracle()   # eager trainer, graph trainer, second graph trainer: captures + replays
     gc.collect()
     test_graph_replay_equals_eager_and_oracle()
+
+
+def test_feature_cache_under_encoder_autocast_is_flagged_and_close():
+    """`build_feature_cache(encoder_autocast=torch.float16 | torch.bfloat16)` — the frozen encoder's one pass per text under
+    `torch.autocast`, what `use_mixed_precision=True` means for the encoder in the reference's GPU loop (backend/training.py:83).
+    NOT the parity path: the default (None) stays bitwise the fp32 cache; the half-precision caches are unit vectors within
+    half-precision rounding of it."""
+    transformers = pytest.importorskip("transformers")
+    from two_towers_overlords_amd.training import TripletTrainer
+    from two_towers_overlords_amd.model import TwoTowersModel
+
+    torch.manual_seed(5)
+    cfg = transformers.BertConfig(vocab_size=400, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                                  max_position_embeddings=64)
+    bert = transformers.BertModel(cfg).eval()
+    model = TwoTowersModel(projection_dim=16, tokenizer=lambda *a, **k: None, pretrained_model=bert, encoder_mode="bert").cuda()
+    gen = torch.Generator().manual_seed(6)
+    N, S = 96, 24
+    ids = torch.randint(1, 400, (N, S), generator=gen).int().cuda()
+    lens = torch.randint(1, S + 1, (N,), generator=gen).int().cuda()
+    tr = TripletTrainer(model, max_batch=32, max_seq_len=S, margin=0.3, lr=1e-3)
+    ref = tr.build_feature_cache(ids, lens=lens, chunk=40).clone()
+    assert torch.equal(tr.build_feature_cache(ids, lens=lens, chunk=40, encoder_autocast=None), ref)
+    for dt, tol in ((torch.float16, 5e-3), (torch.bfloat16, 4e-2)):
+        got = tr.build_feature_cache(ids, lens=lens, chunk=40, encoder_autocast=dt)
+        assert got.dtype == torch.float32 and float((got.norm(dim=1) - 1).abs().max()) <= 1e-5
+        assert 0 < float((got - ref).abs().max()) <= tol, dt
+        assert float((got * ref).sum(1).min()) >= 1 - tol
+    tr.close()

@@ -388,13 +388,17 @@ class TripletTrainer(CalibrationMixin, ExchangeMixin, GraphReplayMixin):
 
     @torch.no_grad()
     def build_feature_cache(self, ids: torch.Tensor, mask: Optional[torch.Tensor] = None,
-                            lens: Optional[torch.Tensor] = None, chunk: Optional[int] = None) -> torch.Tensor:
+                            lens: Optional[torch.Tensor] = None, chunk: Optional[int] = None,
+                            encoder_autocast: Optional[torch.dtype] = None) -> torch.Tensor:
         """Frozen-feature cache: the encoder is frozen (backend/model.py:29-30,51),
         so every text's pooled-normalised vector is computed ONCE here and later batches only copy rows
         (`TripletBatch.cache_rows`).  `embed` mode: K1 over ids [N,S].  `bert` mode: the frozen encoder
         (stock PyTorch-ROCm ops, `chunk` texts at a time) + the dense pool kernel — what the reference
         recomputes three times per step in every epoch (training.py:40-42) runs once per text, and every
-        epoch after that is the fused cache-fed step.  Returns the [N, D] cache."""
+        epoch after that is the fused cache-fed step.  Returns the [N, D] cache.
+        `encoder_autocast` (`bert` mode; NOT the parity path): run the frozen encoder under `torch.autocast` in this dtype
+        (torch.float16 is what the reference's GPU loop does, backend/training.py:83; torch.bfloat16) — its hidden states are
+        pooled in fp32 as always, but they carry half-precision rounding (~1e-3): off by default."""
         N = ids.shape[0]
         out = torch.empty((N, self.D), dtype=torch.float32, device=self.device)
         bert = self.encoder_mode != "embed"
@@ -425,7 +429,11 @@ class TripletTrainer(CalibrationMixin, ExchangeMixin, GraphReplayMixin):
                     tokens = {"input_ids": ids[sel][:, :cut].long().contiguous()}
                     if mask is not None:
                         tokens["attention_mask"] = mask[sel][:, :cut].contiguous()
-                    out[sel] = self.model.query_tower.pool_tokens(tokens)
+                    if encoder_autocast is not None:
+                        with torch.autocast(self.device.type, dtype=encoder_autocast):
+                            out[sel] = self.model.query_tower.pool_tokens(tokens)
+                    else:
+                        out[sel] = self.model.query_tower.pool_tokens(tokens)
             finally:
                 pm.train(was_training)
         else:

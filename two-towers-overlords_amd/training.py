@@ -581,7 +581,8 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
                  run_comprehensive_test: bool = True, *, train_dataset=None, val_dataset=None, test_dataset=None,
                  tokenizer=None, pretrained_model=None, model_name: Optional[str] = None,
                  seed: Optional[int] = None, feature_cache: bool = True, sampler: str = "device",
-                 encoder_mode: Optional[str] = None, calibrate: bool = True, three_encodes: bool = False) -> TwoTowersModel:
+                 encoder_mode: Optional[str] = None, calibrate: bool = True, three_encodes: bool = False,
+                 encoder_autocast: Optional[str] = None) -> TwoTowersModel:
     """Same keyword surface and defaults as backend/training.py:383-397; builds the
     model / criterion / Adam exactly like :433-436 and runs `num_epochs` epochs on
     the fused engine.  Differences, all outside the hot path: the datasets are passed
@@ -599,7 +600,10 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
     the fused cache-fed step, where the reference re-runs the encoder three times per step (99 % of its step
     time); needs feature_cache=True.  `sampler`: "device" draws the in-batch
     negatives with tensor ops (same distribution, no per-batch host work); "reference" reproduces
-    backend/data.py:132-137's draws under `seed`, at its O(B^2) Python cost per batch."""
+    backend/data.py:132-137's draws under `seed`, at its O(B^2) Python cost per batch.
+    `encoder_autocast` ("fp16" | "bf16"; `bert` mode; NOT the parity path): the frozen encoder's one pass per text runs under
+    `torch.autocast` — what `use_mixed_precision=True` means for the encoder in the reference's GPU loop (training.py:83);
+    projections, loss and Adam stay fp32.  `use_mixed_precision` itself stays ignored so that a default call is the parity path."""
     from .data import TokenTripletLoader
 
     if train_dataset is None:
@@ -634,7 +638,8 @@ def run_training(num_epochs: int = 3, batch_size: int = 1024, learning_rate: flo
         # the encoder is frozen: pool every query / passage once, every epoch then only copies rows and
         # takes its negatives by in-batch index
         loader.emit = "cache"
-        trainer.build_feature_cache(*_ids_lens(loader.all_texts()))
+        amp = {None: None, "fp16": torch.float16, "bf16": torch.bfloat16}[encoder_autocast]
+        trainer.build_feature_cache(*_ids_lens(loader.all_texts()), encoder_autocast=(amp if encoder_mode != "embed" else None))
     else:
         # the token rows stay on the device and a batch names its texts by row; the negatives ARE
         # in-batch positives (backend/data.py:113-137), so by default they are taken by index from the positives'

@@ -179,3 +179,52 @@ def test_tower_tokenize_rebuilds_the_reference_calls_tensors(tok):
         assert all(torch.equal(left[k], ref[k]) for k in ref.keys()) and int(left["attention_mask"][0, 0]) in (0, 1)
     finally:
         tok.padding_side = "right"
+
+
+def test_backend_tokenizer_path_is_self_checked_and_falls_back(tmp_path):
+    """`textstore._backend_ids` calls the Rust backend directly (transformers' per-text Python costs more than the tokenizer),
+    after checking ONCE per tokenizer object that the backend's ids are the public call's; a backend that disagrees, or
+    raises, is never used again and the public call's ids are returned."""
+    transformers = pytest.importorskip("transformers")
+    (tmp_path / "vocab.txt").write_text("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + WORDS) + "\n")
+    rng = random.Random(8)
+    texts = _texts(40, rng, 1, 12)
+
+    def fresh():
+        return transformers.BertTokenizerFast.from_pretrained(str(tmp_path))
+
+    good = fresh()
+    want = good(texts, padding=True, truncation=True, return_tensors="pt", max_length=512)
+    rows, lens = hf_token_rows(good, texts)
+    assert good._tt_backend_ids is True
+    keep = want["attention_mask"].numpy().astype(bool)
+    assert np.array_equal(rows[keep], want["input_ids"].numpy()[keep]) and np.array_equal(lens, keep.sum(1))
+
+    class Proxy:
+        def __init__(self, real, mode):
+            self.real, self.mode = real, mode
+
+        def encode_batch(self, batch, **kw):
+            if self.mode == "raise":
+                raise RuntimeError("backend unavailable")
+            out = self.real.encode_batch(batch, **kw)
+
+            class E:
+                def __init__(self, ids):
+                    self.ids = ids
+
+            return [E(list(e.ids[:-1]) + [1]) for e in out]   # last id wrong
+
+    for mode in ("wrong", "raise"):
+        base = fresh()
+
+        class Broken(type(base)):
+            @property
+            def backend_tokenizer(self):
+                return Proxy(super().backend_tokenizer, mode)
+
+        base.__class__ = Broken
+        r2, l2 = hf_token_rows(base, texts)
+        assert base._tt_backend_ids is False and np.array_equal(r2, rows) and np.array_equal(l2, lens)
+        r3, _ = hf_token_rows(base, texts[:5])      # and stays on the public call
+        assert np.array_equal(r3[:, : rows.shape[1]][r3[:, : rows.shape[1]] != PAD32], rows[:5][rows[:5] != PAD32])

@@ -51,8 +51,18 @@ def _string_batches(args, B, S, V, tok):
 
     n = args.steps * B
     t0 = time.perf_counter()
-    queries = synthetic_texts(n, S - 2, V, 1234, args.zipf)
-    positives = synthetic_texts(n, S - 2, V, 4321, args.zipf)
+    if args.ragged:  # MS-MARCO-like lengths (bench_eval.MarcoLike): queries of 6-16 tokens, passages of 32-128
+        rng = np.random.default_rng(99)
+
+        def ragged(lo, hi, seed):
+            words = rng.integers(lo, hi + 1, size=n)
+            by_len = {int(w): iter(synthetic_texts(int((words == w).sum()), int(w), V, seed + int(w), args.zipf)) for w in np.unique(words)}
+            return [next(by_len[int(w)]) for w in words]
+
+        queries, positives = ragged(4, 14, 1234), ragged(30, S - 2, 4321)
+    else:
+        queries = synthetic_texts(n, S - 2, V, 1234, args.zipf)
+        positives = synthetic_texts(n, S - 2, V, 4321, args.zipf)
     items = [{"query_id": i, "query": q, "positive": p} for i, (q, p) in enumerate(zip(queries, positives))]
     build_s = time.perf_counter() - t0
 
@@ -146,7 +156,8 @@ def run_module_path(args, device, CONFIGS, make_ids) -> dict:
                            + "; epoch 1 (tokenises every text once) in `epochs`; NOT the BASELINE metric"),
                 "value": best["triplets_per_s"], "ms_per_step": best["us_per_batch"] / 1e3,
                 "config": {**config, "strings": args.strings, "text_cache": bool(args.text_cache), "items": n_items,
-                           "texts": 2 * n_items, "tokens_per_text": S, "ids": "zipf" if args.zipf else "uniform",
+                           "texts": 2 * n_items, "tokens_per_text": ("queries 6-16, passages 32-%d" % S) if args.ragged else S,
+                           "ids": "zipf" if args.zipf else "uniform",
                            "tokenizer": "transformers.BertTokenizerFast over a synthetic vocab.txt of V words",
                            "host_threads": os.cpu_count(), "dataset_build_s": build_s},
                 "epochs": epochs, "first_epoch": epochs[0],

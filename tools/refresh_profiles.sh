@@ -16,6 +16,7 @@ $B --zipf > $out/${r}_bench_c2_zipf.json
 $B --inputs index > $out/${r}_bench_c2_inputs_index.json
 $B --inputs cache > $out/${r}_bench_c2_inputs_cache.json
 $B --e2e --steps 1000 > $out/${r}_bench_c2_e2e_epoch1000.json
+$B --h2d > $out/${r}_bench_c2_h2d.json                                   # PCIe-inclusive: ids from pinned host memory every step
 $B --path module --steps 400 --warmup 50 > $out/${r}_bench_c2_module_path.json                         # the reference's own torch.optim.Adam, routed
 $B --path module --optimizer fused --steps 400 --warmup 50 > $out/${r}_bench_c2_module_path_fused_adam.json
 $B --path module-unfused --steps 200 > $out/${r}_bench_c2_module_unfused.json
